@@ -1,0 +1,117 @@
+/*
+ * shine_hip.h — C ABI of libshine_hip.so: the MI355X (gfx950) SHINE SDF training hot path.
+ *
+ * The reference (PRBonn/SHINE_mapping) has no FFI of its own: its hot path is the Python
+ * surface the two drivers import (shine_batch.py:13-20, shine_incre.py:12-20).  Each entry
+ * point below names the reference function(s) it replaces; the Python host side in
+ * shine_mapping_amd/ binds them with ctypes and re-exposes the reference's class surface.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every data pointer is DEVICE memory unless it says "host";
+ *  - all work is enqueued on the caller's HIP stream (void* = hipStream_t), no host sync inside
+ *    the per-iteration calls (shine_query / shine_train_step / shine_interp_*), no hidden
+ *    allocation there either (graph-capturable);
+ *  - return 0 on success, a negative SHINE_E_* code otherwise (never throws);
+ *    shine_error_string() explains it; HIP failures carry hipGetErrorString text;
+ *  - featured levels are addressed by "slot" s = 0..L-1, TOP-DOWN like hier_features
+ *    (model/feature_octree.py:61-63): slot L-1 is the leaf level (= tree_level_world),
+ *    slot s is absolute level  tree_level_world - (L-1-s);
+ *  - feature tables are [rows_s + 1, F] fp32 row-major, the LAST row is the reference's
+ *    "trash bin" that index -1 addresses (model/feature_octree.py:76-81,205);
+ *  - F (feature_dim) = 8 and H (hidden) = 32, 2 hidden layers: the only decoder shape any
+ *    shipped config uses (config/ all yamls: feature_dim 8, mlp_hidden_dim 32, mlp_level 2).
+ */
+#ifndef SHINE_HIP_H_
+#define SHINE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHINE_MAX_LEVELS 8
+#define SHINE_FEATURE_DIM 8
+#define SHINE_HIDDEN_DIM 32
+/* packed decoder parameter count: W1[32,8] b1[32] W2[32,32] b2[32] w3[32] b3[1] */
+#define SHINE_MLP_PARAMS 1377
+
+#define SHINE_OK 0
+#define SHINE_E_INVALID (-1)   /* bad argument (null pointer, level out of range, unsupported shape) */
+#define SHINE_E_HIP (-2)       /* a HIP runtime call failed; see shine_error_string */
+#define SHINE_E_NOMEM (-3)     /* device allocation failed */
+#define SHINE_E_STATE (-4)     /* table handle in the wrong state (e.g. level never built) */
+
+typedef struct shine_tables shine_tables; /* opaque: device hash tables node-morton -> 8 corner ids */
+
+/* scalar configuration of one hot-path call (plain-old-data, passed by pointer from the host) */
+typedef struct shine_step_config {
+  int32_t n_levels;        /* L = tree_level_feat                      (utils/config.py:78)  */
+  int32_t max_level;       /* tree_level_world                         (utils/config.py:77)  */
+  int32_t poly_int_on;     /* smooth-step interpolation                (feature_octree.py:176-179) */
+  int32_t reduction_sum;   /* 0: "mean", 1: "sum"                      (utils/loss.py:17-24, shine_incre.py:77-78) */
+  int32_t eikonal_on;      /* closed-form eikonal term                 (shine_batch.py:141-142,182-185) */
+  int32_t decoder_grad_on; /* 0 when the decoder is frozen             (utils/tools.py:188-191) */
+  int32_t sorted_input;    /* points are visited through perm[] (Morton order) when non-zero */
+  int32_t reserved0;
+  float sigma;             /* sigma_sigmoid = ratio*sigma_m*scale      (shine_batch.py:87) */
+  float weight_e;          /* eikonal weight                           (config weight_e) */
+  double inv_n;            /* 1/N_global for "mean", 1 for "sum"       */
+  int64_t n_global;        /* global batch size (data parallel)        */
+} shine_step_config;
+
+/* ---- library ------------------------------------------------------------------------- */
+int shine_version(void);
+const char* shine_error_string(int code);
+
+/* ---- lookup tables: replace the python dicts nodes_lookup_tables[level]
+ *      (model/feature_octree.py:47-52, filled at :162-166, read at :209) ------------------ */
+int shine_tables_create(int32_t n_levels, shine_tables** out);
+int shine_tables_destroy(shine_tables* t);
+/* insert n NEW nodes of one level: keys = kaolin-convention Morton codes (x MSB per triplet),
+ * corner_ids[n,8] = feature-row ids in the corner order of interpolat (:186-193).  Grows/rehashes
+ * as needed (this call may synchronise the stream; it runs per frame, not per iteration). */
+int shine_tables_insert(shine_tables* t, int32_t slot, const int64_t* keys, const int32_t* corner_ids,
+                        int64_t n, void* stream);
+int shine_tables_stats(const shine_tables* t, int32_t slot, int64_t* capacity, int64_t* count);
+
+/* ---- FeatureOctree.get_indices (model/feature_octree.py:199-218):
+ *      idx_out[i] for i = 0..L-1 BOTTOM-UP (i = 0 leaf) each [N,8] int64, -1 on miss --------- */
+int shine_query_indices(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,
+                        int64_t* const* idx_out /* host array of L device pointers */, void* stream);
+
+/* ---- forward only: FeatureOctree.query_feature (:237-244) + Decoder.sdf (model/decoder.py:49-63).
+ *      feats: host array of L device pointers (top-down), rows: host array of L row counts
+ *      (without the trash row).  mlp: 6 device pointers W1,b1,W2,b2,w3,b3 (host array).
+ *      Any of feat_out [N,8], pred_out [N], idx_out (as above), grad_x_out [N,3]
+ *      (= d pred / d coord * sigma, utils/tools.py:175-185) may be NULL. ---------------------- */
+int shine_forward(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,
+                  const float* const* feats, const int64_t* rows, const float* const* mlp, float* feat_out,
+                  float* pred_out, int64_t* const* idx_out, float* grad_x_out, void* stream);
+
+/* ---- fused training step: query + decode + sdf_bce_loss (utils/loss.py:17-24) [+ eikonal
+ *      (shine_batch.py:182-185)] + the whole backward (shine_batch.py:208-209) in one pass.
+ *      Inputs : coord [N,3], sdf_label [N], weight [N] (sign = surface/free, data_sampler.py:102-103),
+ *               perm [N] int32 or NULL, n_surf: device int64 (global #weight>0) or NULL when eikonal off.
+ *      Outputs: pred [N]; grad_x [N,3] or NULL; grad_feats[s] [rows_s+1, 8] and grad_mlp[6]
+ *               ACCUMULATED INTO (caller zero-fills; matches autograd's dense grads incl. the
+ *               trash row); loss_parts: device double[4] accumulated into:
+ *               [0] BCE term (already reduced per cfg), [1] eikonal mean term (unweighted),
+ *               [2] number of points processed, [3] reserved. --------------------------------- */
+int shine_train_step(const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                     const float* sdf_label, const float* weight, const int32_t* perm, const int64_t* n_surf,
+                     int64_t n, const float* const* feats, const int64_t* rows, const float* const* mlp,
+                     float* pred_out, float* grad_x_out, float* const* grad_feats, float* const* grad_mlp,
+                     double* loss_parts, void* stream);
+
+/* ---- Morton ordering of a batch: the new step right after LiDARDataset.get_batch
+ *      (dataset/lidar_dataset.py:430-450).  perm_out[N] int32 = argsort of the leaf-level node keys, to be
+ *      passed as `perm` to shine_train_step.  Call with workspace == NULL to get the required bytes. --- */
+int shine_morton_sort(const shine_step_config* cfg, const float* coord, int64_t n, int32_t* perm_out,
+                      void* workspace, size_t* workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHINE_HIP_H_ */

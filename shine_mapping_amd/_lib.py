@@ -1,0 +1,109 @@
+"""ctypes binding of libshine_hip.so (the C ABI declared in include/shine_hip.h).
+
+The library is the product path.  If it is missing or fails to load this module raises — there is no
+CPU or PyTorch fallback anywhere in shine_mapping_amd.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libshine_hip.so")
+
+MAX_LEVELS = 8
+FEATURE_DIM = 8
+HIDDEN_DIM = 32
+MLP_PARAMS = 1377
+
+
+class StepConfig(C.Structure):
+    """struct shine_step_config (include/shine_hip.h)."""
+
+    _fields_ = [
+        ("n_levels", C.c_int32),
+        ("max_level", C.c_int32),
+        ("poly_int_on", C.c_int32),
+        ("reduction_sum", C.c_int32),
+        ("eikonal_on", C.c_int32),
+        ("decoder_grad_on", C.c_int32),
+        ("sorted_input", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("sigma", C.c_float),
+        ("weight_e", C.c_float),
+        ("inv_n", C.c_double),
+        ("n_global", C.c_int64),
+    ]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "shine_version": (C.c_int, []),
+    "shine_error_string": (C.c_char_p, [C.c_int]),
+    "shine_tables_create": (C.c_int, [C.c_int32, C.POINTER(_P)]),
+    "shine_tables_destroy": (C.c_int, [_P]),
+    "shine_tables_insert": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, _P]),
+    "shine_tables_stats": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "shine_query_indices": (C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), _P]),
+    "shine_forward": (
+        C.c_int,
+        [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, _P,
+         C.POINTER(_P), _P, _P],
+    ),
+    "shine_train_step": (
+        C.c_int,
+        [_P, C.POINTER(StepConfig), _P, _P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64),
+         C.POINTER(_P), _P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P],
+    ),
+    "shine_morton_sort": (C.c_int, [C.POINTER(StepConfig), _P, C.c_int64, _P, _P, C.POINTER(C.c_size_t), _P]),
+}
+
+_lib = None
+
+
+class ShineHipError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Every symbol include/shine_hip.h declares (checked by tests/test_abi.py against the header text)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ShineHipError(
+            "libshine_hip.so not found at %s — build it with `python -m shine_mapping_amd.build` "
+            "(there is no fallback path)" % LIB_PATH
+        )
+    h = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(h, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    _lib = h
+    return h
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = lib().shine_error_string(code)
+        raise ShineHipError("%s failed (%d): %s" % (what or "libshine_hip call", code, (msg or b"").decode()))
+
+
+def ptr_array(ptrs):
+    """host array of device pointers (None -> NULL)."""
+    arr = (_P * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p if p else None
+    return arr
+
+
+def i64_array(vals):
+    arr = (C.c_int64 * len(vals))()
+    for i, v in enumerate(vals):
+        arr[i] = int(v)
+    return arr

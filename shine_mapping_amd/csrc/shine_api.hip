@@ -1,0 +1,54 @@
+// shine_api.hip — library-level entry points of libshine_hip.so (version, errors, kernel dispatch).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "shine_internal.hpp"
+
+namespace shine {
+
+static thread_local char g_err[512] = "ok";
+static thread_local int g_err_code = 0;
+
+int set_error(int code, const char* msg) {
+  g_err_code = code;
+  snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+  return code;
+}
+
+int set_hip_error(hipError_t e, const char* what) {
+  g_err_code = SHINE_E_HIP;
+  snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what ? what : "?");
+  return SHINE_E_HIP;
+}
+
+}  // namespace shine
+
+extern "C" int shine_train_step_v0(const shine_tables*, const shine_step_config*, const float*, const float*,
+                                   const float*, const int32_t*, const int64_t*, int64_t, const float* const*,
+                                   const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
+                                   double*, void*);
+
+extern "C" int shine_version(void) { return 100; }
+
+extern "C" const char* shine_error_string(int code) {
+  if (code == SHINE_OK) return "ok";
+  if (code == shine::g_err_code) return shine::g_err;
+  switch (code) {
+    case SHINE_E_INVALID: return "invalid argument";
+    case SHINE_E_HIP: return "HIP runtime error";
+    case SHINE_E_NOMEM: return "out of device memory";
+    case SHINE_E_STATE: return "table handle in the wrong state";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                                const float* sdf_label, const float* weight, const int32_t* perm,
+                                const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,
+                                const float* const* mlp, float* pred_out, float* grad_x_out, float* const* grad_feats,
+                                float* const* grad_mlp, double* loss_parts, void* stream) {
+  if (!cfg) return shine::set_error(SHINE_E_INVALID, "shine_train_step: null config");
+  return shine_train_step_v0(t, cfg, coord, sdf_label, weight, perm, n_surf, n, feats, rows, mlp, pred_out,
+                             grad_x_out, grad_feats, grad_mlp, loss_parts, stream);
+}

@@ -1,0 +1,64 @@
+// shine_internal.hpp — host-side state shared by the translation units of libshine_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <new>
+
+#include "shine_device.hpp"
+
+namespace shine {
+
+struct TableLevel {
+  unsigned long long* keys = nullptr;
+  int* vals = nullptr;
+  long long cap = 0;
+  long long count = 0;
+  unsigned int shift = 0;
+  unsigned int mask = 0;
+};
+
+int set_error(int code, const char* msg);
+int set_hip_error(hipError_t e, const char* what);
+
+}  // namespace shine
+
+struct shine_tables {
+  int n_levels = 0;
+  shine::TableLevel lv[SHINE_MAX_LEVELS];
+};
+
+#define SHINE_HIP_CHECK(expr)                                      \
+  do {                                                             \
+    hipError_t e__ = (expr);                                       \
+    if (e__ != hipSuccess) return shine::set_hip_error(e__, #expr); \
+  } while (0)
+
+namespace shine {
+
+// Fill the kernel-side level descriptors from the handle + the caller's feature/grad pointers.
+// Returns SHINE_OK or an error code (message set).
+inline int make_level_set(const shine_tables* t, const shine_step_config* cfg, const float* const* feats,
+                          const int64_t* rows, float* const* grads, LevelSet* out) {
+  if (!t || !cfg) return set_error(SHINE_E_INVALID, "null tables/config");
+  const int L = cfg->n_levels;
+  if (L < 1 || L > SHINE_MAX_LEVELS || L != t->n_levels) return set_error(SHINE_E_INVALID, "n_levels mismatch");
+  if (cfg->max_level < L || cfg->max_level > 15) return set_error(SHINE_E_INVALID, "max_level out of range (<=15)");
+  for (int s = 0; s < L; ++s) {
+    const TableLevel& T = t->lv[s];
+    if (!T.keys) return set_error(SHINE_E_STATE, "a featured level has no table yet (call shine_tables_insert)");
+    LevelDev& D = out->lv[s];
+    D.keys = T.keys;
+    D.vals = reinterpret_cast<const int4*>(T.vals);
+    D.feat = feats ? feats[s] : nullptr;
+    D.grad = grads ? grads[s] : nullptr;
+    D.rows = rows ? rows[s] : 0;
+    D.shift = T.shift;
+    D.mask = T.mask;
+    const int level = cfg->max_level - (L - 1 - s);
+    D.res = (float)(1u << level);
+    D.dres = D.res * 0.5f;
+  }
+  return SHINE_OK;
+}
+
+}  // namespace shine

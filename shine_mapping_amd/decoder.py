@@ -1,0 +1,73 @@
+"""Decoder — host-side mirror of model/decoder.py:9-101 (geo decoder; `sdf` is the hot-path method).
+
+Same constructor signature, same sub-module names (so ``pretrained/geo_decoder_8dim.pth`` and the
+reference's checkpoints load with ``load_state_dict``): ``layers.{0,1}``, ``lout``, ``nclass_out``.
+`sdf` stays a differentiable torch composite for the strict drop-in tier (it is three tiny GEMMs and
+must be twice differentiable for get_gradient, utils/tools.py:175-185); the benchmarked tier never
+calls it — the fused HIP step reads the six parameter tensors directly (ops.fused_train_step).
+The out-of-scope heads (time-conditioned, semantic; flags off in every shipped yaml) are plain torch.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+class Decoder(nn.Module):
+    def __init__(self, config, is_geo_encoder=True, is_time_conditioned=False):
+        super().__init__()
+        if is_geo_encoder:
+            hidden, bias_on, level = config.geo_mlp_hidden_dim, config.geo_mlp_bias_on, config.geo_mlp_level
+        else:
+            hidden, bias_on, level = config.sem_mlp_hidden_dim, config.sem_mlp_bias_on, config.sem_mlp_level
+        in_dim = config.feature_dim + (1 if is_time_conditioned else 0)
+        self.layers = nn.ModuleList(
+            [nn.Linear(in_dim if i == 0 else hidden, hidden, bias_on) for i in range(level)]
+        )
+        self.lout = nn.Linear(hidden, 1, bias_on)
+        self.nclass_out = nn.Linear(hidden, config.sem_class_count + 1, bias_on)
+        self.fusable = (
+            level == 2 and hidden == _lib.HIDDEN_DIM and in_dim == _lib.FEATURE_DIM and bias_on
+            and not is_time_conditioned
+        )
+        self.to(config.device)
+
+    def forward(self, feature):
+        return self.sdf(feature)
+
+    # model/decoder.py:49-63
+    def sdf(self, sum_features):
+        h = sum_features
+        for l in self.layers:
+            h = F.relu(l(h))
+        return self.lout(h).squeeze(1)
+
+    # model/decoder.py:65-81
+    def time_conditionded_sdf(self, sum_features, ts):
+        h = torch.cat((sum_features, ts.view(-1, 1)), dim=1)
+        for l in self.layers:
+            h = F.relu(l(h))
+        return self.lout(h).squeeze(1)
+
+    # model/decoder.py:84-86
+    def occupancy(self, sum_features):
+        return torch.sigmoid(self.sdf(sum_features))
+
+    # model/decoder.py:89-101
+    def sem_label_prob(self, sum_features):
+        h = sum_features
+        for l in self.layers:
+            h = F.relu(l(h))
+        return F.log_softmax(self.nclass_out(h), dim=1)
+
+    def sem_label(self, sum_features):
+        return torch.argmax(self.sem_label_prob(sum_features), dim=1)
+
+    # ---- fused-path plumbing
+    def fused_params(self):
+        """W1,b1,W2,b2,w3,b3 in the order libshine_hip expects."""
+        if not self.fusable:
+            raise NotImplementedError("fused HIP decoder supports 8 -> 32 -> 32 -> 1 with bias (every shipped config)")
+        return [self.layers[0].weight, self.layers[0].bias, self.layers[1].weight, self.layers[1].bias,
+                self.lout.weight, self.lout.bias]

@@ -1,0 +1,81 @@
+"""Data-parallel plumbing around the fused step and the Morton ordering of a batch.
+
+The reference is single-GPU (utils/tools.py:26) and has no collective; this is new design:
+one process per GPU, replicated feature tables + decoder, each rank runs the fused step on its shard of
+the global batch, then ONE flat all-reduce(sum) of the dense grads (decoder 1377 floats + the L feature-grad
+tables) over RCCL/xGMI, after which every rank applies the identical dense Adam step (replicas stay
+bit-identical without a broadcast).  Normalisers use the GLOBAL batch size / surface count
+(StepOptions.n_global, all_reduce_scalar) so the summed shard gradients equal the single-GPU gradient.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class GradReducer:
+    """Flat-bucket gradient all-reduce.  `dist` is torch.distributed (backend nccl = RCCL on ROCm, gloo in CPU tests)."""
+
+    def __init__(self, params, dist, group=None):
+        self.params = list(params)
+        self.dist = dist
+        self.group = group
+        self._flat = None
+        self._views = None
+
+    def _ensure_flat(self):
+        """Re-home every .grad as a view into one flat buffer so the collective is a single large message
+        (xGMI is point-to-point: few big messages beat many small ones)."""
+        total = sum(p.numel() for p in self.params)
+        stale = self._flat is None or self._flat.numel() != total or any(
+            p.grad is None or p.grad.data_ptr() != v.data_ptr() for p, v in zip(self.params, self._views)
+        )
+        if not stale:
+            return
+        dev = self.params[0].device
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for p in self.params:
+            v = flat[off: off + p.numel()].view_as(p)
+            if p.grad is not None:
+                v.copy_(p.grad)
+            p.grad = v
+            views.append(v)
+            off += p.numel()
+        self._flat, self._views = flat, views
+
+    def all_reduce_grads(self):
+        self._ensure_flat()
+        self.dist.all_reduce(self._flat, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def all_reduce_scalar(self, t: torch.Tensor):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+_WS = {}
+
+
+def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
+    """argsort of the batch by leaf-level node Morton key -> int32 perm [N] (device; no host sync)."""
+    coord = octree._check_coord(coord.detach())
+    n = coord.shape[0]
+    cfg = octree.step_config()
+    need = C.c_size_t(0)
+    lib = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.shine_morton_sort(C.byref(cfg), None, n, None, None, C.byref(need), stream), "shine_morton_sort")
+    key = (str(coord.device), int(need.value))
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.empty(int(need.value), dtype=torch.uint8, device=coord.device)
+        _WS[key] = ws
+    perm = torch.empty(n, dtype=torch.int32, device=coord.device)
+    _lib.check(
+        lib.shine_morton_sort(C.byref(cfg), coord.data_ptr(), n, perm.data_ptr(), ws.data_ptr(), C.byref(need), stream),
+        "shine_morton_sort",
+    )
+    return perm

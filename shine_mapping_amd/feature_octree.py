@@ -1,0 +1,384 @@
+"""FeatureOctree — host-side mirror of the reference class, backed by libshine_hip.so.
+
+Same constructor, attributes and methods as model/feature_octree.py:29-298 (the surface the drivers,
+the mesher and cal_feature_importance touch — SURVEY.md §8b), but:
+
+  * the per-level python dicts ``nodes_lookup_tables`` are replaced by device hash tables owned by the
+    library (node Morton -> 8 corner ids); dict *views* are still available for code that reads them
+    (utils/mesher.py, checkpoints) and are rebuilt lazily;
+  * ``update`` (:114-166) is vectorised on the host (unique/searchsorted instead of per-node Python
+    loops) and reproduces the reference's corner-id assignment exactly: ids are appended per call in
+    lexicographic (x,y,z) order of the new nodes' unique corners (:132-137,148-151);
+  * ``get_indices`` / ``query_feature`` run on the GPU with no host round trip (the reference crosses
+    the device boundary twice per level, :204,215).
+
+There is no CPU fallback: every query goes through the HIP library and raises if it is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_CORNER_OFFSETS = np.array([[(j >> 2) & 1, (j >> 1) & 1, j & 1] for j in range(8)], dtype=np.int64)
+
+
+# --------------------------------------------------------------------------- integer helpers (host, numpy int64)
+
+
+def _spread3(v: np.ndarray) -> np.ndarray:
+    x = v.astype(np.uint64) & np.uint64(0xFFFF)
+    x = (x | (x << np.uint64(32))) & np.uint64(0x001F00000000FFFF)
+    x = (x | (x << np.uint64(16))) & np.uint64(0x001F0000FF0000FF)
+    x = (x | (x << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+    x = (x | (x << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+    x = (x | (x << np.uint64(2))) & np.uint64(0x1249249249249249)
+    return x
+
+
+def _compact3(m: np.ndarray) -> np.ndarray:
+    x = m.astype(np.uint64) & np.uint64(0x1249249249249249)
+    x = (x | (x >> np.uint64(2))) & np.uint64(0x10C30C30C30C30C3)
+    x = (x | (x >> np.uint64(4))) & np.uint64(0x100F00F00F00F00F)
+    x = (x | (x >> np.uint64(8))) & np.uint64(0x001F0000FF0000FF)
+    x = (x | (x >> np.uint64(16))) & np.uint64(0x001F00000000FFFF)
+    x = (x | (x >> np.uint64(32))) & np.uint64(0xFFFF)
+    return x
+
+
+def morton_encode(xyz: np.ndarray) -> np.ndarray:
+    """kaolin.ops.spc.points_to_morton convention: per bit triplet x is the MSB, z the LSB. -> int64"""
+    m = (_spread3(xyz[..., 0]) << np.uint64(2)) | (_spread3(xyz[..., 1]) << np.uint64(1)) | _spread3(xyz[..., 2])
+    return m.astype(np.int64)
+
+
+def morton_decode(m: np.ndarray) -> np.ndarray:
+    mu = m.astype(np.uint64)
+    return np.stack(
+        (_compact3(mu >> np.uint64(2)), _compact3(mu >> np.uint64(1)), _compact3(mu)), axis=-1
+    ).astype(np.int64)
+
+
+def _pack_lex(xyz: np.ndarray) -> np.ndarray:
+    """(x,y,z) -> one int64 whose ascending order is the lexicographic order torch.unique(dim=0) uses (:132)."""
+    return (xyz[..., 0] << 42) | (xyz[..., 1] << 21) | xyz[..., 2]
+
+
+def _unpack_lex(k: np.ndarray) -> np.ndarray:
+    return np.stack((k >> 42, (k >> 21) & 0x1FFFFF, k & 0x1FFFFF), axis=-1)
+
+
+class _DeviceTables:
+    """Owner of the library's shine_tables handle."""
+
+    def __init__(self, n_levels: int):
+        self.n_levels = n_levels
+        self.handle = C.c_void_p()
+        _lib.check(_lib.lib().shine_tables_create(n_levels, C.byref(self.handle)), "shine_tables_create")
+
+    def insert(self, slot: int, keys: torch.Tensor, ids: torch.Tensor):
+        assert keys.is_cuda and ids.is_cuda and keys.dtype == torch.int64 and ids.dtype == torch.int32
+        keys = keys.contiguous()
+        ids = ids.contiguous()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(
+            _lib.lib().shine_tables_insert(self.handle, slot, keys.data_ptr(), ids.data_ptr(), keys.numel(), stream),
+            "shine_tables_insert",
+        )
+        torch.cuda.current_stream().synchronize()  # keys/ids staging tensors may be freed by the caller
+
+    def stats(self, slot: int):
+        cap, cnt = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().shine_tables_stats(self.handle, slot, C.byref(cap), C.byref(cnt)), "shine_tables_stats")
+        return cap.value, cnt.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().shine_tables_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+
+class FeatureOctree(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        # model/feature_octree.py:35-44
+        self.max_level = config.tree_level_world
+        self.leaf_vox_size = config.leaf_vox_size
+        self.featured_level_num = config.tree_level_feat
+        self.free_level_num = self.max_level - self.featured_level_num + 1
+        self.feature_dim = config.feature_dim
+        self.feature_std = config.feature_std
+        self.polynomial_interpolation = config.poly_int_on
+        self.device = config.device
+        if self.featured_level_num < 1:
+            raise ValueError("No level with grid features!")  # :57-58
+        if self.feature_dim != _lib.FEATURE_DIM:
+            raise NotImplementedError("libshine_hip is built for feature_dim == 8 (every shipped config)")
+        if self.featured_level_num > _lib.MAX_LEVELS or self.max_level > 15:
+            raise NotImplementedError("at most 8 featured levels and tree_level_world <= 15")
+
+        L = self.featured_level_num
+        # host copies of the tables, per featured slot (top-down): everything the dict views need
+        self._node_keys = [np.zeros(0, np.int64) for _ in range(L)]       # insertion order
+        self._node_ids = [np.zeros((0, 8), np.int32) for _ in range(L)]   # insertion order
+        self._node_sorted = [np.zeros(0, np.int64) for _ in range(L)]     # sorted, for membership tests
+        self._corner_lex = [np.zeros(0, np.int64) for _ in range(L)]      # sorted lexicographic keys
+        self._corner_id_of_lex = [np.zeros(0, np.int64) for _ in range(L)]
+        self._corner_count = [0] * L
+        self._dict_cache = None
+        self._tables = None  # created at the first query (needs the GPU); update() itself is host-only
+        self._pending = [[] for _ in range(L)]  # (node keys, corner ids) not yet inserted on the device
+        # a level's regulariser contributes gradient only while its features_last_frame copy is detached
+        # (first-frame branch :146); the later branch :160 stores an attached clone -> zero net gradient.
+        self._reg_grad_on = [True] * L
+
+        self.hier_features = nn.ParameterList([])  # top-down  :63
+        self.hierarchical_indices = []  # bottom-up :67
+        self.importance_weight = []  # :71
+        self.features_last_frame = []  # :72
+        self.to(config.device)
+
+    # ------------------------------------------------------------------ dict views (compat)
+    def _build_dicts(self):
+        nodes = [dict() for _ in range(self.max_level + 1)]
+        corners = [dict() for _ in range(self.max_level + 1)]
+        for s in range(self.featured_level_num):
+            lvl = self.free_level_num + s
+            nodes[lvl] = dict(zip(self._node_keys[s].tolist(), self._node_ids[s].tolist()))
+            cm = morton_encode(_unpack_lex(self._corner_lex[s]))
+            corners[lvl] = dict(zip(cm.tolist(), self._corner_id_of_lex[s].tolist()))
+        self._dict_cache = (nodes, corners)
+
+    @property
+    def nodes_lookup_tables(self):
+        """list over absolute levels of {node morton: [8 corner ids]} (model/feature_octree.py:47-52)."""
+        if self._dict_cache is None:
+            self._build_dicts()
+        return self._dict_cache[0]
+
+    @property
+    def corners_lookup_tables(self):
+        if self._dict_cache is None:
+            self._build_dicts()
+        return self._dict_cache[1]
+
+    # ------------------------------------------------------------------ :78-81
+    def set_zero(self):
+        with torch.no_grad():
+            for n in range(len(self.hier_features)):
+                self.hier_features[n][-1] = 0.0
+
+    def forward(self, x):
+        return self.query_feature(x)
+
+    def is_empty(self):
+        return len(self.hier_features) == 0
+
+    def clear_temp(self):
+        self.hierarchical_indices = []
+        self.importance_weight = []
+        self.features_last_frame = []
+
+    # ------------------------------------------------------------------ :94-101
+    def get_octree_nodes(self, level):
+        s = level - self.free_level_num
+        xyz = morton_decode(self._node_keys[s]).astype(np.float64) if 0 <= s < self.featured_level_num else \
+            np.zeros((0, 3))
+        node_size = 2 ** (1 - level)
+        return (xyz * node_size) - 1.0 + 0.5 * node_size
+
+    # ------------------------------------------------------------------ :114-166
+    def update(self, surface_points: torch.Tensor, incremental_on: bool = False):
+        dev = self.hier_features[0].device if len(self.hier_features) else torch.device(self.device)
+        res = 2 ** self.max_level
+        # kaolin quantize_points, fp32, on whatever device the points live on
+        q = torch.floor(torch.clamp(res * (surface_points.float() + 1.0) / 2.0, 0, res - 1.0)).to(torch.int64)
+        leaf = np.unique(morton_encode(q.cpu().numpy()))
+        self._dict_cache = None
+        for s in range(self.featured_level_num):
+            lvl = self.free_level_num + s
+            nodes = np.unique(leaf >> (3 * (self.max_level - lvl)))  # Morton order, like point_hierarchies
+            known = self._node_sorted[s]
+            if known.size:
+                pos = np.searchsorted(known, nodes)
+                pos[pos == known.size] = 0
+                fresh = nodes[known[pos] != nodes]
+            else:
+                fresh = nodes
+            if fresh.size == 0:
+                continue  # :129-130
+            corners = morton_decode(fresh)[:, None, :] + _CORNER_OFFSETS[None, :, :]  # [M,8,3]
+            lex = _pack_lex(corners.reshape(-1, 3))
+            uniq = np.unique(lex)  # lexicographic (x,y,z)
+            first = self._corner_count[s] == 0
+            if first:
+                new_lex = uniq
+            else:
+                cpos = np.searchsorted(self._corner_lex[s], uniq)
+                cpos[cpos == self._corner_lex[s].size] = 0
+                new_lex = uniq[self._corner_lex[s][cpos] != uniq]
+            base = self._corner_count[s]
+            new_ids = np.arange(base, base + new_lex.size, dtype=np.int64)
+            merged = np.concatenate((self._corner_lex[s], new_lex))
+            merged_ids = np.concatenate((self._corner_id_of_lex[s], new_ids))
+            order = np.argsort(merged, kind="stable")
+            self._corner_lex[s] = merged[order]
+            self._corner_id_of_lex[s] = merged_ids[order]
+            self._corner_count[s] = base + new_lex.size
+            added = int(new_lex.size)
+
+            if first:  # :135-146
+                fts = self.feature_std * torch.randn(added + 1, self.feature_dim, device=dev)
+                fts[-1] = 0.0
+                self.hier_features.append(nn.Parameter(fts))
+                if incremental_on:
+                    self.importance_weight.append(torch.zeros(added + 1, self.feature_dim, device=dev))
+                    self.features_last_frame.append(fts.clone())
+                    self._reg_grad_on[s] = True
+            else:  # :147-160
+                new_fts = self.feature_std * torch.randn(added + 1, self.feature_dim, device=dev)
+                new_fts[-1] = 0.0
+                self.hier_features[s] = nn.Parameter(torch.cat((self.hier_features[s].detach()[:-1], new_fts), 0))
+                if incremental_on:
+                    new_w = torch.zeros(added + 1, self.feature_dim, device=dev)
+                    self.importance_weight[s] = torch.cat((self.importance_weight[s][:-1], new_w), 0)
+                    # the reference clones the Parameter itself (attached to the graph, :160): the regulariser
+                    # then adds to the loss value but its gradient cancels.  Kept.
+                    self.features_last_frame[s] = self.hier_features[s].clone()
+                    self._reg_grad_on[s] = False
+
+            ids = self._corner_id_of_lex[s][np.searchsorted(self._corner_lex[s], lex)].reshape(-1, 8).astype(np.int32)
+            self._node_keys[s] = np.concatenate((self._node_keys[s], fresh))
+            self._node_ids[s] = np.concatenate((self._node_ids[s], ids))
+            self._node_sorted[s] = np.sort(np.concatenate((known, fresh)))
+            self._pending[s].append((fresh, ids))  # uploaded to the device hash table at the next query
+
+    # ------------------------------------------------------------------ hot path plumbing
+    def _require_tables(self):
+        if len(self.hier_features) != self.featured_level_num:
+            raise RuntimeError("FeatureOctree is empty: call update() before querying")
+        if self._tables is None:
+            self._tables = _DeviceTables(self.featured_level_num)
+        dev = self.hier_features[0].device
+        for s in range(self.featured_level_num):
+            for keys, ids in self._pending[s]:
+                self._tables.insert(s, torch.from_numpy(keys).to(dev), torch.from_numpy(ids).to(dev))
+            self._pending[s] = []
+        return self._tables
+
+    def step_config(self, **kw) -> _lib.StepConfig:
+        cfg = _lib.StepConfig()
+        cfg.n_levels = self.featured_level_num
+        cfg.max_level = self.max_level
+        cfg.poly_int_on = 1 if self.polynomial_interpolation else 0
+        cfg.sigma = 1.0
+        cfg.inv_n = 1.0
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        return cfg
+
+    def feature_ptrs(self):
+        return _lib.ptr_array([p.data_ptr() for p in self.hier_features])
+
+    def row_counts(self):
+        return _lib.i64_array([p.shape[0] - 1 for p in self.hier_features])
+
+    @staticmethod
+    def _check_coord(coord):
+        if not (coord.is_cuda and coord.dtype == torch.float32 and coord.dim() == 2 and coord.shape[1] == 3):
+            raise ValueError("coord must be a CUDA float32 tensor of shape [N,3]")
+        return coord.contiguous()
+
+    # ------------------------------------------------------------------ :199-218
+    def get_indices(self, coord):
+        t = self._require_tables()
+        coord = self._check_coord(coord.detach())
+        n = coord.shape[0]
+        out = [torch.empty((n, 8), dtype=torch.int64, device=coord.device) for _ in range(self.featured_level_num)]
+        cfg = self.step_config()
+        _lib.check(
+            _lib.lib().shine_query_indices(
+                t.handle, C.byref(cfg), coord.data_ptr(), n, _lib.ptr_array([o.data_ptr() for o in out]),
+                torch.cuda.current_stream().cuda_stream,
+            ),
+            "shine_query_indices",
+        )
+        self.hierarchical_indices = out
+        return out
+
+    # ------------------------------------------------------------------ :237-244
+    def query_feature(self, coord, faster=False):
+        """`faster` (get_indices_fast, :267-286) is a CPU-side dedup trick; on the GPU both paths are the same."""
+        from .ops import octree_interp  # late import: ops imports this module's types
+
+        self.set_zero()
+        return octree_interp(self, coord)
+
+    # ------------------------------------------------------------------ :246-255
+    def cal_regularization(self):
+        regularization = 0.0
+        for i in range(self.featured_level_num):
+            feature_level = self.featured_level_num - i - 1
+            unique_indices = self.hierarchical_indices[i].flatten().unique()
+            difference = self.hier_features[feature_level][unique_indices] - \
+                self.features_last_frame[feature_level][unique_indices]
+            regularization = regularization + (self.importance_weight[feature_level][unique_indices] *
+                                               (difference ** 2)).sum()
+        return regularization
+
+    # ------------------------------------------------------------------ :288-298
+    def print_detail(self):
+        print("Current Octomap:")
+        total = 0
+        for level in range(self.featured_level_num):
+            size = self.leaf_vox_size * (2 ** (self.featured_level_num - 1 - level))
+            count = self.hier_features[level].shape[0]
+            print("%.2f m: %d voxel corners" % (size, count))
+            total += count
+        print("memory: %d x %d x 4 = %.3f MB" % (total, self.feature_dim, total * self.feature_dim * 4 / 1024 / 1024))
+        print("--------------------------------")
+
+    # ------------------------------------------------------------------ checkpoints (utils/tools.py:200-213 pickles the module)
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_tables"] = None
+        state["_dict_cache"] = None
+        state["_pending"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.rebuild_device_tables()
+
+    def rebuild_device_tables(self):
+        """Drop the library handle; it is re-created from the host copies at the next query
+        (after unpickling / device move)."""
+        self._tables = None
+        self._pending = [[(self._node_keys[s], self._node_ids[s])] if self._node_keys[s].size else []
+                         for s in range(self.featured_level_num)]
+
+    def load_tables(self, tables):
+        """Adopt externally built tables: per featured slot (top-down) a (node_morton[int64 n], corner_ids[int32 n,8])
+        pair, e.g. from a reference checkpoint's nodes_lookup_tables.  Feature rows must be set by the caller."""
+        self._tables = None
+        self._dict_cache = None
+        for s, (keys, ids) in enumerate(tables):
+            keys_np = keys.cpu().numpy().astype(np.int64)
+            ids_np = ids.cpu().numpy().astype(np.int32).reshape(-1, 8)
+            self._node_keys[s], self._node_ids[s] = keys_np, ids_np
+            self._node_sorted[s] = np.sort(keys_np)
+            corners = morton_decode(keys_np)[:, None, :] + _CORNER_OFFSETS[None, :, :]
+            lex = _pack_lex(corners.reshape(-1, 3))
+            uniq, first_idx = np.unique(lex, return_index=True)
+            self._corner_lex[s] = uniq
+            self._corner_id_of_lex[s] = ids_np.reshape(-1)[first_idx].astype(np.int64)
+            self._corner_count[s] = int(ids_np.max()) + 1 if ids_np.size else 0
+        self.rebuild_device_tables()

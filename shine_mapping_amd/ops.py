@@ -1,0 +1,185 @@
+"""Operators of the SHINE hot path on top of libshine_hip.so.
+
+Tier B (fused, benchmarked):  ``fused_train_step`` = query + decode + sdf_bce_loss (+ eikonal) + the
+whole backward in one HIP pass, writing dense ``.grad`` tensors exactly where autograd would
+(shine_batch.py:115-209 minus the optimiser).
+
+Tier A (strict drop-in):      ``octree_interp`` = FeatureOctree.query_feature as an autograd op
+(model/feature_octree.py:237-244) so the reference drivers run unchanged.
+
+Every function here calls the HIP library; none has a CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class StepOptions:
+    """Scalars of one training iteration (names follow utils/config.py)."""
+
+    sigma: float                      # sigma_sigmoid = logistic_gaussian_ratio*sigma_sigmoid_m*scale (shine_batch.py:87)
+    loss_reduction: str = "mean"      # "mean" | "sum" (shine_incre.py:77-78)
+    ekional_loss_on: bool = False     # (sic) config key of the reference
+    weight_e: float = 0.1
+    n_global: Optional[int] = None    # global batch size under data parallelism (defaults to local N)
+    decoder_grad_on: Optional[bool] = None  # default: any decoder parameter requires grad (freeze_model, tools.py:188)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise ValueError("%s must be a CUDA float32 tensor" % name)
+    return t.contiguous()
+
+
+def _dense_grad(p: torch.Tensor) -> torch.Tensor:
+    """autograd hands the optimiser a dense zero-initialised grad of the parameter's shape; so do we."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+def forward_sdf(octree, decoder, coord, want_feat=False, want_indices=False, want_grad_x=False, sigma=1.0):
+    """query_feature + Decoder.sdf, forward only (utils/mesher.py:69-72 style inference).
+
+    Returns dict(pred[N], feat[N,8]|None, indices (bottom-up list)|None, grad_x[N,3]|None = d pred/d coord * sigma).
+    """
+    t = octree._require_tables()
+    coord = octree._check_coord(coord.detach())
+    n = coord.shape[0]
+    dev = coord.device
+    pred = torch.empty(n, dtype=torch.float32, device=dev)
+    feat = torch.empty((n, 8), dtype=torch.float32, device=dev) if want_feat else None
+    gx = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_grad_x else None
+    idx = None
+    if want_indices:
+        idx = [torch.empty((n, 8), dtype=torch.int64, device=dev) for _ in range(octree.featured_level_num)]
+    octree.set_zero()
+    cfg = octree.step_config(sigma=float(sigma))
+    mlp = [p.detach() for p in decoder.fused_params()]
+    _lib.check(
+        _lib.lib().shine_forward(
+            t.handle, C.byref(cfg), coord.data_ptr(), n, octree.feature_ptrs(), octree.row_counts(),
+            _lib.ptr_array([p.data_ptr() for p in mlp]),
+            feat.data_ptr() if feat is not None else None, pred.data_ptr(),
+            _lib.ptr_array([o.data_ptr() for o in idx]) if idx is not None else None,
+            gx.data_ptr() if gx is not None else None, _stream(),
+        ),
+        "shine_forward",
+    )
+    if idx is not None:
+        octree.hierarchical_indices = idx
+    return dict(pred=pred, feat=feat, indices=idx, grad_x=gx)
+
+
+def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
+                     n_surf: Optional[torch.Tensor] = None):
+    """One training iteration's forward+backward (no optimiser): the fused Tier-B step.
+
+    coord [N,3], sdf_label [N], weight [N] (sign: + surface / - free space, utils/data_sampler.py:102-103).
+    Accumulates into ``.grad`` of octree.hier_features[*] and the six decoder tensors (dense, trash row
+    included — what ``cur_loss.backward()`` produces, shine_batch.py:209).  Returns (loss, pred, g) where
+    loss is a 0-dim device tensor (no host sync) and g = get_gradient(coord,pred)*sigma or None.
+    """
+    t = octree._require_tables()
+    coord = octree._check_coord(coord.detach())
+    n = coord.shape[0]
+    dev = coord.device
+    sdf_label = _f32(sdf_label, "sdf_label")
+    eik = bool(opts.ekional_loss_on)
+    if eik or weight is not None:
+        weight = _f32(weight, "weight")
+    if opts.loss_reduction not in ("mean", "sum"):
+        raise ValueError("loss_reduction must be 'mean' or 'sum'")
+    n_global = int(opts.n_global) if opts.n_global else n
+    params = decoder.fused_params()
+    dec_grad = opts.decoder_grad_on
+    if dec_grad is None:
+        dec_grad = any(p.requires_grad for p in params)
+    cfg = octree.step_config(
+        sigma=float(opts.sigma), weight_e=float(opts.weight_e), eikonal_on=1 if eik else 0,
+        reduction_sum=1 if opts.loss_reduction == "sum" else 0, decoder_grad_on=1 if dec_grad else 0,
+        sorted_input=0 if perm is None else 1, n_global=n_global,
+        inv_n=(1.0 if opts.loss_reduction == "sum" else 1.0 / max(n_global, 1)),
+    )
+    if eik and n_surf is None:
+        n_surf = (weight > 0).sum()  # stays on the device; under DP the caller all-reduces it first
+    pred = torch.empty(n, dtype=torch.float32, device=dev)
+    gx = torch.empty((n, 3), dtype=torch.float32, device=dev) if (want_grad_x and eik) else None
+    loss_parts = torch.zeros(4, dtype=torch.float64, device=dev)
+    octree.set_zero()
+    gfeat = [_dense_grad(p) if p.requires_grad else None for p in octree.hier_features]
+    gmlp = [_dense_grad(p) for p in params] if dec_grad else [None] * 6
+    if perm is not None and not (perm.is_cuda and perm.dtype == torch.int32 and perm.numel() == n):
+        raise ValueError("perm must be a CUDA int32 tensor of N entries")
+    _lib.check(
+        _lib.lib().shine_train_step(
+            t.handle, C.byref(cfg), coord.data_ptr(), sdf_label.data_ptr(),
+            weight.data_ptr() if weight is not None else None,
+            perm.data_ptr() if perm is not None else None,
+            n_surf.data_ptr() if n_surf is not None else None, n,
+            octree.feature_ptrs(), octree.row_counts(),
+            _lib.ptr_array([p.data_ptr() for p in params]),
+            pred.data_ptr(), gx.data_ptr() if gx is not None else None,
+            _lib.ptr_array([g.data_ptr() if g is not None else None for g in gfeat]),
+            _lib.ptr_array([g.data_ptr() if g is not None else None for g in gmlp]),
+            loss_parts.data_ptr(), _stream(),
+        ),
+        "shine_train_step",
+    )
+    loss = loss_parts[0]
+    if eik:
+        loss = loss + float(opts.weight_e) * loss_parts[1]
+    return loss.to(torch.float32), pred, gx
+
+
+def octree_interp(octree, coord):
+    """FeatureOctree.query_feature (model/feature_octree.py:237-244) -> [N,8]; also fills hierarchical_indices."""
+    needs_grad = torch.is_grad_enabled() and (
+        coord.requires_grad or any(p.requires_grad for p in octree.hier_features)
+    )
+    if needs_grad:
+        from .autograd_ops import OctreeInterp  # Tier A
+
+        return OctreeInterp.apply(coord, octree, *list(octree.hier_features))
+    return _interp_forward(octree, coord)
+
+
+def _interp_forward(octree, coord):
+    t = octree._require_tables()
+    c = octree._check_coord(coord.detach())
+    n = c.shape[0]
+    feat = torch.empty((n, 8), dtype=torch.float32, device=c.device)
+    idx = [torch.empty((n, 8), dtype=torch.int64, device=c.device) for _ in range(octree.featured_level_num)]
+    cfg = octree.step_config()
+    dummy = _dummy_mlp(c.device)
+    _lib.check(
+        _lib.lib().shine_forward(
+            t.handle, C.byref(cfg), c.data_ptr(), n, octree.feature_ptrs(), octree.row_counts(),
+            _lib.ptr_array([p.data_ptr() for p in dummy]), feat.data_ptr(), None,
+            _lib.ptr_array([o.data_ptr() for o in idx]), None, _stream(),
+        ),
+        "shine_forward",
+    )
+    octree.hierarchical_indices = idx
+    return feat
+
+
+_DUMMY = {}
+
+
+def _dummy_mlp(dev):
+    key = str(dev)
+    if key not in _DUMMY:
+        _DUMMY[key] = [torch.zeros(s, dtype=torch.float32, device=dev) for s in (256, 32, 1024, 32, 32, 1)]
+    return _DUMMY[key]

@@ -1,0 +1,64 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+GOLDEN_NAMES = ["maicity_bce_L3", "maicity_bce_L4", "kitti_eik_L3", "ncd_reg_L3", "linear_L2_nopoly"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (authoring container only)")
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN_DIR, name + ".pt"), map_location="cpu", weights_only=False)
+
+
+@pytest.fixture(params=GOLDEN_NAMES)
+def golden(request):
+    return load_golden(request.param)
+
+
+def oracle_from_golden(fx):
+    """Rebuild the CPU oracle's octree + decoder from a fixture (tables, features, decoder weights)."""
+    from oracle import shine_oracle as so
+
+    cfg = so.make_config(**fx["cfg"])
+    oct_ = so.OracleOctree(cfg)
+    L = cfg.tree_level_feat
+    for s, (keys, ids) in enumerate(fx["tables"]):
+        lvl = oct_.free_level_num + s
+        oct_.node_table[lvl] = dict(zip(keys.tolist(), ids.tolist()))
+    oct_.hier_features = [f.clone().requires_grad_(True) for f in fx["features"]]
+    if fx["regularize"]:
+        oct_.importance_weight = [t.clone() for t in fx["importance"]]
+        # fixtures store values only; the attached-clone quirk (feature_octree.py:160) is re-created here
+        oct_.features_last_frame = [t.clone() for t in fx["features_last"]]
+    mlp = so.OracleDecoder(cfg)
+    mlp.load_state_dict(fx["decoder"])
+    assert len(oct_.hier_features) == L
+    return cfg, oct_, mlp
+
+
+def product_from_golden(fx, device="cuda"):
+    """Our FeatureOctree/Decoder loaded with a fixture's tables and weights."""
+    from shine_mapping_amd import Decoder, FeatureOctree, synth
+
+    cfg = synth.make_config("maicity", device=device, **fx["cfg"])
+    octree = FeatureOctree(cfg)
+    octree.load_tables(fx["tables"])
+    for f in fx["features"]:
+        octree.hier_features.append(torch.nn.Parameter(f.clone().to(device)))
+    if fx["regularize"]:
+        octree.importance_weight = [t.clone().to(device) for t in fx["importance"]]
+        octree.features_last_frame = [t.clone().to(device) for t in fx["features_last"]]
+    dec = Decoder(cfg)
+    dec.load_state_dict(fx["decoder"], strict=False)
+    return cfg, octree, dec

@@ -1,0 +1,51 @@
+"""CPU suite: the C-ABI library is built, loads, and exports every symbol include/shine_hip.h declares."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "shine_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(shine_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_something():
+    syms = declared_symbols()
+    assert "shine_train_step" in syms and "shine_forward" in syms and len(syms) >= 8
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from shine_mapping_amd import build
+
+    path = build.build(verbose=False)
+    assert os.path.isfile(path)
+    h = ctypes.CDLL(path)
+    for name in declared_symbols():
+        assert hasattr(h, name), "libshine_hip.so does not export %s" % name
+
+
+def test_binding_covers_the_header():
+    from shine_mapping_amd import _lib
+
+    assert _lib.exported_symbols() == declared_symbols()
+    lib = _lib.lib()
+    assert lib.shine_version() >= 100
+    assert lib.shine_error_string(0) == b"ok"
+
+
+def test_host_side_argument_errors_do_not_need_a_gpu():
+    from shine_mapping_amd import _lib
+
+    lib = _lib.lib()
+    out = ctypes.c_void_p()
+    assert lib.shine_tables_create(0, ctypes.byref(out)) == -1  # SHINE_E_INVALID
+    assert lib.shine_tables_create(3, ctypes.byref(out)) == 0
+    cap, cnt = ctypes.c_int64(-1), ctypes.c_int64(-1)
+    assert lib.shine_tables_stats(out, 0, ctypes.byref(cap), ctypes.byref(cnt)) == 0
+    assert (cap.value, cnt.value) == (0, 0)
+    assert lib.shine_tables_stats(out, 7, ctypes.byref(cap), ctypes.byref(cnt)) == -1
+    assert b"slot" in lib.shine_error_string(-1)
+    assert lib.shine_tables_destroy(out) == 0
