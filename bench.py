@@ -48,28 +48,40 @@ def cpu_baseline(args, wl, seconds=12.0):
     oct_.hier_features = [p.detach().cpu().clone().requires_grad_(True) for p in wl.octree.hier_features]
     mlp = so.OracleDecoder(ocfg)
     mlp.load_state_dict({k: v.cpu() for k, v in wl.decoder.state_dict().items()})
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    host_cores = os.cpu_count() or 1
     n = 4096
     g = torch.Generator().manual_seed(123)
     pool_n = wl.pool.sdf_label.shape[0]
-    done, t_used = 0, 0.0
-    it = 0
-    while t_used < seconds and it < 400:
-        idx = torch.randint(0, pool_n, (n,), generator=g)
-        c, l, w = wl.pool.coord[idx.to(wl.pool.coord.device)].cpu(), wl.pool.sdf_label[idx.to(wl.pool.coord.device)].cpu(), \
-            wl.pool.weight[idx.to(wl.pool.coord.device)].cpu()
+    pdev = wl.pool.coord.device
+
+    def one_iteration():
+        idx = torch.randint(0, pool_n, (n,), generator=g).to(pdev)
+        c, l, w = wl.pool.coord[idx].cpu(), wl.pool.sdf_label[idx].cpu(), wl.pool.weight[idx].cpu()
         t0 = time.perf_counter()
         so.train_step(oct_, mlp, c, l, w, ocfg)
-        dt = time.perf_counter() - t0
-        if it >= 2:  # two warm-up iterations
-            done += n
-            t_used += dt
+        return time.perf_counter() - t0
+
+    # torch's default (all host cores) is pathological for these small ops on a many-core host, so give the
+    # CPU path its best thread count: calibrate on one iteration each, then time with the winner.
+    best_t, best_threads = None, 1
+    for threads in sorted({host_cores, min(host_cores, 32), min(host_cores, 8), 1}, reverse=True):
+        torch.set_num_threads(threads)
+        one_iteration()  # warm-up at this thread count
+        dt = one_iteration()
+        if best_t is None or dt < best_t:
+            best_t, best_threads = dt, threads
+    torch.set_num_threads(best_threads)
+    done, t_used, it = 0, 0.0, 0
+    while t_used < seconds and it < 400:
+        t_used += one_iteration()
+        done += n
         it += 1
     return {
-        "value": done / max(t_used, 1e-9), "unit": "samples/s", "cores": cores, "kind": "port",
-        "sample": "%d iterations of N=4096 (reference batch size) from the same pool/octree; oracle/shine_oracle.py "
-                  "train_step = query+decode+loss+backward, torch %s CPU" % (max(it - 2, 0), torch.__version__),
+        "value": done / max(t_used, 1e-9), "unit": "samples/s", "cores": best_threads, "kind": "port",
+        "host_cores": host_cores,
+        "sample": "%d iterations of N=4096 (reference batch size, config/maicity/maicity_batch.yaml:54) from the same "
+                  "pool/octree; oracle/shine_oracle.py train_step = query+decode+loss+backward (no optimiser), torch %s "
+                  "CPU, thread count calibrated over {all,32,8,1}" % (it, torch.__version__),
     }
 
 
@@ -84,6 +96,7 @@ def main():
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,28 +129,19 @@ def main():
     params = list(octree.hier_features) + decoder.fused_params()
     for p in params:
         p.grad = torch.zeros_like(p)
-    reducer = shine_dp.GradReducer(params, dist) if world > 1 else None
+    reducer = shine_dp.GradReducer(params, dist)  # flat grad bucket: one fill per step, one all-reduce under DP
 
-    ev_pairs = []
-
-    def step(i, timed):
+    def step_body(i):
+        """zero grads -> Morton order -> fused query+decode+loss+backward (-> all-reduce)"""
         c, l, w = batches[i % len(batches)]
-        for p in params:
-            p.grad.zero_()
+        reducer.zero_grads()
         n_surf = None
         if opts.ekional_loss_on:
             n_surf = (w > 0).sum()
-            if reducer is not None:
-                reducer.all_reduce_scalar(n_surf)
+            reducer.all_reduce_scalar(n_surf)
         perm = None if args.no_sort else shine_dp.morton_order(octree, c)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         loss, pred, _ = fused_train_step(octree, decoder, c, l, w, opts, perm=perm, n_surf=n_surf)
-        if timed:
-            e1.record()
-            ev_pairs.append((e0, e1))
-        if reducer is not None:
+        if world > 1:
             reducer.all_reduce_grads()
         return loss
 
@@ -146,19 +150,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The loop body has no host sync and no allocation outside torch's allocator, so it is captured once per
+    # resident batch into a HIP graph and replayed (launch-bound inner loops belong in hipGraphs); the collective
+    # stays outside the graph.
+    launch = "eager"
+    graphs, graph_loss = [], []
+    if not args.no_graph and world == 1:
+        try:
+            for i in range(len(batches)):
+                step_body(i)  # warm caches / allocate workspaces outside capture
+            torch.cuda.synchronize()
+            for i in range(len(batches)):
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    graph_loss.append(step_body(i))
+                graphs.append(g_)
+            launch = "hipgraph"
+        except Exception as e:  # capture not possible on this stack: measure eagerly and say so
+            print("graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
+            graphs, graph_loss, launch = [], [], "eager"
+            torch.cuda.synchronize()
+
+    def step(i):
+        if graphs:
+            graphs[i % len(graphs)].replay()
+            return graph_loss[i % len(graphs)]
+        return step_body(i)
+
     for i in range(args.warmup):
-        step(i, False)
+        step(i)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = step(args.warmup + i, True)
+        loss = step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(len(ev_pairs), 1)
+
+    # dominant kernel: HIP events on the launch stream around R back-to-back launches of the fused step alone
+    # (same sorted batch; the tiny partial-sum reduction rides along), averaged per launch.
+    R = 10
+    c0, l0, w0 = batches[0]
+    perm0 = None if args.no_sort else shine_dp.morton_order(octree, c0)
+    ns0 = (w0 > 0).sum() if opts.ekional_loss_on else None
+
+    def fused_only():
+        for _ in range(R):
+            fused_train_step(octree, decoder, c0, l0, w0, opts, perm=perm0, n_surf=ns0)
+
+    fused_only()
+    torch.cuda.synchronize()
+    kg = None
+    if launch == "hipgraph":
+        try:
+            kg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(kg):
+                fused_only()
+        except Exception:
+            kg = None
+            torch.cuda.synchronize()
+    times = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if kg is not None:
+            kg.replay()
+        else:
+            fused_only()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) / R)
+    kernel_ms = sorted(times)[len(times) // 2]
 
     if rank == 0:
         bpp = algorithmic_bytes_per_point(levels)
@@ -176,7 +241,7 @@ def main():
                 "points_per_iter_per_gpu": points, "levels": levels, "frames": args.frames,
                 "pool_samples": int(pool.sdf_label.shape[0]),
                 "corner_rows": [int(p.shape[0]) for p in octree.hier_features],
-                "morton_sorted": not args.no_sort, "parallelism": "dp%d" % world,
+                "morton_sorted": not args.no_sort, "parallelism": "dp%d" % world, "launch": launch,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

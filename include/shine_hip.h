@@ -54,11 +54,13 @@ typedef struct shine_step_config {
   int32_t eikonal_on;      /* closed-form eikonal term                 (shine_batch.py:141-142,182-185) */
   int32_t decoder_grad_on; /* 0 when the decoder is frozen             (utils/tools.py:188-191) */
   int32_t sorted_input;    /* points are visited through perm[] (Morton order) when non-zero */
-  int32_t reserved0;
+  int32_t kernel_variant;  /* 0: auto (fastest kernel that supports the config), 1: force the simple v0 kernel */
   float sigma;             /* sigma_sigmoid = ratio*sigma_m*scale      (shine_batch.py:87) */
   float weight_e;          /* eikonal weight                           (config weight_e) */
   double inv_n;            /* 1/N_global for "mean", 1 for "sum"       */
   int64_t n_global;        /* global batch size (data parallel)        */
+  int32_t sort_origin[3];  /* leaf-level voxel coords of the map's bounding-box corner (shine_morton_sort) */
+  int32_t sort_bits[3];    /* bits per axis that cover the box; 0 = whole cube (tree_level_world bits)     */
 } shine_step_config;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -90,26 +92,49 @@ int shine_forward(const shine_tables* t, const shine_step_config* cfg, const flo
                   const float* const* feats, const int64_t* rows, const float* const* mlp, float* feat_out,
                   float* pred_out, int64_t* const* idx_out, float* grad_x_out, void* stream);
 
+/* ---- Tier A (strict drop-in): the backward of FeatureOctree.query_feature as autograd derives it from
+ *      model/feature_octree.py:222-234, and its own backward (needed by get_gradient(create_graph=True),
+ *      utils/tools.py:175-185, when the eikonal term is differentiated, shine_batch.py:182-185).
+ *      grad_feat [N,8] = d loss / d feat.  grad_coord_out [N,3] or NULL.  grad_feats[s] [rows_s+1,8] ACCUMULATED
+ *      INTO (trash row included) or NULL array / NULL entries.
+ *      _backward_backward: gg_coord [N,3] = d loss / d(grad_coord); grad_gfeat_out [N,8] = d loss / d(grad_feat). */
+int shine_interp_backward(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,
+                          const float* const* feats, const int64_t* rows, const float* grad_feat,
+                          float* grad_coord_out, float* const* grad_feats, void* stream);
+int shine_interp_backward_backward(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,
+                                   const float* const* feats, const int64_t* rows, const float* grad_feat,
+                                   const float* gg_coord, float* grad_gfeat_out, float* const* grad_feats,
+                                   void* stream);
+
 /* ---- fused training step: query + decode + sdf_bce_loss (utils/loss.py:17-24) [+ eikonal
  *      (shine_batch.py:182-185)] + the whole backward (shine_batch.py:208-209) in one pass.
  *      Inputs : coord [N,3], sdf_label [N], weight [N] (sign = surface/free, data_sampler.py:102-103),
  *               perm [N] int32 or NULL, n_surf: device int64 (global #weight>0) or NULL when eikonal off.
  *      Outputs: pred [N]; grad_x [N,3] or NULL; grad_feats[s] [rows_s+1, 8] and grad_mlp[6]
  *               ACCUMULATED INTO (caller zero-fills; matches autograd's dense grads incl. the
- *               trash row); loss_parts: device double[4] accumulated into:
+ *               trash row); loss_parts: device double[4] OVERWRITTEN with
  *               [0] BCE term (already reduced per cfg), [1] eikonal mean term (unweighted),
- *               [2] number of points processed, [3] reserved. --------------------------------- */
+ *               [2] number of points processed, [3] [0] + weight_e * [1].
+ *               The trash row of every feats[s] is re-zeroed (FeatureOctree.set_zero, :78-81). ---------- */
 int shine_train_step(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                      const float* sdf_label, const float* weight, const int32_t* perm, const int64_t* n_surf,
                      int64_t n, const float* const* feats, const int64_t* rows, const float* const* mlp,
                      float* pred_out, float* grad_x_out, float* const* grad_feats, float* const* grad_mlp,
-                     double* loss_parts, void* stream);
+                     double* loss_parts, void* workspace, size_t workspace_bytes, void* stream);
+/* bytes of device scratch shine_train_step wants for a batch of n points (per-workgroup partial sums of
+ * the decoder / trash-row gradients, reduced by a second tiny kernel: deterministic, no hot-spot atomics).
+ * workspace may be NULL (or too small): the step then falls back to fp32 atomics for those sums. */
+size_t shine_train_step_workspace_bytes(const shine_step_config* cfg, int64_t n);
 
 /* ---- Morton ordering of a batch: the new step right after LiDARDataset.get_batch
  *      (dataset/lidar_dataset.py:430-450).  perm_out[N] int32 = argsort of the leaf-level node keys, to be
  *      passed as `perm` to shine_train_step.  Call with workspace == NULL to get the required bytes. --- */
 int shine_morton_sort(const shine_step_config* cfg, const float* coord, int64_t n, int32_t* perm_out,
                       void* workspace, size_t* workspace_bytes, void* stream);
+
+/* ---- device self-test: D[32,32] = A[32,2] . B[2,32] through ONE v_mfma_f32_32x32x2_f32, written back with the
+ *      accumulator lane map the fused kernel relies on (pins the MFMA operand layouts on the hardware). --- */
+int shine_selftest_mfma(const float* a, const float* b, float* d, void* stream);
 
 #ifdef __cplusplus
 }

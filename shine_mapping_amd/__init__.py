@@ -9,6 +9,8 @@ All compute goes through libshine_hip.so (include/shine_hip.h); there is no CPU 
 """
 from .decoder import Decoder
 from .feature_octree import FeatureOctree
+from .losses import get_gradient, sdf_bce_loss
 from .ops import StepOptions, forward_sdf, fused_train_step, octree_interp
 
-__all__ = ["Decoder", "FeatureOctree", "StepOptions", "forward_sdf", "fused_train_step", "octree_interp"]
+__all__ = ["Decoder", "FeatureOctree", "StepOptions", "forward_sdf", "fused_train_step", "octree_interp",
+           "sdf_bce_loss", "get_gradient"]

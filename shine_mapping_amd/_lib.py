@@ -26,11 +26,13 @@ class StepConfig(C.Structure):
         ("eikonal_on", C.c_int32),
         ("decoder_grad_on", C.c_int32),
         ("sorted_input", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("kernel_variant", C.c_int32),
         ("sigma", C.c_float),
         ("weight_e", C.c_float),
         ("inv_n", C.c_double),
         ("n_global", C.c_int64),
+        ("sort_origin", C.c_int32 * 3),
+        ("sort_bits", C.c_int32 * 3),
     ]
 
 
@@ -52,9 +54,17 @@ _SIGNATURES = {
     "shine_train_step": (
         C.c_int,
         [_P, C.POINTER(StepConfig), _P, _P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64),
-         C.POINTER(_P), _P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P],
+         C.POINTER(_P), _P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P, C.c_size_t, _P],
     ),
+    "shine_train_step_workspace_bytes": (C.c_size_t, [C.POINTER(StepConfig), C.c_int64]),
     "shine_morton_sort": (C.c_int, [C.POINTER(StepConfig), _P, C.c_int64, _P, _P, C.POINTER(C.c_size_t), _P]),
+    "shine_selftest_mfma": (C.c_int, [_P, _P, _P, _P]),
+    "shine_interp_backward": (
+        C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P,
+                  C.POINTER(_P), _P]),
+    "shine_interp_backward_backward": (
+        C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P,
+                  C.POINTER(_P), _P]),
 }
 
 _lib = None

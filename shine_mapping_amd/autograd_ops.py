@@ -1,0 +1,110 @@
+"""Tier A: FeatureOctree.query_feature as a twice-differentiable torch.autograd.Function.
+
+The reference builds the interpolation out of ~30 torch ops per level and lets autograd differentiate it,
+twice when the eikonal term is on (get_gradient(create_graph=True), utils/tools.py:175-185).  Here forward,
+backward and backward-of-backward are one HIP kernel each (shine_forward / shine_interp_backward /
+shine_interp_backward_backward); the Decoder stays a torch composite, so the reference drivers run unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _null_ptrs(n):
+    return _lib.ptr_array([None] * n)
+
+
+class OctreeInterp(torch.autograd.Function):
+    """feat = sum_l interp(F_l, coord).  Inputs: coord [N,3], the octree (non-tensor), then the L feature tables."""
+
+    @staticmethod
+    def forward(ctx, coord, octree, *feats):
+        from .ops import _interp_forward
+
+        feat = _interp_forward(octree, coord)
+        ctx.octree = octree
+        ctx.save_for_backward(coord, *feats)
+        return feat
+
+    @staticmethod
+    def backward(ctx, g):
+        coord, *feats = ctx.saved_tensors
+        outs = OctreeInterpBackward.apply(g, coord, ctx.octree, ctx.needs_input_grad[0], *feats)
+        grad_coord = outs[0] if ctx.needs_input_grad[0] else None
+        grad_feats = tuple(o if need else None for o, need in zip(outs[1:], ctx.needs_input_grad[2:]))
+        return (grad_coord, None) + grad_feats
+
+
+class OctreeInterpBackward(torch.autograd.Function):
+    """(grad_coord, dense grad_F_0..L-1) = backward of OctreeInterp; itself differentiable wrt g and the tables."""
+
+    @staticmethod
+    def forward(ctx, g, coord, octree, want_coord, *feats):
+        t = octree._require_tables()
+        c = octree._check_coord(coord.detach())
+        g = g.detach().contiguous().float()
+        n = c.shape[0]
+        grad_coord = torch.zeros((n, 3), dtype=torch.float32, device=c.device)
+        grad_feats = [torch.zeros_like(f, memory_format=torch.contiguous_format) for f in feats]
+        cfg = octree.step_config()
+        _lib.check(
+            _lib.lib().shine_interp_backward(
+                t.handle, C.byref(cfg), c.data_ptr(), n, _lib.ptr_array([f.data_ptr() for f in feats]),
+                octree.row_counts(), g.data_ptr(), grad_coord.data_ptr() if want_coord else None,
+                _lib.ptr_array([gf.data_ptr() for gf in grad_feats]), _stream(),
+            ),
+            "shine_interp_backward",
+        )
+        ctx.octree = octree
+        ctx.save_for_backward(g, coord, *feats)
+        return (grad_coord,) + tuple(grad_feats)
+
+    @staticmethod
+    def backward(ctx, gg_coord, *gg_feats):
+        g, coord, *feats = ctx.saved_tensors
+        octree = ctx.octree
+        t = octree._require_tables()
+        c = octree._check_coord(coord.detach())
+        n = c.shape[0]
+        cfg = octree.step_config()
+        grad_g = None
+        grad_feats = [None] * len(feats)
+        if gg_coord is not None:
+            gg = gg_coord.detach().contiguous().float()
+            grad_g = torch.zeros((n, 8), dtype=torch.float32, device=c.device)
+            dense = [torch.zeros_like(f, memory_format=torch.contiguous_format) for f in feats]
+            _lib.check(
+                _lib.lib().shine_interp_backward_backward(
+                    t.handle, C.byref(cfg), c.data_ptr(), n, _lib.ptr_array([f.data_ptr() for f in feats]),
+                    octree.row_counts(), g.data_ptr(), gg.data_ptr(), grad_g.data_ptr(),
+                    _lib.ptr_array([d.data_ptr() for d in dense]), _stream(),
+                ),
+                "shine_interp_backward_backward",
+            )
+            grad_feats = dense
+        if any(x is not None for x in gg_feats):
+            # d(grad_F_l)/dg: grad_F_l[id] = sum w g  ->  dg += sum_l interp(gg_F_l): the forward kernel on gg tables
+            tabs = [x.detach().contiguous().float() if x is not None else torch.zeros_like(f)
+                    for x, f in zip(gg_feats, feats)]
+            extra = torch.empty((n, 8), dtype=torch.float32, device=c.device)
+            from .ops import _dummy_mlp
+
+            _lib.check(
+                _lib.lib().shine_forward(
+                    t.handle, C.byref(cfg), c.data_ptr(), n, _lib.ptr_array([x.data_ptr() for x in tabs]),
+                    octree.row_counts(), _lib.ptr_array([p.data_ptr() for p in _dummy_mlp(c.device)]),
+                    extra.data_ptr(), None, None, None, _stream(),
+                ),
+                "shine_forward",
+            )
+            grad_g = extra if grad_g is None else grad_g + extra
+        # inputs: g, coord, octree, want_coord, *feats   (no second derivative wrt coord: it is a leaf nobody reads)
+        return (grad_g, None, None, None) + tuple(grad_feats)

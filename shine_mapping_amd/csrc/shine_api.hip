@@ -29,6 +29,11 @@ extern "C" int shine_train_step_v0(const shine_tables*, const shine_step_config*
                                    const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
                                    double*, void*);
 
+extern "C" int shine_train_step_v1(const shine_tables*, const shine_step_config*, const float*, const float*,
+                                   const float*, const int32_t*, const int64_t*, int64_t, const float* const*,
+                                   const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
+                                   double*, void*, size_t, void*);
+
 extern "C" int shine_version(void) { return 100; }
 
 extern "C" const char* shine_error_string(int code) {
@@ -47,8 +52,22 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
                                 const float* sdf_label, const float* weight, const int32_t* perm,
                                 const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,
                                 const float* const* mlp, float* pred_out, float* grad_x_out, float* const* grad_feats,
-                                float* const* grad_mlp, double* loss_parts, void* stream) {
+                                float* const* grad_mlp, double* loss_parts, void* workspace, size_t workspace_bytes,
+                                void* stream) {
   if (!cfg) return shine::set_error(SHINE_E_INVALID, "shine_train_step: null config");
+  if (n == 0) {  // empty batch: nothing to add to the grads, loss terms are zero
+    if (loss_parts && hipMemsetAsync(loss_parts, 0, 4 * sizeof(double), (hipStream_t)stream) != hipSuccess)
+      return shine::set_error(SHINE_E_HIP, "hipMemsetAsync(loss_parts)");
+    return SHINE_OK;
+  }
+  static const int force_v0 = []() {
+    const char* e = getenv("SHINE_KERNEL");
+    return (e && strcmp(e, "v0") == 0) ? 1 : 0;
+  }();
+  // v1 (MFMA decoder, run-length scatter) covers the BCE step; the eikonal step still runs on v0
+  if (!force_v0 && (cfg->kernel_variant & 0xff) != 1 && !cfg->eikonal_on && cfg->n_levels <= 4)
+    return shine_train_step_v1(t, cfg, coord, sdf_label, weight, perm, n_surf, n, feats, rows, mlp, pred_out,
+                               grad_x_out, grad_feats, grad_mlp, loss_parts, workspace, workspace_bytes, stream);
   return shine_train_step_v0(t, cfg, coord, sdf_label, weight, perm, n_surf, n, feats, rows, mlp, pred_out,
                              grad_x_out, grad_feats, grad_mlp, loss_parts, stream);
 }

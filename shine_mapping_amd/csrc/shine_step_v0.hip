@@ -402,9 +402,12 @@ __global__ __launch_bounds__(256) void k_step_v0(StepArgs a) {
     }
     double ls = wave_sum_d(loss_acc), es = wave_sum_d(eik_acc), cs = wave_sum_d(cnt_acc);
     if (lane == 0 && a.loss_parts) {
-      atomicAdd(a.loss_parts + 0, a.reduction_sum ? ls : ls * (double)a.inv_n);
-      if (EIK) atomicAdd(a.loss_parts + 1, es * (double)inv_nsurf);
+      const double bce = a.reduction_sum ? ls : ls * (double)a.inv_n;
+      const double eik = EIK ? es * (double)inv_nsurf : 0.0;
+      atomicAdd(a.loss_parts + 0, bce);
+      if (EIK) atomicAdd(a.loss_parts + 1, eik);
       atomicAdd(a.loss_parts + 2, cs);
+      atomicAdd(a.loss_parts + 3, bce + (double)a.weight_e * eik);
     }
   }
 }
@@ -541,6 +544,10 @@ extern "C" int shine_train_step_v0(const shine_tables* t, const shine_step_confi
   a.pred = pred_out;
   a.grad_x = grad_x_out;
   a.loss_parts = loss_parts;
+  if (loss_parts) SHINE_HIP_CHECK(hipMemsetAsync(loss_parts, 0, 4 * sizeof(double), (hipStream_t)stream));
+  for (int s = 0; s < cfg->n_levels; ++s)  // FeatureOctree.set_zero (:78-81): the kernel never reads the trash row
+    SHINE_HIP_CHECK(hipMemsetAsync(const_cast<float*>(feats[s]) + rows[s] * F, 0, F * sizeof(float),
+                                   (hipStream_t)stream));
   if (cfg->eikonal_on)
     launch_v0<true, true>(a, cfg->poly_int_on != 0, (hipStream_t)stream);
   else

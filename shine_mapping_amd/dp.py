@@ -19,7 +19,7 @@ from . import _lib
 class GradReducer:
     """Flat-bucket gradient all-reduce.  `dist` is torch.distributed (backend nccl = RCCL on ROCm, gloo in CPU tests)."""
 
-    def __init__(self, params, dist, group=None):
+    def __init__(self, params, dist=None, group=None):
         self.params = list(params)
         self.dist = dist
         self.group = group
@@ -47,12 +47,19 @@ class GradReducer:
             off += p.numel()
         self._flat, self._views = flat, views
 
+    def zero_grads(self):
+        """One fill for every gradient (what opt.zero_grad amounts to for the fused step's dense grads)."""
+        self._ensure_flat()
+        self._flat.zero_()
+
     def all_reduce_grads(self):
         self._ensure_flat()
-        self.dist.all_reduce(self._flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.dist is not None:
+            self.dist.all_reduce(self._flat, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce_scalar(self, t: torch.Tensor):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
 
@@ -64,15 +71,18 @@ def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
     coord = octree._check_coord(coord.detach())
     n = coord.shape[0]
     cfg = octree.step_config()
-    need = C.c_size_t(0)
     lib = _lib.lib()
     stream = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.shine_morton_sort(C.byref(cfg), None, n, None, None, C.byref(need), stream), "shine_morton_sort")
-    key = (str(coord.device), int(need.value))
-    ws = _WS.get(key)
-    if ws is None:
-        ws = torch.empty(int(need.value), dtype=torch.uint8, device=coord.device)
-        _WS[key] = ws
+    wide = sum(cfg.sort_bits) > 32 or min(cfg.sort_bits) <= 0
+    key = (str(coord.device), n, wide)
+    ent = _WS.get(key)
+    if ent is None:  # size query once per (device, batch size, key width); the buffer is reused every iteration
+        need = C.c_size_t(0)
+        _lib.check(lib.shine_morton_sort(C.byref(cfg), None, n, None, None, C.byref(need), stream),
+                   "shine_morton_sort")
+        ent = (torch.empty(int(need.value), dtype=torch.uint8, device=coord.device), int(need.value))
+        _WS[key] = ent
+    ws, need = ent[0], C.c_size_t(ent[1])
     perm = torch.empty(n, dtype=torch.int32, device=coord.device)
     _lib.check(
         lib.shine_morton_sort(C.byref(cfg), coord.data_ptr(), n, perm.data_ptr(), ws.data_ptr(), C.byref(need), stream),

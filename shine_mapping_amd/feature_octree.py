@@ -134,6 +134,7 @@ class FeatureOctree(nn.Module):
         self._corner_id_of_lex = [np.zeros(0, np.int64) for _ in range(L)]
         self._corner_count = [0] * L
         self._dict_cache = None
+        self._sort_box_cache = None
         self._tables = None  # created at the first query (needs the GPU); update() itself is host-only
         self._pending = [[] for _ in range(L)]  # (node keys, corner ids) not yet inserted on the device
         # a level's regulariser contributes gradient only while its features_last_frame copy is detached
@@ -203,6 +204,7 @@ class FeatureOctree(nn.Module):
         q = torch.floor(torch.clamp(res * (surface_points.float() + 1.0) / 2.0, 0, res - 1.0)).to(torch.int64)
         leaf = np.unique(morton_encode(q.cpu().numpy()))
         self._dict_cache = None
+        self._sort_box_cache = None
         for s in range(self.featured_level_num):
             lvl = self.free_level_num + s
             nodes = np.unique(leaf >> (3 * (self.max_level - lvl)))  # Morton order, like point_hierarchies
@@ -281,9 +283,29 @@ class FeatureOctree(nn.Module):
         cfg.poly_int_on = 1 if self.polynomial_interpolation else 0
         cfg.sigma = 1.0
         cfg.inv_n = 1.0
+        origin, bits = self._sort_box()
+        cfg.sort_origin[0], cfg.sort_origin[1], cfg.sort_origin[2] = origin
+        cfg.sort_bits[0], cfg.sort_bits[1], cfg.sort_bits[2] = bits
         for k, v in kw.items():
             setattr(cfg, k, v)
         return cfg
+
+    def _sort_box(self):
+        """Leaf-level voxel bounding box of the map (from the coarsest featured level's nodes, so it is cheap):
+        lets shine_morton_sort use bx+by+bz-bit keys instead of 3*tree_level_world."""
+        if self._sort_box_cache is None:
+            keys = self._node_keys[0]
+            if keys.size == 0:
+                self._sort_box_cache = ((0, 0, 0), (0, 0, 0))
+            else:
+                shift = self.featured_level_num - 1  # coarsest featured level -> leaf voxel units
+                xyz = morton_decode(keys)
+                lo = (xyz.min(0) << shift) - (1 << shift)  # one coarse cell of margin for free-space samples
+                hi = ((xyz.max(0) + 2) << shift)
+                lo = np.maximum(lo, 0)
+                bits = tuple(min(self.max_level, max(1, int(int(e) - 1).bit_length())) for e in (hi - lo))
+                self._sort_box_cache = (tuple(int(v) for v in lo), bits)
+        return self._sort_box_cache
 
     def feature_ptrs(self):
         return _lib.ptr_array([p.data_ptr() for p in self.hier_features])
@@ -370,6 +392,7 @@ class FeatureOctree(nn.Module):
         pair, e.g. from a reference checkpoint's nodes_lookup_tables.  Feature rows must be set by the caller."""
         self._tables = None
         self._dict_cache = None
+        self._sort_box_cache = None
         for s, (keys, ids) in enumerate(tables):
             keys_np = keys.cpu().numpy().astype(np.int64)
             ids_np = ids.cpu().numpy().astype(np.int32).reshape(-1, 8)

@@ -30,6 +30,7 @@ class StepOptions:
     weight_e: float = 0.1
     n_global: Optional[int] = None    # global batch size under data parallelism (defaults to local N)
     decoder_grad_on: Optional[bool] = None  # default: any decoder parameter requires grad (freeze_model, tools.py:188)
+    kernel_variant: int = 0           # 0 auto; 1 forces the simple v0 kernel (kept as an on-device cross-check)
 
 
 def _stream():
@@ -89,7 +90,7 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     coord [N,3], sdf_label [N], weight [N] (sign: + surface / - free space, utils/data_sampler.py:102-103).
     Accumulates into ``.grad`` of octree.hier_features[*] and the six decoder tensors (dense, trash row
     included — what ``cur_loss.backward()`` produces, shine_batch.py:209).  Returns (loss, pred, g) where
-    loss is a 0-dim device tensor (no host sync) and g = get_gradient(coord,pred)*sigma or None.
+    loss is a 0-dim float64 device tensor (no host sync) and g = get_gradient(coord,pred)*sigma or None.
     """
     t = octree._require_tables()
     coord = octree._check_coord(coord.detach())
@@ -109,19 +110,19 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     cfg = octree.step_config(
         sigma=float(opts.sigma), weight_e=float(opts.weight_e), eikonal_on=1 if eik else 0,
         reduction_sum=1 if opts.loss_reduction == "sum" else 0, decoder_grad_on=1 if dec_grad else 0,
-        sorted_input=0 if perm is None else 1, n_global=n_global,
+        sorted_input=0 if perm is None else 1, n_global=n_global, kernel_variant=int(opts.kernel_variant),
         inv_n=(1.0 if opts.loss_reduction == "sum" else 1.0 / max(n_global, 1)),
     )
     if eik and n_surf is None:
         n_surf = (weight > 0).sum()  # stays on the device; under DP the caller all-reduces it first
     pred = torch.empty(n, dtype=torch.float32, device=dev)
     gx = torch.empty((n, 3), dtype=torch.float32, device=dev) if (want_grad_x and eik) else None
-    loss_parts = torch.zeros(4, dtype=torch.float64, device=dev)
-    octree.set_zero()
+    loss_parts = torch.empty(4, dtype=torch.float64, device=dev)  # overwritten by the step; set_zero is in-kernel
     gfeat = [_dense_grad(p) if p.requires_grad else None for p in octree.hier_features]
     gmlp = [_dense_grad(p) for p in params] if dec_grad else [None] * 6
     if perm is not None and not (perm.is_cuda and perm.dtype == torch.int32 and perm.numel() == n):
         raise ValueError("perm must be a CUDA int32 tensor of N entries")
+    ws = _workspace(dev, int(_lib.lib().shine_train_step_workspace_bytes(C.byref(cfg), n)))
     _lib.check(
         _lib.lib().shine_train_step(
             t.handle, C.byref(cfg), coord.data_ptr(), sdf_label.data_ptr(),
@@ -133,14 +134,11 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
             pred.data_ptr(), gx.data_ptr() if gx is not None else None,
             _lib.ptr_array([g.data_ptr() if g is not None else None for g in gfeat]),
             _lib.ptr_array([g.data_ptr() if g is not None else None for g in gmlp]),
-            loss_parts.data_ptr(), _stream(),
+            loss_parts.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
         ),
         "shine_train_step",
     )
-    loss = loss_parts[0]
-    if eik:
-        loss = loss + float(opts.weight_e) * loss_parts[1]
-    return loss.to(torch.float32), pred, gx
+    return loss_parts[3], pred, gx  # 0-dim float64 view: BCE (+ weight_e * eikonal), no extra launch
 
 
 def octree_interp(octree, coord):
@@ -176,6 +174,17 @@ def _interp_forward(octree, coord):
 
 
 _DUMMY = {}
+_WORKSPACE = {}
+
+
+def _workspace(dev, nbytes):
+    """Scratch for the fused step, owned by torch's caching allocator and reused across iterations."""
+    key = str(dev)
+    ws = _WORKSPACE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        _WORKSPACE[key] = ws
+    return ws
 
 
 def _dummy_mlp(dev):

@@ -1,0 +1,88 @@
+"""CPU suite: the data-parallel path with world_size 2 over gloo.
+
+The N>1 design: replicated tables + decoder, each rank runs the step on its shard of the global batch with
+the GLOBAL normalisers (1/N_global for 'mean', global surface count for the eikonal mean), then one flat
+all-reduce(sum) of the dense grads.  Here the per-rank compute is the CPU oracle (tests may use it as the
+stand-in; the product path is HIP-only) — what is under test is shine_mapping_amd.dp.GradReducer and the
+normaliser algebra: reduced shard grads == single-process full-batch grads."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden, oracle_from_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _sharded_step(oct_, mlp, c, l, w, cfg, n_global, n_surf_global, reset=True):
+    """The oracle's step with GLOBAL normalisers: what each rank's fused kernel computes under DP."""
+    from oracle import shine_oracle as so
+
+    if reset:
+        oct_.zero_grad()
+        mlp.zero_grad()
+    sig = so.sigma_sigmoid(cfg)
+    eik = bool(cfg.ekional_loss_on)
+    coord = c.detach().clone().requires_grad_(eik)
+    pred = mlp.sdf(oct_.query_feature(coord))
+    loss = so.sdf_bce_loss(pred, l, sig, "sum") / n_global
+    if eik:
+        g = so.coord_gradient(coord, pred) * sig
+        e = ((1.0 - g[w > 0].norm(2, dim=-1)) ** 2).sum() / n_surf_global
+        loss = loss + cfg.weight_e * e
+    loss.backward()
+    return loss.detach()
+
+
+def _worker(rank, world, port, name, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from shine_mapping_amd.dp import GradReducer
+
+    fx = load_golden(name)
+    cfg, oct_, mlp = oracle_from_golden(fx)
+    n = fx["coord"].shape[0]
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    c, l, w = fx["coord"][lo:hi], fx["sdf_label"][lo:hi], fx["weight"][lo:hi]
+    params = list(oct_.hier_features) + mlp.params()
+    reducer = GradReducer(params, dist)
+    n_surf = (w > 0).sum()
+    reducer.all_reduce_scalar(n_surf)
+    loss = _sharded_step(oct_, mlp, c, l, w, cfg, n, int(n_surf))
+    reducer.all_reduce_grads()
+    dist.all_reduce(loss)
+    # second iteration re-uses the flat bucket (grads are views into it)
+    for p in params:
+        p.grad.zero_()
+    _sharded_step(oct_, mlp, c, l, w, cfg, n, int(n_surf), reset=False)
+    for p in params:  # autograd accumulates in place into the bucket views
+        assert p.grad.data_ptr() >= reducer._flat.data_ptr()
+    reducer.all_reduce_grads()
+    if rank == 0:
+        torch.save(dict(loss=loss, grads=[p.grad.clone() for p in params]), os.path.join(out_dir, "dp.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["maicity_bce_L3", "kitti_eik_L3"])
+def test_two_rank_gloo_matches_single_process(name, tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "dp.pt"), weights_only=False)
+    fx = load_golden(name)
+    ref = fx["out"]
+    refs = list(ref["feat_grads"]) + list(ref["mlp_grads"])
+    assert abs(float(got["loss"]) - float(ref["loss"])) <= 1e-5 * max(1.0, abs(float(ref["loss"])))
+    for g, r in zip(got["grads"], refs):
+        assert float((g - r).abs().max()) <= 1e-5 * max(float(r.abs().max()), 1e-30)

@@ -181,7 +181,17 @@ def test_morton_sort_is_a_permutation_in_key_order_and_step_is_order_invariant()
     torch.cuda.synchronize()
     p = perm.cpu().long()
     assert torch.equal(torch.sort(p).values, torch.arange(coord.shape[0]))
-    keys = kal.points_to_morton(kal.quantize_points(fx["coord"], cfg.tree_level_world))
+    # the sort key is the Z-order code of the leaf voxel relative to the map's bounding box, clamped to it
+    origin, bits = octree._sort_box()
+    vox = kal.quantize_points(fx["coord"], cfg.tree_level_world).long() - torch.tensor(origin)
+    vox = torch.minimum(vox.clamp(min=0), torch.tensor([(1 << b) - 1 for b in bits]))
+    bmin = min(bits)
+    keys = kal.points_to_morton((vox & ((1 << bmin) - 1)).short())
+    sh = 3 * bmin
+    for axis in (2, 1, 0):  # z_hi, then y_hi, then x_hi on top
+        keys = keys | ((vox[:, axis] >> bmin) << sh)
+        sh += bits[axis] - bmin
+    assert sum(bits) <= 32
     assert bool((keys[p][1:] >= keys[p][:-1]).all())
     loss, pred, _ = fused_train_step(octree, dec, coord, fx["sdf_label"].cuda(), fx["weight"].cuda(), step_options(fx),
                                      perm=perm)
@@ -189,3 +199,121 @@ def test_morton_sort_is_a_permutation_in_key_order_and_step_is_order_invariant()
     assert abs_err(pred, ref["pred"]) <= TOL
     for k, r in enumerate(ref["feat_grads"]):
         assert rel_err(octree.hier_features[k].grad, r) <= TOL
+
+
+def test_mfma_lane_maps_on_hardware():
+    """D = A.B through one v_mfma_f32_32x32x2_f32 with the operand/accumulator maps the fused kernel assumes
+    (asymmetric random A and B so a transposed read or write cannot pass)."""
+    from shine_mapping_amd import _lib
+
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(32, 2, generator=g)
+    B = torch.randn(2, 32, generator=g)
+    d = torch.zeros(32, 32, device="cuda")
+    Ad, Bd = A.cuda(), B.cuda()
+    _lib.check(_lib.lib().shine_selftest_mfma(Ad.data_ptr(), Bd.data_ptr(), d.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "shine_selftest_mfma")
+    torch.cuda.synchronize()
+    assert torch.allclose(d.cpu(), A @ B, atol=1e-6)
+
+
+@pytest.mark.parametrize("levels,n", [(3, 1 << 14), (4, 1 << 18)])
+def test_v1_against_v0_at_scale_and_grad_checksum(levels, n):
+    """BASELINE-size batch (2^18 points, 4 levels): the MFMA/run-length kernel vs the simple v0 kernel on the same
+    device inputs, plus a size-independent property: per level, the column sums of the feature-grad table
+    (trash row included) equal sum_p d loss/d f_p up to rounding, because the 8 corner weights sum to 1 — so
+    every level must report the SAME column sums ("checksum of checksums")."""
+    from shine_mapping_amd import StepOptions, dp, fused_train_step, synth
+
+    wl = synth.build_workload("maicity", frames=6, device="cuda", seed=3, tree_level_feat=levels, azimuths=300)
+    cfg, octree, dec = wl.cfg, wl.octree, wl.decoder
+    with torch.no_grad():
+        for p in octree.hier_features:
+            p[:-1] *= 6.0
+    g = torch.Generator(device="cuda").manual_seed(5)
+    coord, label, weight = synth.draw_batch(wl.pool, n, g)
+    params = list(octree.hier_features) + dec.fused_params()
+    outs = {}
+    for variant, perm in ((1, None), (0, None), (0, dp.morton_order(octree, coord))):
+        for p in params:
+            p.grad = None
+        opts = StepOptions(sigma=cfg.sigma_sigmoid, kernel_variant=variant)
+        loss, pred, _ = fused_train_step(octree, dec, coord, label, weight, opts, perm=perm)
+        torch.cuda.synchronize()
+        outs[(variant, perm is not None)] = (float(loss), pred.clone(), [p.grad.clone() for p in params])
+    ref = outs[(1, False)]
+    for key in ((0, False), (0, True)):
+        got = outs[key]
+        assert abs(got[0] - ref[0]) <= 1e-5 * max(1.0, abs(ref[0])), key
+        assert abs_err(got[1], ref[1]) <= 2e-5, key
+        for a, b in zip(got[2], ref[2]):
+            assert rel_err(a, b) <= TOL, key
+    sums = [gr.double().sum(0) for gr in outs[(0, True)][2][:levels]]
+    scale = max(float(s.abs().max()) for s in sums)
+    for s in sums[1:]:
+        assert float((s - sums[0]).abs().max()) <= 1e-3 * scale
+
+
+def test_tier_a_drop_in_loop_matches_reference(golden):
+    """The reference's inner loop, verbatim (shine_batch.py:119-209 / shine_incre.py:129-180), on OUR classes:
+    query_feature -> sdf -> get_gradient(create_graph=True) -> sdf_bce_loss (+ regulariser, + eikonal) ->
+    loss.backward().  Exercises the autograd ops incl. the double backward."""
+    from shine_mapping_amd import get_gradient, sdf_bce_loss
+
+    cfg, octree, dec = product_from_golden(golden)
+    ref = golden["out"]
+    c = golden["cfg"]
+    eik = c.get("ekional_loss_on", False)
+    sigma = golden["sigma"]
+    if golden["regularize"]:
+        # feature_octree.py:160: the stored copy is an attached clone of the Parameter (see DESIGN.md quirks)
+        vals = octree.features_last_frame
+        octree.features_last_frame = [p.clone() for p in octree.hier_features]
+        with torch.no_grad():
+            for t, v in zip(octree.features_last_frame, vals):
+                t.copy_(v)
+    coord = golden["coord"].cuda()
+    sdf_label, weight = golden["sdf_label"].cuda(), golden["weight"].cuda()
+    if eik:
+        coord.requires_grad_(True)
+    feature = octree.query_feature(coord)
+    pred = dec.sdf(feature)
+    surface_mask = weight > 0
+    if eik:
+        g = get_gradient(coord, pred) * sigma
+    cur_loss = 0.0
+    w_abs = torch.abs(weight)
+    cur_loss = cur_loss + sdf_bce_loss(pred, sdf_label, sigma, w_abs, False, c.get("loss_reduction", "mean"))
+    if golden["regularize"]:
+        cur_loss = cur_loss + c["lambda_forget"] * octree.cal_regularization()
+    if eik:
+        cur_loss = cur_loss + c["weight_e"] * ((1.0 - g[surface_mask].norm(2, dim=-1)) ** 2).mean()
+    cur_loss.backward()
+    torch.cuda.synchronize()
+    for k in range(len(ref["indices"])):
+        assert torch.equal(octree.hierarchical_indices[k].cpu(), ref["indices"][k])
+    assert abs_err(pred, ref["pred"]) <= TOL
+    assert abs(float(cur_loss) - float(ref["loss"])) <= TOL * max(1.0, abs(float(ref["loss"])))
+    if eik:
+        assert rel_err(g, ref["g"]) <= TOL
+    gtol = 3e-4 if golden["regularize"] else TOL
+    for k, r in enumerate(ref["feat_grads"]):
+        assert rel_err(octree.hier_features[k].grad, r) <= gtol, "feature grad level %d" % k
+    for k, (p, r) in enumerate(zip(dec.fused_params(), ref["mlp_grads"])):
+        assert rel_err(p.grad, r) <= TOL, "decoder grad %d" % k
+
+
+def test_octree_pickle_roundtrip_keeps_tables():
+    """utils/tools.py:200-213 pickles the whole FeatureOctree module; the device tables are rebuilt on load."""
+    import io
+
+    fx = load_golden("maicity_bce_L3")
+    cfg, octree, dec = product_from_golden(fx)
+    buf = io.BytesIO()
+    torch.save({"feature_octree": octree}, buf)
+    buf.seek(0)
+    oct2 = torch.load(buf, weights_only=False)["feature_octree"]
+    idx = oct2.get_indices(fx["coord"].cuda())
+    for k, r in enumerate(fx["out"]["indices"]):
+        assert torch.equal(idx[k].cpu(), r)
+    assert oct2.nodes_lookup_tables[cfg.tree_level_world] == octree.nodes_lookup_tables[cfg.tree_level_world]
