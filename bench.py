@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--order", default="plan", choices=["plan", "radix"],
+                    help="plan: counting sort by octree node + slot hand-off (shine_plan_batch); radix: Morton radix sort")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     args = ap.parse_args()
 
@@ -131,16 +133,22 @@ def main():
         p.grad = torch.zeros_like(p)
     reducer = shine_dp.GradReducer(params, dist)  # flat grad bucket: one fill per step, one all-reduce under DP
 
+    def order(c, zero=None):
+        if args.no_sort or args.order != "plan":
+            if zero is not None:
+                reducer.zero_grads()
+            return (None if args.no_sort else shine_dp.morton_order(octree, c)), None
+        return shine_dp.plan_batch(octree, c, zero=zero)  # the plan pass also clears the gradient bucket
+
     def step_body(i):
         """zero grads -> Morton order -> fused query+decode+loss+backward (-> all-reduce)"""
         c, l, w = batches[i % len(batches)]
-        reducer.zero_grads()
         n_surf = None
         if opts.ekional_loss_on:
             n_surf = (w > 0).sum()
             reducer.all_reduce_scalar(n_surf)
-        perm = None if args.no_sort else shine_dp.morton_order(octree, c)
-        loss, pred, _ = fused_train_step(octree, decoder, c, l, w, opts, perm=perm, n_surf=n_surf)
+        perm, slots = order(c, zero=reducer.flat)
+        loss, pred, _ = fused_train_step(octree, decoder, c, l, w, opts, perm=perm, n_surf=n_surf, slots=slots)
         if world > 1:
             reducer.all_reduce_grads()
         return loss
@@ -194,12 +202,12 @@ def main():
     # (same sorted batch; the tiny partial-sum reduction rides along), averaged per launch.
     R = 10
     c0, l0, w0 = batches[0]
-    perm0 = None if args.no_sort else shine_dp.morton_order(octree, c0)
+    perm0, slots0 = order(c0)
     ns0 = (w0 > 0).sum() if opts.ekional_loss_on else None
 
     def fused_only():
         for _ in range(R):
-            fused_train_step(octree, decoder, c0, l0, w0, opts, perm=perm0, n_surf=ns0)
+            fused_train_step(octree, decoder, c0, l0, w0, opts, perm=perm0, n_surf=ns0, slots=slots0)
 
     fused_only()
     torch.cuda.synchronize()
@@ -241,7 +249,8 @@ def main():
                 "points_per_iter_per_gpu": points, "levels": levels, "frames": args.frames,
                 "pool_samples": int(pool.sdf_label.shape[0]),
                 "corner_rows": [int(p.shape[0]) for p in octree.hier_features],
-                "morton_sorted": not args.no_sort, "parallelism": "dp%d" % world, "launch": launch,
+                "batch_order": "none" if args.no_sort else args.order, "parallelism": "dp%d" % world,
+                "launch": launch,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -109,18 +109,24 @@ int shine_interp_backward_backward(const shine_tables* t, const shine_step_confi
 /* ---- fused training step: query + decode + sdf_bce_loss (utils/loss.py:17-24) [+ eikonal
  *      (shine_batch.py:182-185)] + the whole backward (shine_batch.py:208-209) in one pass.
  *      Inputs : coord [N,3], sdf_label [N], weight [N] (sign = surface/free, data_sampler.py:102-103),
- *               perm [N] int32 or NULL, n_surf: device int64 (global #weight>0) or NULL when eikonal off.
+ *               perm [N] int32 or NULL (visiting order), slots [N,L] int32 or NULL (per point IN VISITING ORDER the
+ *               hash slot of its node at each level, -1 = miss; both come from shine_plan_batch),
+ *               n_surf: device int64 (global #weight>0) or NULL when eikonal off.
  *      Outputs: pred [N]; grad_x [N,3] or NULL; grad_feats[s] [rows_s+1, 8] and grad_mlp[6]
  *               ACCUMULATED INTO (caller zero-fills; matches autograd's dense grads incl. the
  *               trash row); loss_parts: device double[4] OVERWRITTEN with
  *               [0] BCE term (already reduced per cfg), [1] eikonal mean term (unweighted),
  *               [2] number of points processed, [3] [0] + weight_e * [1].
- *               The trash row of every feats[s] is re-zeroed (FeatureOctree.set_zero, :78-81). ---------- */
+ *               The trash row of every feats[s] is re-zeroed (FeatureOctree.set_zero, :78-81).
+ *               touched: NULL, or L device byte arrays [rows_s]: the step sets touched[s][r] = 1 for every row r
+ *               that received gradient (= the unique() of hierarchical_indices without -1), for shine_regularize. */
 int shine_train_step(const shine_tables* t, const shine_step_config* cfg, const float* coord,
-                     const float* sdf_label, const float* weight, const int32_t* perm, const int64_t* n_surf,
-                     int64_t n, const float* const* feats, const int64_t* rows, const float* const* mlp,
+                     const float* sdf_label, const float* weight, const int32_t* perm, const int32_t* slots,
+                     const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,
+                     const float* const* mlp,
                      float* pred_out, float* grad_x_out, float* const* grad_feats, float* const* grad_mlp,
-                     double* loss_parts, void* workspace, size_t workspace_bytes, void* stream);
+                     double* loss_parts, unsigned char* const* touched, void* workspace, size_t workspace_bytes,
+                     void* stream);
 /* bytes of device scratch shine_train_step wants for a batch of n points (per-workgroup partial sums of
  * the decoder / trash-row gradients, reduced by a second tiny kernel: deterministic, no hot-spot atomics).
  * workspace may be NULL (or too small): the step then falls back to fp32 atomics for those sums. */
@@ -131,6 +137,33 @@ size_t shine_train_step_workspace_bytes(const shine_step_config* cfg, int64_t n)
  *      passed as `perm` to shine_train_step.  Call with workspace == NULL to get the required bytes. --- */
 int shine_morton_sort(const shine_step_config* cfg, const float* coord, int64_t n, int32_t* perm_out,
                       void* workspace, size_t* workspace_bytes, void* stream);
+
+/* ---- incremental mapping epilogues (config/ncd/ncd_incre_reg.yaml)
+ *      shine_regularize = FeatureOctree.cal_regularization (model/feature_octree.py:246-255) on the rows flagged by the
+ *      last shine_train_step: *reg_out = sum importance*(F - F_last)^2 (unweighted; overwritten), and, for levels with
+ *      grad_on[s] != 0, grad_feats[s] += 2*lambda*importance*(F - F_last).  grad_on[s] = 0 is the reference's
+ *      attached-clone quirk (:160): value only.  Clears the flags.
+ *      shine_importance_accumulate = the per-chunk epilogue of cal_feature_importance (utils/incre_learning.py:36-40):
+ *      importance += |grad|, grad = 0, importance[trash row] = 0, for one level ([rows+1, 8] tensors). ------------- */
+int shine_regularize(int32_t n_levels, const float* const* feats, const float* const* feats_last,
+                     const float* const* importance, float* const* grad_feats, unsigned char* const* touched,
+                     const int64_t* rows, const int32_t* grad_on, float lambda_forget, double* reg_out, void* stream);
+int shine_importance_accumulate(float* importance, float* grad, int64_t rows, void* stream);
+
+/* ---- Batch plan: order a batch by octree node (counting sort) and remember every point's hash slots.
+ *      shine_tables_set_ranks: per level, the rank of every node in ONE Z-order over all featured levels (a parent's
+ *      own bucket right after its children's); n_buckets = number of nodes of all levels + 64 (miss buckets); call for every level
+ *      after the tree grew, the leaf level (slot L-1) last.  keys/ranks: device arrays of n entries.
+ *      shine_plan_batch: perm_out [N] int32 (visiting order) and slots_out [N,L] int32 (in visiting order) to pass
+ *      to shine_train_step.  zero_ptr/zero_bytes (16-B aligned, may be NULL/0): a buffer cleared in the same pass —
+ *      the flat gradient bucket, i.e. opt.zero_grad() for the fused step.  workspace == NULL returns the required
+ *      bytes.  Replaces shine_morton_sort on the training path: ~3 small launches, and the fused kernel no longer
+ *      hashes or probes. ------------------------------------------------------------------------------------------ */
+int shine_tables_set_ranks(shine_tables* t, int32_t slot, const int64_t* keys, const int32_t* ranks, int64_t n,
+                           int64_t n_buckets, void* stream);
+int shine_plan_batch(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,
+                     int32_t* perm_out, int32_t* slots_out, void* zero_ptr, size_t zero_bytes, void* workspace,
+                     size_t* workspace_bytes, void* stream);
 
 /* ---- device self-test: D[32,32] = A[32,2] . B[2,32] through ONE v_mfma_f32_32x32x2_f32, written back with the
  *      accumulator lane map the fused kernel relies on (pins the MFMA operand layouts on the hardware). --- */

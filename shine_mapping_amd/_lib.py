@@ -53,12 +53,19 @@ _SIGNATURES = {
     ),
     "shine_train_step": (
         C.c_int,
-        [_P, C.POINTER(StepConfig), _P, _P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64),
-         C.POINTER(_P), _P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P, C.c_size_t, _P],
+        [_P, C.POINTER(StepConfig), _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64),
+         C.POINTER(_P), _P, _P, C.POINTER(_P), C.POINTER(_P), _P, C.POINTER(_P), _P, C.c_size_t, _P],
     ),
+    "shine_regularize": (
+        C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                  C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_float, _P, _P]),
+    "shine_importance_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
     "shine_train_step_workspace_bytes": (C.c_size_t, [C.POINTER(StepConfig), C.c_int64]),
     "shine_morton_sort": (C.c_int, [C.POINTER(StepConfig), _P, C.c_int64, _P, _P, C.POINTER(C.c_size_t), _P]),
     "shine_selftest_mfma": (C.c_int, [_P, _P, _P, _P]),
+    "shine_tables_set_ranks": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, C.c_int64, _P]),
+    "shine_plan_batch": (C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, _P, _P, _P, C.c_size_t, _P,
+                                   C.POINTER(C.c_size_t), _P]),
     "shine_interp_backward": (
         C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P,
                   C.POINTER(_P), _P]),

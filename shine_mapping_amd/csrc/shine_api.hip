@@ -30,9 +30,10 @@ extern "C" int shine_train_step_v0(const shine_tables*, const shine_step_config*
                                    double*, void*);
 
 extern "C" int shine_train_step_v1(const shine_tables*, const shine_step_config*, const float*, const float*,
-                                   const float*, const int32_t*, const int64_t*, int64_t, const float* const*,
+                                   const float*, const int32_t*, const int32_t*, const int64_t*, int64_t,
+                                   const float* const*,
                                    const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
-                                   double*, void*, size_t, void*);
+                                   double*, unsigned char* const*, void*, size_t, void*);
 
 extern "C" int shine_version(void) { return 100; }
 
@@ -50,10 +51,10 @@ extern "C" const char* shine_error_string(int code) {
 
 extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                                 const float* sdf_label, const float* weight, const int32_t* perm,
-                                const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,
-                                const float* const* mlp, float* pred_out, float* grad_x_out, float* const* grad_feats,
-                                float* const* grad_mlp, double* loss_parts, void* workspace, size_t workspace_bytes,
-                                void* stream) {
+                                const int32_t* slots, const int64_t* n_surf, int64_t n, const float* const* feats,
+                                const int64_t* rows, const float* const* mlp, float* pred_out, float* grad_x_out,
+                                float* const* grad_feats, float* const* grad_mlp, double* loss_parts,
+                                unsigned char* const* touched, void* workspace, size_t workspace_bytes, void* stream) {
   if (!cfg) return shine::set_error(SHINE_E_INVALID, "shine_train_step: null config");
   if (n == 0) {  // empty batch: nothing to add to the grads, loss terms are zero
     if (loss_parts && hipMemsetAsync(loss_parts, 0, 4 * sizeof(double), (hipStream_t)stream) != hipSuccess)
@@ -64,10 +65,13 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
     const char* e = getenv("SHINE_KERNEL");
     return (e && strcmp(e, "v0") == 0) ? 1 : 0;
   }();
-  // v1 (MFMA decoder, run-length scatter) covers the BCE step; the eikonal step still runs on v0
-  if (!force_v0 && (cfg->kernel_variant & 0xff) != 1 && !cfg->eikonal_on && cfg->n_levels <= 4)
-    return shine_train_step_v1(t, cfg, coord, sdf_label, weight, perm, n_surf, n, feats, rows, mlp, pred_out,
-                               grad_x_out, grad_feats, grad_mlp, loss_parts, workspace, workspace_bytes, stream);
+  // v1 (MFMA decoder, run-length scatter) handles up to 4 featured levels (every shipped yaml); v0 is the
+  // simple cross-check kernel and the fallback for deeper trees
+  if (!force_v0 && (cfg->kernel_variant & 0xff) != 1 && cfg->n_levels <= 4)
+    return shine_train_step_v1(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
+                               grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,
+                               stream);
+  if (touched) return shine::set_error(SHINE_E_INVALID, "shine_train_step: touched flags need <= 4 featured levels");
   return shine_train_step_v0(t, cfg, coord, sdf_label, weight, perm, n_surf, n, feats, rows, mlp, pred_out,
                              grad_x_out, grad_feats, grad_mlp, loss_parts, stream);
 }

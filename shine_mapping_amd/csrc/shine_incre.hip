@@ -1,0 +1,120 @@
+// shine_incre.hip — the incremental-mapping epilogues of the hot path (config ncd_incre_reg):
+//
+//   shine_regularize             FeatureOctree.cal_regularization   model/feature_octree.py:246-255
+//       reg = sum_levels sum_{u in unique(hierarchical_indices)} importance[u] * (F[u] - F_last[u])^2
+//       The reference finds the touched rows with a sort-based unique() of 8N int64 per level per iteration; here
+//       the fused step leaves a byte flag per touched row (shine_train_step `touched`), and one row-parallel
+//       pass evaluates value and gradient and clears the flags.  grad_on[s] = 0 reproduces the reference's
+//       attached-clone quirk (:160): the term adds to the loss value but not to the gradient.
+//   shine_importance_accumulate  the per-chunk epilogue of cal_feature_importance   utils/incre_learning.py:36-40
+//       importance += |grad| ; grad = 0 ; importance[trash row] = 0
+#include "shine_internal.hpp"
+
+namespace shine {
+
+struct RegArgs {
+  const float* feat[SHINE_MAX_LEVELS];
+  const float* last[SHINE_MAX_LEVELS];
+  const float* imp[SHINE_MAX_LEVELS];
+  float* grad[SHINE_MAX_LEVELS];
+  unsigned char* touched[SHINE_MAX_LEVELS];
+  long long rows[SHINE_MAX_LEVELS];
+  long long start[SHINE_MAX_LEVELS + 1];  // prefix of rows over levels (work partition)
+  int grad_on[SHINE_MAX_LEVELS];
+  int n_levels;
+  float lambda;
+  double* out;  // out[0] += reg (unweighted)
+};
+
+__global__ __launch_bounds__(256) void k_regularize(RegArgs a) {
+  __shared__ double s_red[4];
+  double acc = 0.0;
+  const long long total = a.start[a.n_levels] * F;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long row_g = e / F;
+    const int q = (int)(e % F);
+    int s = 0;
+    while (s + 1 < a.n_levels && row_g >= a.start[s + 1]) ++s;
+    const long long r = row_g - a.start[s];
+    if (a.touched[s][r]) {
+      const long long idx = r * F + q;
+      const float d = a.feat[s][idx] - a.last[s][idx];
+      const float w = a.imp[s][idx];
+      acc += (double)(w * d * d);
+      if (a.grad_on[s] && a.grad[s]) a.grad[s][idx] += 2.0f * a.lambda * w * d;  // one thread per element: no atomics
+    }
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(a.out, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_clear_touched(RegArgs a) {
+  const long long total = a.start[a.n_levels];
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    int s = 0;
+    while (s + 1 < a.n_levels && e >= a.start[s + 1]) ++s;
+    a.touched[s][e - a.start[s]] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_importance(float* imp, float* grad, long long n_elems, long long trash_begin) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n_elems; e += (long long)gridDim.x * 256) {
+    const float g = grad[e];
+    grad[e] = 0.f;
+    imp[e] = e >= trash_begin ? 0.f : imp[e] + fabsf(g);
+  }
+}
+
+}  // namespace shine
+
+using namespace shine;
+
+extern "C" int shine_regularize(int32_t n_levels, const float* const* feats, const float* const* feats_last,
+                                const float* const* importance, float* const* grad_feats,
+                                unsigned char* const* touched, const int64_t* rows, const int32_t* grad_on,
+                                float lambda_forget, double* reg_out, void* stream) {
+  if (n_levels < 1 || n_levels > SHINE_MAX_LEVELS || !feats || !feats_last || !importance || !touched || !rows ||
+      !reg_out)
+    return set_error(SHINE_E_INVALID, "shine_regularize: null argument");
+  RegArgs a = {};
+  a.n_levels = n_levels;
+  a.lambda = lambda_forget;
+  a.out = reg_out;
+  a.start[0] = 0;
+  for (int s = 0; s < n_levels; ++s) {
+    if (!feats[s] || !feats_last[s] || !importance[s] || !touched[s])
+      return set_error(SHINE_E_INVALID, "shine_regularize: null level pointer");
+    a.feat[s] = feats[s];
+    a.last[s] = feats_last[s];
+    a.imp[s] = importance[s];
+    a.grad[s] = grad_feats ? grad_feats[s] : nullptr;
+    a.touched[s] = touched[s];
+    a.rows[s] = rows[s];
+    a.grad_on[s] = grad_on ? grad_on[s] : 1;
+    a.start[s + 1] = a.start[s] + rows[s];  // the trash row is excluded: its importance is reset to 0 (incre_learning.py:40)
+  }
+  hipStream_t st = (hipStream_t)stream;
+  SHINE_HIP_CHECK(hipMemsetAsync(reg_out, 0, sizeof(double), st));
+  const long long total = a.start[n_levels] * F;
+  if (total == 0) return SHINE_OK;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_regularize, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  SHINE_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_clear_touched, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
+}
+
+extern "C" int shine_importance_accumulate(float* importance, float* grad, int64_t rows, void* stream) {
+  if (!importance || !grad || rows < 0) return set_error(SHINE_E_INVALID, "shine_importance_accumulate: null argument");
+  const long long n_elems = (rows + 1) * F;
+  long long blocks = (n_elems + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_importance, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, importance, grad, n_elems,
+                     (long long)rows * F);
+  SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
+}

@@ -11,6 +11,7 @@ namespace shine {
 struct TableLevel {
   unsigned long long* keys = nullptr;
   int* vals = nullptr;
+  int* ranks = nullptr;  // [cap] bucket rank of the node in the all-level Z-order (shine_tables_set_ranks), or null
   long long cap = 0;
   long long count = 0;
   unsigned int shift = 0;
@@ -24,6 +25,7 @@ int set_hip_error(hipError_t e, const char* what);
 
 struct shine_tables {
   int n_levels = 0;
+  long long n_buckets = 0;  // nodes of all featured levels + 1 ("misses everywhere"); 0: ranks not set
   shine::TableLevel lv[SHINE_MAX_LEVELS];
 };
 

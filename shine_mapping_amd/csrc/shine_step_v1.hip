@@ -1,28 +1,33 @@
-// shine_step_v1.hip — the fused SHINE training step for gfx950 (BCE path), MI355X-first.
+// shine_step_v1.hip — the fused SHINE training step for gfx950, MI355X-first.
 //
 //   query    FeatureOctree.query_feature   model/feature_octree.py:199-244
 //   decode   Decoder.sdf                   model/decoder.py:49-63
-//   loss     sdf_bce_loss                  utils/loss.py:17-24
-//   backward cur_loss.backward()           shine_batch.py:208-209 (closed form)
+//   loss     sdf_bce_loss, eikonal term    utils/loss.py:17-24, shine_batch.py:141-142,182-185 (get_gradient: utils/tools.py:175-185)
+//   backward cur_loss.backward()           shine_batch.py:208-209 (closed form, SURVEY.md §8a math contract)
 //
 // One wave owns a contiguous run of the Morton-sorted batch and walks it in tiles of 32 points.
 //   lane = (pt = lane & 31, h = lane >> 5): the two half-waves hold features 4h..4h+3 of the same 32 points,
 //   which is exactly the B-operand / C-accumulator shape of v_mfma_f32_32x32x2_f32 (exact fp32):
 //     D[32 channels x 32 points] += A[32 x 2] . B[2 x 32],   lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
 //     acc reg r of lane l = D[row (r&3) + 8(r>>2) + 4(l>>5)][col l&31].
-//   * decoder forward/backward are chained MFMAs that never leave registers: the k-order of each product is
-//     permuted to the accumulator row order of the previous one (k(t,h) = rowidx(t,h)), so the ReLU'd
-//     accumulator register t IS the next B operand; the matching A operands are pre-permuted once per block
-//     into LDS (s_opA);
-//   * the weight-grad GEMMs contract over POINTS, so their operands are the transposes: d2/h1/d1/f go once
-//     through a padded [32][33] LDS tile per wave, and accumulate into MFMA accumulators that live in registers
-//     for the whole kernel (flushed once per wave);
-//   * feature grads: lane = (corner c = lane>>3, feature q = lane&7); the wave walks its sorted points and
-//     keeps a running sum per level while the node (hence the 8 corner rows) stays the same, so one
-//     64-lane global_atomic_add_f32 (8 rows x 32 B) is issued per NODE RUN instead of per point; misses
-//     (index -1, the trash row :205,231) are summed in registers for the whole kernel;
-//   * decoder / trash-row / loss sums leave the block as one partial vector in the caller's workspace and a
-//     second tiny kernel adds them up: no hot-spot atomics, deterministic.
+//   * query: leaf Morton key once (parents are key >> 3), first-slot key loads of every level issued together,
+//     then ids and 16-B row gathers two levels at a time; a miss reads row 0 with weight 0 (no branches);
+//   * decoder forward/backward (and the eikonal chain v1, J, a1, a2) are chained MFMAs that never leave
+//     registers: the k-order of each product is permuted to the accumulator row order of the previous one
+//     (k(t,h) = rowidx(t,h)), so the ReLU'd accumulator register t IS the next B operand; the matching A
+//     operands are pre-permuted once per workgroup into LDS (s_opA);
+//   * decoder weight grads contract over POINTS, so their operands are the transposes: d2/h1, d1/f (and v2/a1,
+//     v1/r for the eikonal term) go through a padded [32][33] LDS tile pair per wave and accumulate in MFMA
+//     accumulators that live in registers for the whole kernel; db1 rides in a spare MFMA column, db2 is the
+//     sum of the transposed operands that are loaded anyway;
+//   * feature grads: lane = (corner c = lane>>3, feature q = lane&7); node-run boundaries / hits of the sorted
+//     stream are wave-uniform bit masks, the wave keeps a running sum while the node stays the same and issues
+//     ONE 64-lane global_atomic_add_f32 (8 rows x 32 B) per node run; misses (index -1, the trash row :205,231)
+//     are summed in registers for the whole kernel;
+//   * decoder / trash-row / loss sums leave the workgroup as one partial vector in the caller's workspace and a
+//     second tiny kernel adds them up (deterministic, no hot-spot atomics), re-zeroes the trash rows
+//     (set_zero, :78-81) and finalises the loss.
+// Workgroup = 512 threads (8 waves, 2 per SIMD), one per CU: ~151 KB of LDS, ~17 KB of it private to each wave.
 #include "shine_internal.hpp"
 
 namespace shine {
@@ -30,23 +35,26 @@ namespace shine {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LCAP = 4;        // featured levels handled by this kernel (tree_level_feat <= 4 in every yaml)
+constexpr int WAVES = 8;       // waves per workgroup
+constexpr int NT = WAVES * 64;
 constexpr int TP = 33;         // transpose tile pitch (floats)
 constexpr int WP = 36;         // pitch of the [corner][point] / [feature][point] staging rows (conflict-free b128 reads)
-constexpr int U_IDS = LCAP * 8 * WP;             // ids  [LCAP][8 corners][WP]      int32 (point-contiguous)
-constexpr int U_W = LCAP * 8 * WP;               // w    [LCAP][8 corners][WP]      (point-contiguous)
-constexpr int U_FLOATS = U_IDS + U_W;            // 2176 >= 2*32*TP = 2112 (the transpose tiles alias this region)
-constexpr int DF_FLOATS = 8 * WP;                // df   [8 features][WP]
-constexpr int WAVE_FLOATS = U_FLOATS + DF_FLOATS;
+constexpr int U_IDS = LCAP * 8 * WP;             // ids  [LCAP][8 corners][WP]  int32 (point-contiguous)
+constexpr int U_W = LCAP * 8 * WP;               // w    [LCAP][8 corners][WP]
+constexpr int R2_TL = 0, R2_TR = 32 * TP;        // region 2, first life: the two transpose tiles
+constexpr int R2_DF = 0, R2_J = 8 * WP, R2_CQ = 16 * WP;  // second life: df [8][WP], J [8][WP], cq [LCAP][8][WP]
+constexpr int R2_FLOATS = 2 * 32 * TP;           // 2112
+constexpr int WAVE_FLOATS = U_IDS + U_W + R2_FLOATS;  // 4416 floats = 17,664 B per wave
 constexpr int OP_A1 = 0, OP_A2 = 4 * 64, OP_A2T = 20 * 64, OP_A1T = 36 * 64, OP_TOTAL = 52 * 64;
 constexpr int SB_B1 = 0, SB_B2 = 32, SB_W3 = 64, SB_B3 = 96;
-constexpr int PART_TRASH = SHINE_MLP_PARAMS;               // + s*8 + q
-constexpr int PART_FLOATS = PART_TRASH + SHINE_MAX_LEVELS * 8;  // 1441
-constexpr int PART_LOSS = 1444;                            // float index of double[2] {loss, count} (8-B aligned)
-constexpr int PART_STRIDE = 1448;
+constexpr int PART_TRASH = SHINE_MLP_PARAMS;                     // + s*8 + q
+constexpr int PART_FLOATS = PART_TRASH + SHINE_MAX_LEVELS * 8;   // 1441
+constexpr int PART_LOSS = 1444;   // float index of double[3] {bce sum, count, eikonal sum} (8-B aligned)
+constexpr int PART_STRIDE = 1456;
 
-static_assert(LCAP % 2 == 0, "levels are processed in pairs");
-static_assert(2 * 32 * TP <= U_FLOATS, "staging region must hold the two transpose tiles");
-static_assert((PART_LOSS * 4) % 8 == 0 && PART_LOSS >= PART_FLOATS, "loss slot");
+static_assert(16 * WP + LCAP * 8 * WP <= R2_FLOATS, "df/J/cq must fit the transpose region");
+static_assert((PART_LOSS * 4) % 8 == 0 && PART_LOSS >= PART_FLOATS && PART_LOSS + 6 <= PART_STRIDE, "loss slot");
+static_assert(PART_STRIDE <= WAVE_FLOATS, "each wave's partial vector aliases its staging region at the end");
 
 // what the hot loop needs per level, nothing else (SGPR budget)
 struct V1Level {
@@ -62,15 +70,21 @@ struct V1Level {
 struct V1Args {
   V1Level lv[LCAP];
   long long rows[LCAP];
+  float* feat_rw[LCAP];  // same tables, writable: the trash row is re-zeroed in-kernel (set_zero, :78-81)
+  unsigned char* touched[LCAP];  // optional byte flag per row that received gradient (for shine_regularize)
   const float* coord;
   const float* label;
+  const float* weight;
   const int* perm;
+  const int* slots;  // [n][L] hash slots per point IN VISITING ORDER (shine_plan_batch), or null: probe in-kernel
+  const long long* n_surf;
   const float* mlp[6];
   float* pred;
+  float* grad_x;
   float* grad_mlp[6];
   double* loss_parts;
   float* partials;
-  float* feat_rw[LCAP];  // same tables, writable: the trash row is re-zeroed in-kernel (set_zero, :78-81)
+  long long* prof;  // debug: per-wave phase cycle counters [waves][8] (shine_debug_set_profile_buffer) or null
   long long n;
   long long chunk;
   int n_levels;
@@ -81,7 +95,7 @@ struct V1Args {
                // 8 no row gathers, 16 no probe (every point misses)
   float sigma;
   float inv_n;
-  long long* prof;  // debug: per-wave phase cycle counters [waves][8] (shine_debug_set_profile_buffer) or null
+  float weight_e;
 };
 
 __device__ __forceinline__ long long clk() { return (long long)__builtin_readcyclecounter(); }
@@ -90,6 +104,13 @@ __device__ __forceinline__ int rowidx(int r, int h) { return (r & 3) + 8 * (r >>
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
 }
 
 // wave-local LDS hand-off: DS ops of one wave execute in order; this only stops the compiler reordering them
@@ -108,17 +129,46 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// d w_c / d x for ONE corner (keeps the eikonal path's live set small; corner_weight_grads builds all 24 values)
+__device__ __forceinline__ void corner_dw(const Axis& X, const Axis& Y, const Axis& Z, int c, float out[3]) {
+  const int cx = (c >> 2) & 1, cy = (c >> 1) & 1, cz = c & 1;
+  const float px = cx ? X.t : 1.0f - X.t, py = cy ? Y.t : 1.0f - Y.t, pz = cz ? Z.t : 1.0f - Z.t;
+  const float gx = cx ? X.dt : -X.dt, gy = cy ? Y.dt : -Y.dt, gz = cz ? Z.dt : -Z.dt;
+  out[0] = gx * py * pz;
+  out[1] = px * gy * pz;
+  out[2] = px * py * gz;
+}
+
 __device__ __forceinline__ Axis axis_weight_rt(bool poly, float x, float res) {
   return poly ? axis_weight<true>(x, res, res * 0.5f) : axis_weight<false>(x, res, res * 0.5f);
 }
 
-template <int L, bool PROF>
-__global__ __launch_bounds__(256, 2) void k_step_v1(V1Args a) {
+// one transposed weight-grad pass: acc[i][j] += sum_k L[i][k] * R[j][k] over the tile's 32 points.
+// TL/TR hold the operands as [channel][point]; RCOLS < 32 zero-fills the unused B columns, ONES makes column
+// RCOLS all ones (so acc[:, RCOLS] = sum_k L[i][k]); lsum, if given, accumulates this lane's L operands.
+template <int RCOLS, bool ONES>
+__device__ __forceinline__ f32x16 wgrad_pass(const float* TL, const float* TR, int pt, int h, f32x16 acc, float* lsum) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int k = 2 * t + h;
+    const float l = TL[pt * TP + k];
+    if (lsum) *lsum += l;
+    float b;
+    if (RCOLS == 32)
+      b = TR[pt * TP + k];
+    else
+      b = pt < RCOLS ? TR[pt * TP + k] : ((ONES && pt == RCOLS) ? 1.f : 0.f);
+    acc = mfma32(l, b, acc);
+  }
+  return acc;
+}
+
+template <int L, bool EIK, bool PROF>
+__global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   __shared__ float s_opA[OP_TOTAL];
   __shared__ float s_bias[100];
-  __shared__ float s_part[PART_STRIDE];
-  __shared__ double s_loss[2];
-  __shared__ float s_wave[4][WAVE_FLOATS];
+  __shared__ double s_loss[4];
+  __shared__ float s_wave[WAVES][WAVE_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pt = lane & 31, h = lane >> 5;
@@ -132,54 +182,53 @@ __global__ __launch_bounds__(256, 2) void k_step_v1(V1Args a) {
     tk = now__;                   \
   }
 
-  // ---- per-block setup: A operands in MFMA lane order, biases, zeroed partial vector
-  for (int idx = tid; idx < OP_TOTAL; idx += 256) {
-    const int t = idx >> 6, l = idx & 63, li = l & 31, lh = l >> 5;
-    float v;
-    if (t < 4) {
-      v = a.mlp[0][li * F + 4 * lh + t];                       // W1[ch=li][k = 4h+t]
-    } else if (t < 20) {
-      v = a.mlp[2][li * H + rowidx(t - 4, lh)];                // W2[out=li][in = rowidx]
-    } else if (t < 36) {
-      v = a.mlp[2][rowidx(t - 20, lh) * H + li];               // W2^T[in=li][out = rowidx]
-    } else {
-      v = li < F ? a.mlp[0][rowidx(t - 36, lh) * F + li] : 0.f;  // W1^T[feat=li][ch = rowidx], rows >= 8 zero
+  // ---- per-workgroup setup: A operands in MFMA lane order, biases
+#pragma unroll
+  for (int it = 0; it < (OP_TOTAL + NT - 1) / NT; ++it) {  // branch-free source select: the loads of all passes overlap
+    const int idx = it * NT + tid;
+    if (idx < OP_TOTAL) {
+      const int t = idx >> 6, l = idx & 63, li = l & 31, lh = l >> 5;
+      const float* src = t < 4    ? a.mlp[0] + li * F + 4 * lh + t                   // W1[ch=li][k = 4h+t]
+                         : t < 20 ? a.mlp[2] + li * H + rowidx((t - 4) & 15, lh)      // W2[out=li][in = rowidx]
+                         : t < 36 ? a.mlp[2] + rowidx((t - 20) & 15, lh) * H + li     // W2^T[in=li][out = rowidx]
+                                  : a.mlp[0] + rowidx((t - 36) & 15, lh) * F + (li & 7);  // W1^T[feat=li][ch], rows >= 8 zero
+      const float v = *src;
+      s_opA[idx] = (t >= 36 && li >= F) ? 0.f : v;
     }
-    s_opA[idx] = v;
   }
-  for (int idx = tid; idx < 32; idx += 256) {
-    s_bias[SB_B1 + idx] = a.mlp[1][idx];
-    s_bias[SB_B2 + idx] = a.mlp[3][idx];
-    s_bias[SB_W3 + idx] = a.mlp[4][idx];
+  if (tid < 32) {
+    s_bias[SB_B1 + tid] = a.mlp[1][tid];
+    s_bias[SB_B2 + tid] = a.mlp[3][tid];
+    s_bias[SB_W3 + tid] = a.mlp[4][tid];
   }
   if (tid == 0) {
     s_bias[SB_B3] = a.mlp[5][0];
-    s_loss[0] = 0.0;
-    s_loss[1] = 0.0;
+    s_loss[0] = s_loss[1] = s_loss[2] = s_loss[3] = 0.0;
   }
-  for (int idx = tid; idx < PART_STRIDE; idx += 256) s_part[idx] = 0.f;
   __syncthreads();
 
   float* U = s_wave[wv];
-  int* U_ids = reinterpret_cast<int*>(U);        // [LCAP][8][WP]
-  float* U_w = U + U_IDS;                        // [LCAP][8][WP]
-  float* TL = U;                                 // [32][TP]   (aliases the staging above, used after the scatter)
-  float* TR = U + 32 * TP;                       // [32][TP]
-  float* s_df = U + U_FLOATS;                    // [8][WP]
+  int* U_ids = reinterpret_cast<int*>(U);  // [LCAP][8][WP]
+  float* U_w = U + U_IDS;                  // [LCAP][8][WP]
+  float* R2 = U + U_IDS + U_W;             // transposes, then df / J / cq
+  float* TL = R2 + R2_TL;
+  float* TR = R2 + R2_TR;
 
   const float b3 = s_bias[SB_B3];
+  const float sigma = a.sigma;
+  float inv_nsurf = 0.f;
+  if (EIK) {
+    const long long ns = a.n_surf ? *a.n_surf : 0;
+    inv_nsurf = ns > 0 ? 1.0f / (float)ns : 0.f;
+  }
 
-  f32x16 accW2, accW1;
-  float dw3c[16];   // sum_p delta_p h2[ch][p] for this lane's point column, reduced over lanes once per wave
+  f32x16 accW2 = zero16(), accW1 = zero16();
+  float dw3c[16];      // sum_p delta_p h2[ch][p] (+ a2) for this lane's point column, reduced over lanes once per wave
   float db2acc = 0.f;  // sum_p d2[ch = lane&31][p] for the points of this half-wave's parity (transposed reads)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    accW2[r] = 0.f;
-    accW1[r] = 0.f;
-    dw3c[r] = 0.f;
-  }
+  for (int r = 0; r < 16; ++r) dw3c[r] = 0.f;
   float db3 = 0.f;
-  double loss_acc = 0.0, cnt_acc = 0.0;
+  double loss_acc = 0.0, cnt_acc = 0.0, eik_acc = 0.0;
   int run_id[LCAP];      // corner id (this lane's corner) of the node run in progress, -1: none / a run of misses
   int last_slot[LCAP];   // node (hash slot) of the previous point, wave-uniform: carries runs across tiles
   float run_acc[LCAP], trash_acc[LCAP];
@@ -192,45 +241,64 @@ __global__ __launch_bounds__(256, 2) void k_step_v1(V1Args a) {
   }
   const int sc = lane >> 3, sq = lane & 7;  // scatter role: corner, feature
 
-  const long long wave_g = (long long)blockIdx.x * 4 + wv;
+  const long long wave_g = (long long)blockIdx.x * WAVES + wv;
   const long long begin = wave_g * a.chunk;
   const long long end = (begin + a.chunk < a.n) ? begin + a.chunk : a.n;
-  SHINE_STAMP(0)  // setup
 
   // software prefetch of the {perm -> coord, label} chain: tile t+1's point is fetched while tile t computes
   long long np = 0;
-  float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, nlabel = 0.f;
+  float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, nlabel = 0.f, nweight = 0.f;
+  int nslot[LCAP];
+#pragma unroll
+  for (int s = 0; s < LCAP; ++s) nslot[s] = -1;
   bool nvalid = begin + pt < end;
   if (nvalid) {
+    if (a.slots) {
+#pragma unroll
+      for (int s = 0; s < L; ++s) nslot[s] = a.slots[(begin + pt) * L + s];
+    }
     np = a.perm ? (long long)a.perm[begin + pt] : begin + pt;
     nx0 = a.coord[3 * np];
     nx1 = a.coord[3 * np + 1];
     nx2 = a.coord[3 * np + 2];
     nlabel = a.label[np];
+    if (EIK) nweight = a.weight[np];
   }
+  SHINE_STAMP(0)  // setup
 
   for (long long base = begin; base < end; base += 32) {
     const bool valid = nvalid;
     const long long p = np;
-    const float x0 = nx0, x1 = nx1, x2 = nx2, label = nlabel;
+    const float x0 = nx0, x1 = nx1, x2 = nx2, label = nlabel, wgt = nweight;
+    int pslot[LCAP];
+#pragma unroll
+    for (int s = 0; s < LCAP; ++s) pslot[s] = nslot[s];
     {
       const long long ni = base + 32 + pt;
       nvalid = ni < end;
       np = 0;
-      nx0 = nx1 = nx2 = nlabel = 0.f;
+      nx0 = nx1 = nx2 = nlabel = nweight = 0.f;
+#pragma unroll
+      for (int s = 0; s < LCAP; ++s) nslot[s] = -1;
       if (nvalid) {
+        if (a.slots) {
+#pragma unroll
+          for (int s = 0; s < L; ++s) nslot[s] = a.slots[ni * L + s];
+        }
         np = a.perm ? (long long)a.perm[ni] : ni;
         nx0 = a.coord[3 * np];
         nx1 = a.coord[3 * np + 1];
         nx2 = a.coord[3 * np + 2];
         nlabel = a.label[np];
+        if (EIK) nweight = a.weight[np];
       }
     }
 
     // ================================================================ phase 1: query (all levels)
-    // Straight-line across levels so the L independent {probe -> ids -> 8 rows} chains overlap: first-slot key
-    // loads for every level, then ids, then rows (a miss reads row 0 with weight 0 instead of branching).
     float f4[4] = {0.f, 0.f, 0.f, 0.f};
+    float A4[4][3];  // EIK: d f_{4h+q} / d x_a
+#pragma unroll
+    for (int q = 0; q < 4; ++q) A4[q][0] = A4[q][1] = A4[q][2] = 0.f;
     unsigned int chgmask[LCAP], hitmask[LCAP];
     const unsigned int validmask = (unsigned int)__ballot(valid);
 #pragma unroll
@@ -239,10 +307,14 @@ __global__ __launch_bounds__(256, 2) void k_step_v1(V1Args a) {
       hitmask[s] = 0;
     }
     // leaf-level key once; a parent's Morton code is the child's >> 3 (quantisation is exact power-of-two scaling)
+    int slot[LCAP];
+    if (a.slots) {  // planned batch: the slots were found by shine_plan_batch (wave-uniform branch)
+#pragma unroll
+      for (int s = 0; s < L; ++s) slot[s] = (valid && !(a.ablate & 16)) ? pslot[s] : -1;
+    } else {
     unsigned long long key[LCAP];
     unsigned int slot0[LCAP];
     unsigned long long k0[LCAP];
-    int slot[LCAP];
     {
       const float rl = a.lv[L - 1].res;
       const unsigned long long kleaf = morton3(quantize(x0, rl), quantize(x1, rl), quantize(x2, rl));
@@ -273,19 +345,18 @@ __global__ __launch_bounds__(256, 2) void k_step_v1(V1Args a) {
       }
       slot[s] = (valid && !(a.ablate & 16)) ? sl : -1;
     }
-#pragma unroll
-    for (int sp = 0; sp < L; sp += 2) {  // ids + rows of two levels in flight at a time (register budget)
+    }
     int4 i0[LCAP], i1[LCAP];
 #pragma unroll
-    for (int s = sp; s < (sp + 2 < L ? sp + 2 : L); ++s) {
+    for (int s = 0; s < L; ++s) {  // the corner ids of every level in flight together
       const V1Level& Lv = a.lv[s];
       const int sl = slot[s] >= 0 ? slot[s] : 0;
       i0[s] = Lv.vals[2 * sl];
       i1[s] = Lv.vals[2 * sl + 1];
     }
+    {
 #pragma unroll
-    for (int s = sp; s < (sp + 2 < L ? sp + 2 : L); ++s) {
-      {
+      for (int s = 0; s < L; ++s) {
         const V1Level& Lv = a.lv[s];
         const bool hit = slot[s] >= 0;
         // node-run boundaries of the sorted stream (wave-uniform bit masks over the 32 points of the tile)
@@ -302,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void k_step_v1(V1Args a) {
 #pragma unroll
           for (int c = 0; c < 8; ++c) w[c] = 0.f;  // padding lanes contribute nothing anywhere
         }
-        // staging for the scatter: ids [pt][8] (h=0 writes corners 0-3, h=1 corners 4-7), w [corner][pt]
+        // staging for the scatter (h = 0 writes corners 0-3, h = 1 corners 4-7), point-contiguous rows
         {
           const int m = hit ? 0 : -1;  // a miss stages -1 (trash row), never the speculative ids
           U_ids[(s * 8 + 4 * h + 0) * WP + pt] = (h == 0 ? i0[s].x : i1[s].x) | m;
@@ -323,13 +394,23 @@ __global__ __launch_bounds__(256, 2) void k_step_v1(V1Args a) {
             f4[1] = fmaf(wz, r.y, f4[1]);
             f4[2] = fmaf(wz, r.z, f4[2]);
             f4[3] = fmaf(wz, r.w, f4[3]);
+            if (EIK) {
+              const float rr[4] = {r.x, r.y, r.z, r.w};
+              float dwc[3];
+              corner_dw(X, Y, Z, c, dwc);
+#pragma unroll
+              for (int e = 0; e < 3; ++e) {
+                const float dz = hit ? dwc[e] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) A4[q][e] = fmaf(dz, rr[q], A4[q][e]);
+              }
+            }
           }
         }
       }
     }
-    }  // level pairs
-
     SHINE_STAMP(1)  // query
+
     // ================================================================ phase 2: decoder forward (MFMA chain)
     f32x16 c1, c2;
 #pragma unroll
@@ -353,19 +434,71 @@ __global__ __launch_bounds__(256, 2) void k_step_v1(V1Args a) {
     const float y = yp + __shfl_xor(yp, 32, 64) + b3;
     if (valid && h == 0 && a.pred) a.pred[p] = y;
 
+    // ---------------------------------------------------------------- eikonal: d pred / d coord (closed form)
+    float v1[16], J4[4], g[3] = {0.f, 0.f, 0.f};
+    if (EIK) {
+      f32x16 ev = zero16(), ej = zero16();
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        ev = mfma32(s_opA[OP_A2T + t * 64 + lane], h2[t] > 0.f ? s_bias[SB_W3 + rowidx(t, h)] : 0.f, ev);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v1[r] = h1[r] > 0.f ? ev[r] : 0.f;  // m1 .* (W2^T (m2 .* w3))
+#pragma unroll
+      for (int t = 0; t < 16; ++t) ej = mfma32(s_opA[OP_A1T + t * 64 + lane], v1[t], ej);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) J4[q] = ej[q];  // d y / d f_{4h+q}
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s = fmaf(J4[q], A4[q][e], s);
+        s += __shfl_xor(s, 32, 64);
+        g[e] = sigma * s;
+      }
+      if (valid && h == 0 && a.grad_x) {
+        a.grad_x[3 * p] = g[0];
+        a.grad_x[3 * p + 1] = g[1];
+        a.grad_x[3 * p + 2] = g[2];
+      }
+    }
     SHINE_STAMP(2)  // decoder forward
+
     // ================================================================ phase 3: loss
     float delta = 0.f;
+    float qv[3] = {0.f, 0.f, 0.f};
     if (valid) {
-      const float zt = sigmoidf_acc(label / a.sigma);
+      const float zt = sigmoidf_acc(label / sigma);
       if (h == 0) {
         loss_acc += (double)(fmaxf(y, 0.f) - y * zt + log1pf(expf(-fabsf(y))));
         cnt_acc += 1.0;
       }
       delta = (sigmoidf_acc(y) - zt) * a.inv_n;
+      if (EIK && wgt > 0.f) {
+        const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+        const float e = 1.0f - gn;
+        if (h == 0) eik_acc += (double)(e * e);
+        const float coef = gn > 0.f ? (-2.0f * e / gn) * (a.weight_e * inv_nsurf) : 0.f;  // norm's sub-gradient 0 at 0
+        qv[0] = coef * g[0];
+        qv[1] = coef * g[1];
+        qv[2] = coef * g[2];
+      }
     }
 
     // ================================================================ phase 4: backward through the decoder
+    float r4[4], a1[16];
+    if (EIK) {
+      f32x16 t1 = zero16(), t2 = zero16();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r4[q] = sigma * (A4[q][0] * qv[0] + A4[q][1] * qv[1] + A4[q][2] * qv[2]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) t1 = mfma32(s_opA[OP_A1 + t * 64 + lane], r4[t], t1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = h1[r] > 0.f ? t1[r] : 0.f;  // (W1 r) .* m1
+#pragma unroll
+      for (int t = 0; t < 16; ++t) t2 = mfma32(s_opA[OP_A2 + t * 64 + lane], a1[t], t2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dw3c[r] += h2[r] > 0.f ? t2[r] : 0.f;  // a2 = (W2 a1) .* m2
+    }
     float d2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -373,89 +506,18 @@ __global__ __launch_bounds__(256, 2) void k_step_v1(V1Args a) {
       dw3c[r] = fmaf(delta, h2[r], dw3c[r]);
     }
     if (h == 0) db3 += delta;
-    f32x16 e1, e0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      e1[r] = 0.f;
-      e0[r] = 0.f;
-    }
+    f32x16 e1 = zero16(), e0 = zero16();
 #pragma unroll
     for (int t = 0; t < 16; ++t) e1 = mfma32(s_opA[OP_A2T + t * 64 + lane], d2[t], e1);
     float d1[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      d1[r] = h1[r] > 0.f ? e1[r] : 0.f;
-    }
+    for (int r = 0; r < 16; ++r) d1[r] = h1[r] > 0.f ? e1[r] : 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) e0 = mfma32(s_opA[OP_A1T + t * 64 + lane], d1[t], e0);
     // rows 0..7 of e0 = d loss / d f ; lane (pt,h) holds rows 4h..4h+3 in regs 0..3
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s_df[(4 * h + q) * WP + pt] = e0[q];
-    wave_lds_fence();
-
+    const float df4[4] = {e0[0], e0[1], e0[2], e0[3]};
     SHINE_STAMP(3)  // loss + decoder backward
-    // ================================================================ phase 6: feature-grad scatter (run-length)
-    // lane = (corner sc, feature sq).  Run boundaries / hits are wave-uniform bit masks, so the loop below has
-    // scalar branches only; one 64-lane atomic (8 rows x 32 B) per node run, misses go to a register sum.
-    if (!(a.ablate & 4)) {
-#pragma unroll 1
-      for (int half = 0; half < 2; ++half) {  // 16 points at a time keeps the staged operands in 32 registers
-        float dfr[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 v = *reinterpret_cast<const float4*>(s_df + sq * WP + 16 * half + 4 * j);
-          dfr[4 * j] = v.x;
-          dfr[4 * j + 1] = v.y;
-          dfr[4 * j + 2] = v.z;
-          dfr[4 * j + 3] = v.w;
-        }
-#pragma unroll
-        for (int s = 0; s < L; ++s) {
-          {
-            float* gbase = a.lv[s].grad;
-            if (gbase) {
-              float wr[16];
-              int idr[16];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float4 v = *reinterpret_cast<const float4*>(U_w + (s * 8 + sc) * WP + 16 * half + 4 * j);
-                wr[4 * j] = v.x;
-                wr[4 * j + 1] = v.y;
-                wr[4 * j + 2] = v.z;
-                wr[4 * j + 3] = v.w;
-                const int4 u = *reinterpret_cast<const int4*>(U_ids + (s * 8 + sc) * WP + 16 * half + 4 * j);
-                idr[4 * j] = u.x;
-                idr[4 * j + 1] = u.y;
-                idr[4 * j + 2] = u.z;
-                idr[4 * j + 3] = u.w;
-              }
-              int rid = run_id[s];
-              float racc = run_acc[s], tacc = trash_acc[s];
-              const unsigned int cm = (chgmask[s] & validmask) >> (16 * half), hm = hitmask[s] >> (16 * half);
-#pragma unroll
-              for (int p2 = 0; p2 < 16; ++p2) {
-                if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
-                  if (rid >= 0 && !(a.ablate & 1)) atomic_add_f32(gbase + (long long)rid * F + sq, racc);
-                  racc = 0.f;
-                  rid = idr[p2];
-                }
-                const float v = wr[p2] * dfr[p2];
-                if (hm & (1u << p2))
-                  racc += v;
-                else
-                  tacc += v;  // padding lanes carry w = 0
-              }
-              run_id[s] = rid;
-              run_acc[s] = racc;
-              trash_acc[s] = tacc;
-            }
-          }
-        }
-      }
-    }
-    wave_lds_fence();
 
-    SHINE_STAMP(4)  // scatter
     // ================================================================ phase 5: decoder weight grads (transposed MFMA)
     if (a.decoder_grad_on && !(a.ablate & 2)) {
 #pragma unroll
@@ -464,116 +526,241 @@ __global__ __launch_bounds__(256, 2) void k_step_v1(V1Args a) {
         TR[rowidx(r, h) * TP + pt] = h1[r];
       }
       wave_lds_fence();
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int k = 2 * t + h;
-        const float d2t = TL[pt * TP + k];
-        db2acc += d2t;                                   // db2[out = pt] rides on the operand that is loaded anyway
-        accW2 = mfma32(d2t, TR[pt * TP + k], accW2);     // dW2[out][in] += d2[out][k] * h1[in][k]
-      }
+      accW2 = wgrad_pass<32, false>(TL, TR, pt, h, accW2, &db2acc);  // dW2[out][in] += d2[out][k] h1[in][k]; db2 rides
       wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = d1[r];
 #pragma unroll
       for (int q = 0; q < 4; ++q) TR[(4 * h + q) * TP + pt] = f4[q];
       wave_lds_fence();
+      // B columns 0..7 = f, column 8 = ones: accW1[:,8] accumulates db1 = sum_k d1[ch][k] in the spare MFMA lanes
+      accW1 = wgrad_pass<F, true>(TL, TR, pt, h, accW1, nullptr);    // dW1[ch][feat] += d1[ch][k] f[feat][k]
+      wave_lds_fence();
+      if (EIK) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int k = 2 * t + h;
-        // B columns 0..7 = f, column 8 = ones: accW1[:,8] accumulates db1 = sum_k d1[ch][k] in the spare MFMA lanes
-        const float b = pt < F ? TR[pt * TP + k] : (pt == F ? 1.f : 0.f);
-        accW1 = mfma32(TL[pt * TP + k], b, accW1);  // dW1[ch][feat] += d1[ch][k] * f[feat][k]
+        for (int r = 0; r < 16; ++r) {
+          TL[rowidx(r, h) * TP + pt] = h2[r] > 0.f ? s_bias[SB_W3 + rowidx(r, h)] : 0.f;  // v2
+          TR[rowidx(r, h) * TP + pt] = a1[r];
+        }
+        wave_lds_fence();
+        accW2 = wgrad_pass<32, false>(TL, TR, pt, h, accW2, nullptr);  // dW2 += v2 (x) a1
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = v1[r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) TR[(4 * h + q) * TP + pt] = r4[q];
+        wave_lds_fence();
+        accW1 = wgrad_pass<F, false>(TL, TR, pt, h, accW1, nullptr);   // dW1 += v1 (x) r   (no bias term)
+        wave_lds_fence();
+      }
+    }
+    SHINE_STAMP(5)  // weight grads
+
+    // ================================================================ phase 6: feature-grad scatter (run-length)
+    // stage df [feature][pt] (and, EIK, J and cq = sigma * (d w_c / d x . q)) in region 2, then
+    // lane = (corner sc, feature sq): run boundaries / hits are wave-uniform bit masks (scalar branches only);
+    // one 64-lane atomic (8 rows x 32 B) per node run, misses go to a register sum.
+    if (!(a.ablate & 4)) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) R2[R2_DF + (4 * h + q) * WP + pt] = df4[q];
+      if (EIK) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R2[R2_J + (4 * h + q) * WP + pt] = J4[q];
+#pragma unroll
+        for (int s = 0; s < L; ++s) {
+          const float res = a.lv[s].res;
+          Axis X = axis_weight_rt(poly, x0, res), Y = axis_weight_rt(poly, x1, res), Z = axis_weight_rt(poly, x2, res);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float d0[3], d1[3];
+            corner_dw(X, Y, Z, c, d0);
+            corner_dw(X, Y, Z, 4 + c, d1);
+            const float v = h == 0 ? (d0[0] * qv[0] + d0[1] * qv[1] + d0[2] * qv[2])
+                                   : (d1[0] * qv[0] + d1[1] * qv[1] + d1[2] * qv[2]);
+            R2[R2_CQ + (s * 8 + 4 * h + c) * WP + pt] = sigma * v;
+          }
+        }
+      }
+      wave_lds_fence();
+      constexpr int CH = EIK ? 8 : 16;  // points per chunk (register budget)
+#pragma unroll 1
+      for (int ch = 0; ch < 32 / CH; ++ch) {
+        float dfr[CH], jr[EIK ? CH : 1];
+#pragma unroll
+        for (int j = 0; j < CH / 4; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(R2 + R2_DF + sq * WP + CH * ch + 4 * j);
+          dfr[4 * j] = v.x;
+          dfr[4 * j + 1] = v.y;
+          dfr[4 * j + 2] = v.z;
+          dfr[4 * j + 3] = v.w;
+          if (EIK) {
+            const float4 u = *reinterpret_cast<const float4*>(R2 + R2_J + sq * WP + CH * ch + 4 * j);
+            jr[4 * j] = u.x;
+            jr[4 * j + 1] = u.y;
+            jr[4 * j + 2] = u.z;
+            jr[4 * j + 3] = u.w;
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < L; ++s) {
+          float* gbase = a.lv[s].grad;
+          if (gbase) {
+            float wr[CH], cqr[EIK ? CH : 1];
+            int idr[CH];
+#pragma unroll
+            for (int j = 0; j < CH / 4; ++j) {
+              const float4 v = *reinterpret_cast<const float4*>(U_w + (s * 8 + sc) * WP + CH * ch + 4 * j);
+              wr[4 * j] = v.x;
+              wr[4 * j + 1] = v.y;
+              wr[4 * j + 2] = v.z;
+              wr[4 * j + 3] = v.w;
+              const int4 u = *reinterpret_cast<const int4*>(U_ids + (s * 8 + sc) * WP + CH * ch + 4 * j);
+              idr[4 * j] = u.x;
+              idr[4 * j + 1] = u.y;
+              idr[4 * j + 2] = u.z;
+              idr[4 * j + 3] = u.w;
+              if (EIK) {
+                const float4 c4 = *reinterpret_cast<const float4*>(R2 + R2_CQ + (s * 8 + sc) * WP + CH * ch + 4 * j);
+                cqr[4 * j] = c4.x;
+                cqr[4 * j + 1] = c4.y;
+                cqr[4 * j + 2] = c4.z;
+                cqr[4 * j + 3] = c4.w;
+              }
+            }
+            int rid = run_id[s];
+            float racc = run_acc[s], tacc = trash_acc[s];
+            const unsigned int cm = (chgmask[s] & validmask) >> (CH * ch), hm = hitmask[s] >> (CH * ch);
+#pragma unroll
+            for (int p2 = 0; p2 < CH; ++p2) {
+              if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
+                if (rid >= 0 && !(a.ablate & 1)) atomic_add_f32(gbase + (long long)rid * F + sq, racc);
+                racc = 0.f;
+                rid = idr[p2];
+                if (a.touched[s] && sq == 0 && rid >= 0) a.touched[s][rid] = 1;  // idempotent plain store
+              }
+              float v = wr[p2] * dfr[p2];
+              if (EIK) v = fmaf(cqr[p2], jr[p2], v);
+              if (hm & (1u << p2))
+                racc += v;
+              else
+                tacc += v;  // padding lanes carry w = 0 (and q = 0)
+            }
+            run_id[s] = rid;
+            run_acc[s] = racc;
+            trash_acc[s] = tacc;
+          }
+        }
       }
       wave_lds_fence();
     }
-    SHINE_STAMP(5)  // weight grads
+    SHINE_STAMP(4)  // scatter
   }
 
   // ---- end of the wave's run: flush the open node runs
 #pragma unroll
   for (int s = 0; s < L; ++s) {
-    {
-      float* gbase = a.lv[s].grad;
-      if (gbase && run_id[s] >= 0) atomic_add_f32(gbase + (long long)run_id[s] * F + sq, run_acc[s]);
-      // trash row: sum the 8 corner lanes of each feature
-      float tsum = trash_acc[s];
-      tsum += __shfl_xor(tsum, 8, 64);
-      tsum += __shfl_xor(tsum, 16, 64);
-      tsum += __shfl_xor(tsum, 32, 64);
-      if (sc == 0 && tsum != 0.f) atomicAdd(&s_part[PART_TRASH + s * 8 + sq], tsum);
-    }
+    float* gbase = a.lv[s].grad;
+    if (gbase && run_id[s] >= 0) atomic_add_f32(gbase + (long long)run_id[s] * F + sq, run_acc[s]);
+  }
+  __syncthreads();  // every wave is done with its staging region: it now holds the wave's partial vector
+  // Each wave writes its sums with plain stores into ITS OWN region (no LDS atomics: 8 waves adding into the
+  // same 1377 addresses cost ~40k cycles), then the workgroup adds the 8 vectors in one pass.
+  float* wvec = s_wave[wv];
+#pragma unroll
+  for (int s = 0; s < L; ++s) {
+    // trash row: sum the 8 corner lanes of each feature
+    float tsum = trash_acc[s];
+    tsum += __shfl_xor(tsum, 8, 64);
+    tsum += __shfl_xor(tsum, 16, 64);
+    tsum += __shfl_xor(tsum, 32, 64);
+    if (sc == 0) wvec[PART_TRASH + s * 8 + sq] = tsum;
   }
   if (a.decoder_grad_on) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rowidx(r, h);
-      atomicAdd(&s_part[MLP_W2 + row * H + pt], accW2[r]);
-      if (pt < F) atomicAdd(&s_part[MLP_W1 + row * F + pt], accW1[r]);
-      if (pt == F) atomicAdd(&s_part[MLP_B1 + row], accW1[r]);
-      const float w3v = row16_sum(dw3c[r]);
-      if ((lane & 15) == 0) atomicAdd(&s_part[MLP_W3 + row], w3v);  // two DPP rows per half-wave
+      wvec[MLP_W2 + row * H + pt] = accW2[r];
+      if (pt <= F) wvec[pt < F ? MLP_W1 + row * F + pt : MLP_B1 + row] = accW1[r];  // column 8 of accW1 is db1
+      float w3v = row16_sum(dw3c[r]);
+      w3v += __shfl_xor(w3v, 16, 64);  // the half-wave's second DPP row
+      if (pt == 0) wvec[MLP_W3 + row] = w3v;
     }
-    atomicAdd(&s_part[MLP_B2 + pt], db2acc);  // the two half-waves hold the two point parities
-    float b3v = wave_sum(db3);
-    if (lane == 0) atomicAdd(&s_part[MLP_B3], b3v);
+    const float b2v = db2acc + __shfl_xor(db2acc, 32, 64);  // the two half-waves hold the two point parities
+    if (h == 0) wvec[MLP_B2 + pt] = b2v;
+    const float b3v = wave_sum(db3);
+    if (lane == 0) wvec[MLP_B3] = b3v;
   }
   {
     double ls = wave_sum_d(loss_acc), cs = wave_sum_d(cnt_acc);
+    double es = EIK ? wave_sum_d(eik_acc) : 0.0;
     if (lane == 0) {
       atomicAdd(&s_loss[0], ls);
       atomicAdd(&s_loss[1], cs);
+      if (EIK) atomicAdd(&s_loss[2], es);
     }
   }
   SHINE_STAMP(6)  // flush
   __syncthreads();
-  SHINE_STAMP(7)  // wait for the block
+  SHINE_STAMP(7)  // wait for the workgroup
   if (PROF && lane == 0) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) a.prof[wave_g * 8 + k] = pc[k];
   }
 
+  const int mlp_lo = a.decoder_grad_on ? 0 : SHINE_MLP_PARAMS;  // a frozen decoder has no sums to move
   if (a.partials) {
     float* dst = a.partials + (long long)blockIdx.x * PART_STRIDE;
-    for (int idx = tid; idx < PART_FLOATS; idx += 256) dst[idx] = s_part[idx];
+    for (int idx = tid; idx < PART_TRASH + L * 8; idx += NT) {
+      float v = 0.f;
+      if (idx >= mlp_lo) {
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += s_wave[w][idx];
+      }
+      dst[idx] = v;
+    }
+    for (int idx = PART_TRASH + L * 8 + tid; idx < PART_FLOATS; idx += NT) dst[idx] = 0.f;
     if (tid == 0) {
       double* dl = reinterpret_cast<double*>(dst + PART_LOSS);
       dl[0] = s_loss[0];
       dl[1] = s_loss[1];
+      dl[2] = s_loss[2];
     }
   } else {
-    // no workspace: hot-spot atomics (slower, not deterministic)
-    if (a.decoder_grad_on) {
-      for (int idx = tid; idx < SHINE_MLP_PARAMS; idx += 256) {
-        float v = s_part[idx];
-        float* d;
-        if (idx < MLP_B1) d = a.grad_mlp[0] + idx;
-        else if (idx < MLP_W2) d = a.grad_mlp[1] + (idx - MLP_B1);
-        else if (idx < MLP_B2) d = a.grad_mlp[2] + (idx - MLP_W2);
-        else if (idx < MLP_W3) d = a.grad_mlp[3] + (idx - MLP_B2);
-        else if (idx < MLP_B3) d = a.grad_mlp[4] + (idx - MLP_W3);
-        else d = a.grad_mlp[5];
-        if (v != 0.f) atomic_add_f32(d, v);
+    // no workspace: hot-spot atomics (slower, not deterministic); loss_parts was zeroed by the host side
+    for (int idx = mlp_lo + tid; idx < PART_TRASH + L * 8; idx += NT) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) v += s_wave[w][idx];
+      if (v == 0.f) continue;
+      float* d;
+      if (idx < MLP_B1) d = a.grad_mlp[0] + idx;
+      else if (idx < MLP_W2) d = a.grad_mlp[1] + (idx - MLP_B1);
+      else if (idx < MLP_B2) d = a.grad_mlp[2] + (idx - MLP_W2);
+      else if (idx < MLP_W3) d = a.grad_mlp[3] + (idx - MLP_B2);
+      else if (idx < MLP_B3) d = a.grad_mlp[4] + (idx - MLP_W3);
+      else if (idx < PART_TRASH) d = a.grad_mlp[5];
+      else {
+        const int sl = (idx - PART_TRASH) >> 3, q = (idx - PART_TRASH) & 7;
+        d = a.lv[sl].grad ? a.lv[sl].grad + a.rows[sl] * F + q : nullptr;
       }
-    }
-    for (int idx = tid; idx < L * 8; idx += 256) {
-      const int s = idx >> 3, q = idx & 7;
-      float v = s_part[PART_TRASH + idx];
-      if (v != 0.f && a.lv[s].grad) atomic_add_f32(a.lv[s].grad + a.rows[s] * F + q, v);
+      if (d) atomic_add_f32(d, v);
     }
     if (tid == 0 && a.loss_parts) {
       const double bce = a.reduction_sum ? s_loss[0] : s_loss[0] * (double)a.inv_n;
+      const double eik = EIK ? s_loss[2] * (double)inv_nsurf : 0.0;
       atomicAdd(a.loss_parts + 0, bce);
+      atomicAdd(a.loss_parts + 1, eik);
       atomicAdd(a.loss_parts + 2, s_loss[1]);
-      atomicAdd(a.loss_parts + 3, bce);
+      atomicAdd(a.loss_parts + 3, bce + (double)a.weight_e * eik);
     }
   }
 }
 
-// second stage: add the per-block partial vectors into the gradient tensors / loss.
+// second stage: add the per-workgroup partial vectors into the gradient tensors / loss.
 // One 1024-thread block per 64 entries: lane = entry (coalesced 256-B rows), the 16 waves split the blocks.
 __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks) {
   __shared__ float s_red[16][64];
-  __shared__ double s_dred[16][2];
+  __shared__ double s_dred[16][3];
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
   const int L = a.n_levels;
@@ -591,7 +778,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
     s = (s0 + s1) + (s2 + s3);
   }
   s_red[part][lane] = s;
-  if (blockIdx.x == 0 && lane < 2) {  // loss / count doubles ride along in block 0
+  if (blockIdx.x == 0 && lane < 3) {  // loss / count / eikonal doubles ride along in block 0
     double d = 0.0;
     for (int b = part; b < nblocks; b += 16)
       d += reinterpret_cast<const double*>(a.partials + (long long)b * PART_STRIDE + PART_LOSS)[lane];
@@ -619,16 +806,19 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_parts) {
-    double ls = 0.0, cs = 0.0;
+    double ls = 0.0, cs = 0.0, es = 0.0;
     for (int k = 0; k < 16; ++k) {
       ls += s_dred[k][0];
       cs += s_dred[k][1];
+      es += s_dred[k][2];
     }
+    const long long ns = a.n_surf ? *a.n_surf : 0;
     const double bce = a.reduction_sum ? ls : ls * (double)a.inv_n;
+    const double eik = ns > 0 ? es * (double)(1.0f / (float)ns) : 0.0;
     a.loss_parts[0] = bce;
-    a.loss_parts[1] = 0.0;
+    a.loss_parts[1] = eik;
     a.loss_parts[2] = cs;
-    a.loss_parts[3] = bce;  // total of the fused terms
+    a.loss_parts[3] = bce + (double)a.weight_e * eik;  // total of the fused terms
   }
   // FeatureOctree.set_zero (model/feature_octree.py:78-81): the fused step never reads the trash row (a miss
   // contributes nothing), so re-zeroing it here is equivalent to zeroing it before the query
@@ -641,9 +831,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
 // D[32x32] = A[32x2] . B[2x32] through one v_mfma_f32_32x32x2_f32: pins the operand / accumulator lane maps
 __global__ void k_selftest_mfma(const float* A, const float* B, float* D) {
   const int lane = threadIdx.x;
-  f32x16 c;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  f32x16 c = zero16();
   c = mfma32(A[(lane & 31) * 2 + (lane >> 5)], B[(lane >> 5) * 32 + (lane & 31)], c);
 #pragma unroll
   for (int r = 0; r < 16; ++r) D[rowidx(r, lane >> 5) * 32 + (lane & 31)] = c[r];
@@ -655,14 +843,30 @@ struct V1Geometry {
 static V1Geometry v1_geometry(long long n) {
   V1Geometry g;
   long long tiles = (n + 31) / 32;
-  long long max_waves = 256 * 2 * 4;  // 2 resident blocks of 4 waves per CU
+  long long max_waves = 256 * WAVES;  // one resident 8-wave workgroup per CU
   g.waves = tiles < max_waves ? (tiles < 1 ? 1 : tiles) : max_waves;
   long long per = (n + g.waves - 1) / g.waves;
   g.chunk = ((per + 31) / 32) * 32;
   g.waves = (n + g.chunk - 1) / g.chunk;
   if (g.waves < 1) g.waves = 1;
-  g.blocks = (g.waves + 3) / 4;
+  g.blocks = (g.waves + WAVES - 1) / WAVES;
   return g;
+}
+
+template <bool EIK>
+static void launch_v1(const V1Args& a0, int levels, dim3 grid, hipStream_t st) {
+  V1Args a = a0;
+  if (a.prof && levels == 4) {  // debug build of the same kernel with s_memtime stamps per phase
+    hipLaunchKernelGGL((k_step_v1<4, EIK, true>), grid, dim3(NT), 0, st, a);
+    return;
+  }
+  a.prof = nullptr;
+  switch (levels) {  // the level count is a template parameter: straight-line query code, no guards
+    case 1: hipLaunchKernelGGL((k_step_v1<1, EIK, false>), grid, dim3(NT), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_step_v1<2, EIK, false>), grid, dim3(NT), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_step_v1<3, EIK, false>), grid, dim3(NT), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_step_v1<4, EIK, false>), grid, dim3(NT), 0, st, a); break;
+  }
 }
 
 }  // namespace shine
@@ -688,16 +892,16 @@ extern "C" int shine_selftest_mfma(const float* a, const float* b, float* d, voi
 
 extern "C" int shine_train_step_v1(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                                    const float* sdf_label, const float* weight, const int32_t* perm,
-                                   const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,
-                                   const float* const* mlp, float* pred_out, float* grad_x_out,
+                                   const int32_t* slots, const int64_t* n_surf, int64_t n, const float* const* feats,
+                                   const int64_t* rows, const float* const* mlp, float* pred_out, float* grad_x_out,
                                    float* const* grad_feats, float* const* grad_mlp, double* loss_parts,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
-  (void)weight;
-  (void)n_surf;
-  (void)grad_x_out;
+                                   unsigned char* const* touched, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
   if (n < 0 || !feats || !rows || !mlp || !grad_feats || (n > 0 && (!coord || !sdf_label)))
     return set_error(SHINE_E_INVALID, "shine_train_step: null argument");
-  if (cfg->n_levels > LCAP || cfg->eikonal_on) return set_error(SHINE_E_INVALID, "shine_train_step_v1: unsupported config");
+  if (cfg->n_levels > LCAP) return set_error(SHINE_E_INVALID, "shine_train_step_v1: more than 4 featured levels");
+  if (cfg->eikonal_on && (!weight || !n_surf))
+    return set_error(SHINE_E_INVALID, "shine_train_step: eikonal needs weight and n_surf");
   V1Args a = {};
   LevelSet ls = {};
   int rc = make_level_set(t, cfg, feats, rows, grad_feats, &ls);
@@ -713,6 +917,7 @@ extern "C" int shine_train_step_v1(const shine_tables* t, const shine_step_confi
     a.lv[s].res = ls.lv[s].res;
     a.rows[s] = ls.lv[s].rows;
     a.feat_rw[s] = const_cast<float*>(feats[s]);
+    a.touched[s] = touched ? touched[s] : nullptr;
   }
   for (int k = 0; k < 6; ++k) {
     if (!mlp[k]) return set_error(SHINE_E_INVALID, "shine_train_step: null decoder parameter");
@@ -726,8 +931,12 @@ extern "C" int shine_train_step_v1(const shine_tables* t, const shine_step_confi
   V1Geometry g = v1_geometry(n);
   a.coord = coord;
   a.label = sdf_label;
+  a.weight = weight;
   a.perm = perm;
+  a.slots = slots;
+  a.n_surf = cfg->eikonal_on ? reinterpret_cast<const long long*>(n_surf) : nullptr;
   a.pred = pred_out;
+  a.grad_x = grad_x_out;
   a.loss_parts = loss_parts;
   a.n = n;
   a.chunk = g.chunk;
@@ -739,22 +948,16 @@ extern "C" int shine_train_step_v1(const shine_tables* t, const shine_step_confi
   a.prof = g_prof_buffer;
   a.sigma = cfg->sigma;
   a.inv_n = (float)cfg->inv_n;
+  a.weight_e = cfg->weight_e;
   const size_t need = (size_t)g.blocks * PART_STRIDE * sizeof(float);
   a.partials = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (!a.partials && loss_parts) SHINE_HIP_CHECK(hipMemsetAsync(loss_parts, 0, 4 * sizeof(double), st));
-  const dim3 grid((unsigned)g.blocks), block(256);
-  if (a.prof && cfg->n_levels == 4) {  // debug build of the same kernel with s_memtime stamps per phase
-    hipLaunchKernelGGL((k_step_v1<4, true>), grid, block, 0, st, a);
-  } else {
-    a.prof = nullptr;
-    switch (cfg->n_levels) {  // the level count is a template parameter: straight-line query code, no guards
-      case 1: hipLaunchKernelGGL((k_step_v1<1, false>), grid, block, 0, st, a); break;
-      case 2: hipLaunchKernelGGL((k_step_v1<2, false>), grid, block, 0, st, a); break;
-      case 3: hipLaunchKernelGGL((k_step_v1<3, false>), grid, block, 0, st, a); break;
-      default: hipLaunchKernelGGL((k_step_v1<4, false>), grid, block, 0, st, a); break;
-    }
-  }
+  const dim3 grid((unsigned)g.blocks);
+  if (cfg->eikonal_on)
+    launch_v1<true>(a, cfg->n_levels, grid, st);
+  else
+    launch_v1<false>(a, cfg->n_levels, grid, st);
   SHINE_HIP_CHECK(hipGetLastError());
   if (a.partials) {
     hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks);

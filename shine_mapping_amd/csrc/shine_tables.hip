@@ -56,14 +56,38 @@ __global__ void k_rehash(const unsigned long long* old_keys, const int* old_vals
   }
 }
 
+__global__ void k_set_ranks(const unsigned long long* keys, int* ranks, unsigned int shift, unsigned int mask,
+                            const long long* in_keys, const int* in_ranks, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = (unsigned long long)in_keys[i];
+  unsigned int slot = hash_slot(key, shift);
+  for (unsigned int probe_n = 0; probe_n <= mask; ++probe_n) {
+    const unsigned long long k = keys[slot];
+    if (k == key) {
+      ranks[slot] = in_ranks[i];
+      return;
+    }
+    if (k == EMPTY_KEY) return;
+    slot = (slot + 1) & mask;
+  }
+}
+
 static int alloc_level(TableLevel& L, long long cap, hipStream_t st) {
   unsigned long long* keys = nullptr;
   int* vals = nullptr;
+  int* ranks = nullptr;
   if (hipMalloc(&keys, (size_t)cap * sizeof(unsigned long long)) != hipSuccess) return SHINE_E_NOMEM;
   if (hipMalloc(&vals, (size_t)cap * 8 * sizeof(int)) != hipSuccess) {
     (void)hipFree(keys);
     return SHINE_E_NOMEM;
   }
+  if (hipMalloc(&ranks, (size_t)cap * sizeof(int)) != hipSuccess) {
+    (void)hipFree(keys);
+    (void)hipFree(vals);
+    return SHINE_E_NOMEM;
+  }
+  L.ranks = ranks;
   hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, keys, cap);
   SHINE_HIP_CHECK(hipGetLastError());
   L.keys = keys;
@@ -94,6 +118,7 @@ extern "C" int shine_tables_destroy(shine_tables* t) {
   for (int s = 0; s < SHINE_MAX_LEVELS; ++s) {
     if (t->lv[s].keys) (void)hipFree(t->lv[s].keys);
     if (t->lv[s].vals) (void)hipFree(t->lv[s].vals);
+    if (t->lv[s].ranks) (void)hipFree(t->lv[s].ranks);
   }
   delete t;
   return SHINE_OK;
@@ -128,13 +153,31 @@ extern "C" int shine_tables_insert(shine_tables* t, int32_t slot, const int64_t*
       SHINE_HIP_CHECK(hipStreamSynchronize(st));  // old arrays are freed below
       (void)hipFree(L.keys);
       (void)hipFree(L.vals);
+      (void)hipFree(L.ranks);
     }
     fresh.count = L.count;
     L = fresh;
   }
+  t->n_buckets = 0;  // node ranks are stale after any insert: shine_tables_set_ranks must run again
   hipLaunchKernelGGL(k_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, L.keys, L.vals, L.shift, L.mask,
                      (const long long*)keys, (const int*)corner_ids, (long long)n);
   SHINE_HIP_CHECK(hipGetLastError());
   L.count += n;
+  return SHINE_OK;
+}
+
+extern "C" int shine_tables_set_ranks(shine_tables* t, int32_t slot, const int64_t* keys, const int32_t* ranks,
+                                      int64_t n, int64_t n_buckets, void* stream) {
+  if (!t || slot < 0 || slot >= t->n_levels || n < 0 || n_buckets < 1)
+    return set_error(SHINE_E_INVALID, "shine_tables_set_ranks: bad table/slot/n");
+  TableLevel& L = t->lv[slot];
+  if (!L.keys) return set_error(SHINE_E_STATE, "shine_tables_set_ranks: level has no table yet");
+  if (n > 0) {
+    if (!keys || !ranks) return set_error(SHINE_E_INVALID, "shine_tables_set_ranks: null keys/ranks");
+    hipLaunchKernelGGL(k_set_ranks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L.keys,
+                       L.ranks, L.shift, L.mask, (const long long*)keys, (const int*)ranks, (long long)n);
+    SHINE_HIP_CHECK(hipGetLastError());
+  }
+  if (slot == t->n_levels - 1) t->n_buckets = n_buckets;  // by convention the leaf level is set last
   return SHINE_OK;
 }

@@ -36,7 +36,9 @@ class GradReducer:
         if not stale:
             return
         dev = self.params[0].device
-        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        padded = torch.zeros((total + 3) // 4 * 4, dtype=torch.float32, device=dev)
+        flat = padded[:total]
+        self._flat_padded = padded
         views, off = [], 0
         for p in self.params:
             v = flat[off: off + p.numel()].view_as(p)
@@ -46,6 +48,12 @@ class GradReducer:
             views.append(v)
             off += p.numel()
         self._flat, self._views = flat, views
+
+    @property
+    def flat(self):
+        """The flat gradient bucket (padded to a multiple of 16 bytes): pass it as plan_batch(zero=...)."""
+        self._ensure_flat()
+        return self._flat_padded
 
     def zero_grads(self):
         """One fill for every gradient (what opt.zero_grad amounts to for the fused step's dense grads)."""
@@ -89,3 +97,38 @@ def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
         "shine_morton_sort",
     )
     return perm
+
+
+def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None):
+    """Order the batch by octree node (counting sort over the node ranks) and look up every point's hash slots.
+
+    Returns (perm [N] int32, slots [N, L] int32), both on the device, to pass to fused_train_step(perm=, slots=).
+    Cheaper than morton_order (3 small launches vs a multi-pass radix sort) and it moves the hash probing out of the
+    fused kernel.  `zero`: an optional contiguous float tensor cleared in the same pass (GradReducer.flat, i.e. the
+    step's opt.zero_grad())."""
+    t = octree._require_tables(with_ranks=True)
+    coord = octree._check_coord(coord.detach())
+    n = coord.shape[0]
+    L = octree.featured_level_num
+    cfg = octree.step_config()
+    lib = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    key = ("plan", str(coord.device), n, octree._n_buckets)
+    ent = _WS.get(key)
+    if ent is None:
+        need = C.c_size_t(0)
+        _lib.check(lib.shine_plan_batch(t.handle, C.byref(cfg), None, n, None, None, None, 0, None, C.byref(need),
+                                        stream), "shine_plan_batch")
+        ent = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=coord.device), int(need.value))
+        _WS[key] = ent
+    ws, need = ent[0], C.c_size_t(ent[1])
+    perm = torch.empty(n, dtype=torch.int32, device=coord.device)
+    slots = torch.empty((n, L), dtype=torch.int32, device=coord.device)
+    _lib.check(
+        lib.shine_plan_batch(t.handle, C.byref(cfg), coord.data_ptr(), n, perm.data_ptr(), slots.data_ptr(),
+                             zero.data_ptr() if zero is not None else None,
+                             zero.numel() * zero.element_size() if zero is not None else 0,
+                             ws.data_ptr(), C.byref(need), stream),
+        "shine_plan_batch",
+    )
+    return perm, slots

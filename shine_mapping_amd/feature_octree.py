@@ -135,6 +135,8 @@ class FeatureOctree(nn.Module):
         self._corner_count = [0] * L
         self._dict_cache = None
         self._sort_box_cache = None
+        self._ranks_uploaded = False
+        self._n_buckets = 0
         self._tables = None  # created at the first query (needs the GPU); update() itself is host-only
         self._pending = [[] for _ in range(L)]  # (node keys, corner ids) not yet inserted on the device
         # a level's regulariser contributes gradient only while its features_last_frame copy is detached
@@ -264,17 +266,49 @@ class FeatureOctree(nn.Module):
             self._pending[s].append((fresh, ids))  # uploaded to the device hash table at the next query
 
     # ------------------------------------------------------------------ hot path plumbing
-    def _require_tables(self):
+    def _require_tables(self, with_ranks=False):
         if len(self.hier_features) != self.featured_level_num:
             raise RuntimeError("FeatureOctree is empty: call update() before querying")
         if self._tables is None:
             self._tables = _DeviceTables(self.featured_level_num)
+            self._ranks_uploaded = False
         dev = self.hier_features[0].device
         for s in range(self.featured_level_num):
             for keys, ids in self._pending[s]:
                 self._tables.insert(s, torch.from_numpy(keys).to(dev), torch.from_numpy(ids).to(dev))
+                self._ranks_uploaded = False
             self._pending[s] = []
+        if with_ranks and not self._ranks_uploaded:
+            self._upload_ranks(dev)
         return self._tables
+
+    def _upload_ranks(self, dev):
+        """Rank every node of every featured level in ONE Z-order (a parent's own bucket right after its
+        children's) for shine_plan_batch's counting sort.  Host-side argsort, once per tree growth."""
+        L = self.featured_level_num
+        ext, lvl = [], []
+        for s in range(L):
+            sh = 3 * (L - 1 - s)
+            k = self._node_keys[s].astype(np.int64)
+            ext.append(((k << sh) | ((1 << sh) - 1)) * 8 + (L - 1 - s))  # end of the subtree range; deeper first
+            lvl.append(np.full(k.shape, s, np.int64))
+        ext_all, lvl_all = np.concatenate(ext), np.concatenate(lvl)
+        order = np.argsort(ext_all, kind="stable")
+        rank_all = np.empty(order.size, np.int32)
+        rank_all[order] = np.arange(order.size, dtype=np.int32)
+        self._n_buckets = int(order.size) + 64  # + the miss buckets (shine_plan.hip MISS_BUCKETS)
+        off = 0
+        lib = _lib.lib()
+        stream = torch.cuda.current_stream().cuda_stream
+        for s in range(L):
+            n = self._node_keys[s].size
+            keys_d = torch.from_numpy(self._node_keys[s]).to(dev)
+            ranks_d = torch.from_numpy(rank_all[off:off + n].copy()).to(dev)
+            _lib.check(lib.shine_tables_set_ranks(self._tables.handle, s, keys_d.data_ptr(), ranks_d.data_ptr(), n,
+                                                  self._n_buckets, stream), "shine_tables_set_ranks")
+            torch.cuda.current_stream().synchronize()
+            off += n
+        self._ranks_uploaded = True
 
     def step_config(self, **kw) -> _lib.StepConfig:
         cfg = _lib.StepConfig()
@@ -384,6 +418,7 @@ class FeatureOctree(nn.Module):
         """Drop the library handle; it is re-created from the host copies at the next query
         (after unpickling / device move)."""
         self._tables = None
+        self._ranks_uploaded = False
         self._pending = [[(self._node_keys[s], self._node_ids[s])] if self._node_keys[s].size else []
                          for s in range(self.featured_level_num)]
 

@@ -84,7 +84,7 @@ def forward_sdf(octree, decoder, coord, want_feat=False, want_indices=False, wan
 
 
 def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
-                     n_surf: Optional[torch.Tensor] = None):
+                     n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None):
     """One training iteration's forward+backward (no optimiser): the fused Tier-B step.
 
     coord [N,3], sdf_label [N], weight [N] (sign: + surface / - free space, utils/data_sampler.py:102-103).
@@ -122,19 +122,25 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     gmlp = [_dense_grad(p) for p in params] if dec_grad else [None] * 6
     if perm is not None and not (perm.is_cuda and perm.dtype == torch.int32 and perm.numel() == n):
         raise ValueError("perm must be a CUDA int32 tensor of N entries")
+    if slots is not None and not (perm is not None and slots.is_cuda and slots.dtype == torch.int32
+                                  and slots.numel() == n * octree.featured_level_num):
+        raise ValueError("slots must come with perm from dp.plan_batch: CUDA int32 [N, L]")
     ws = _workspace(dev, int(_lib.lib().shine_train_step_workspace_bytes(C.byref(cfg), n)))
     _lib.check(
         _lib.lib().shine_train_step(
             t.handle, C.byref(cfg), coord.data_ptr(), sdf_label.data_ptr(),
             weight.data_ptr() if weight is not None else None,
             perm.data_ptr() if perm is not None else None,
+            slots.data_ptr() if slots is not None else None,
             n_surf.data_ptr() if n_surf is not None else None, n,
             octree.feature_ptrs(), octree.row_counts(),
             _lib.ptr_array([p.data_ptr() for p in params]),
             pred.data_ptr(), gx.data_ptr() if gx is not None else None,
             _lib.ptr_array([g.data_ptr() if g is not None else None for g in gfeat]),
             _lib.ptr_array([g.data_ptr() if g is not None else None for g in gmlp]),
-            loss_parts.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
+            loss_parts.data_ptr(),
+            _lib.ptr_array([x.data_ptr() for x in touched]) if touched is not None else None,
+            ws.data_ptr(), ws.numel(), _stream(),
         ),
         "shine_train_step",
     )
@@ -192,3 +198,36 @@ def _dummy_mlp(dev):
     if key not in _DUMMY:
         _DUMMY[key] = [torch.zeros(s, dtype=torch.float32, device=dev) for s in (256, 32, 1024, 32, 32, 1)]
     return _DUMMY[key]
+
+
+def fused_regularization(octree, lambda_forget: float, touched):
+    """FeatureOctree.cal_regularization (model/feature_octree.py:246-255) on the rows the last fused step touched.
+
+    Returns the UNWEIGHTED regulariser as a 0-dim float64 device tensor and adds lambda * d(reg)/dF into the feature
+    grads of the levels whose features_last_frame copy is detached (octree._reg_grad_on; the reference's attached
+    clone, :160, contributes value only).  `touched`: the per-level uint8 flag tensors passed to fused_train_step."""
+    import ctypes as _C
+
+    L = octree.featured_level_num
+    dev = octree.hier_features[0].device
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    feats = [p.detach() for p in octree.hier_features]
+    last = [t.detach().contiguous() for t in octree.features_last_frame]
+    imp = [t.contiguous() for t in octree.importance_weight]
+    grads = [_dense_grad(p) for p in octree.hier_features]
+    grad_on = (_C.c_int32 * L)(*[1 if g else 0 for g in octree._reg_grad_on])
+    _lib.check(
+        _lib.lib().shine_regularize(
+            L, _lib.ptr_array([t.data_ptr() for t in feats]), _lib.ptr_array([t.data_ptr() for t in last]),
+            _lib.ptr_array([t.data_ptr() for t in imp]), _lib.ptr_array([g.data_ptr() for g in grads]),
+            _lib.ptr_array([t.data_ptr() for t in touched]), octree.row_counts(), grad_on, float(lambda_forget),
+            out.data_ptr(), _stream(),
+        ),
+        "shine_regularize",
+    )
+    return out[0]
+
+
+def touched_flags(octree):
+    """Per-level uint8 row flags for fused_train_step(touched=...) / fused_regularization (zero-initialised)."""
+    return [torch.zeros(p.shape[0], dtype=torch.uint8, device=p.device) for p in octree.hier_features]

@@ -317,3 +317,99 @@ def test_octree_pickle_roundtrip_keeps_tables():
     for k, r in enumerate(fx["out"]["indices"]):
         assert torch.equal(idx[k].cpu(), r)
     assert oct2.nodes_lookup_tables[cfg.tree_level_world] == octree.nodes_lookup_tables[cfg.tree_level_world]
+
+
+@pytest.mark.parametrize("name", ["maicity_bce_L4", "kitti_eik_L3", "linear_L2_nopoly"])
+def test_plan_batch_counting_sort_and_planned_step(name):
+    """shine_plan_batch: perm is a permutation, points of one (deepest) node are adjacent, the slots agree with
+    get_indices' hits, and the fused step fed (perm, slots) reproduces the reference."""
+    from shine_mapping_amd import dp, fused_train_step
+
+    fx = load_golden(name)
+    cfg, octree, dec = product_from_golden(fx)
+    coord = fx["coord"].cuda()
+    perm, slots = dp.plan_batch(octree, coord)
+    torch.cuda.synchronize()
+    n, L = coord.shape[0], cfg.tree_level_feat
+    p = perm.cpu().long()
+    assert torch.equal(torch.sort(p).values, torch.arange(n))
+    sl = slots.cpu()
+    assert sl.shape == (n, L)
+    ref_idx = fx["out"]["indices"]  # bottom-up; slots are top-down
+    for s in range(L):
+        hit_ref = (ref_idx[L - 1 - s][:, 0] >= 0)[p]
+        assert torch.equal(sl[:, s] >= 0, hit_ref), "level slot %d hit pattern" % s
+    # points that share their deepest node are contiguous in the visiting order
+    deepest = torch.full((n,), -1, dtype=torch.int64)
+    for s in range(L):
+        deepest = torch.where(sl[:, s] >= 0, sl[:, s].long() + (s << 40), deepest)
+    change = (deepest[1:] != deepest[:-1]).sum().item() + 1
+    assert change == len(torch.unique(deepest)), "a node's points are split into several runs"
+    loss, pred, g = fused_train_step(octree, dec, coord, fx["sdf_label"].cuda(), fx["weight"].cuda(), step_options(fx),
+                                     want_grad_x=True, perm=perm, slots=slots)
+    ref = fx["out"]
+    assert abs_err(pred, ref["pred"]) <= TOL
+    if ref["g"] is not None:
+        assert rel_err(g, ref["g"]) <= TOL
+    for k, r in enumerate(ref["feat_grads"]):
+        assert rel_err(octree.hier_features[k].grad, r) <= TOL
+    for k, (pp, r) in enumerate(zip(dec.fused_params(), ref["mlp_grads"])):
+        assert rel_err(pp.grad, r) <= TOL
+
+
+def test_fused_regulariser_and_importance_sweep_match_reference():
+    """config ncd_incre_reg: fused step (sum reduction) + shine_regularize on the touched rows reproduces the
+    reference loss (BCE + lambda * reg) and grads; cal_feature_importance (fused) reproduces the oracle's sweep."""
+    from oracle import shine_oracle as so
+    from shine_mapping_amd import dp, fused_train_step
+    from shine_mapping_amd.incre_learning import cal_feature_importance
+    from shine_mapping_amd.ops import fused_regularization, touched_flags
+
+    fx = load_golden("ncd_reg_L3")
+    cfg, octree, dec = product_from_golden(fx)
+    octree._reg_grad_on = [False] * cfg.tree_level_feat  # fixture = second frame: attached clones (:160), value only
+    coord, label, weight = fx["coord"].cuda(), fx["sdf_label"].cuda(), fx["weight"].cuda()
+    touched = touched_flags(octree)
+    perm, slots = dp.plan_batch(octree, coord)
+    loss, pred, _ = fused_train_step(octree, dec, coord, label, weight, step_options(fx), perm=perm, slots=slots,
+                                     touched=touched)
+    reg = fused_regularization(octree, fx["cfg"]["lambda_forget"], touched)
+    torch.cuda.synchronize()
+    ref = fx["out"]
+    assert abs(float(reg) - float(ref["parts"]["reg"])) <= 1e-4 * abs(float(ref["parts"]["reg"]))
+    total = float(loss) + fx["cfg"]["lambda_forget"] * float(reg)
+    assert abs(total - float(ref["loss"])) <= 1e-4 * abs(float(ref["loss"]))
+    for k, r in enumerate(ref["feat_grads"]):
+        assert rel_err(octree.hier_features[k].grad, r) <= 3e-4
+    assert all(int(t.sum()) == 0 for t in touched)  # flags are cleared for the next iteration
+    # with a detached copy (first-frame branch, :146) the regulariser DOES contribute: d/dF = 2*lambda*imp*(F-F_last)
+    octree._reg_grad_on = [True] * cfg.tree_level_feat
+    for p in octree.hier_features:
+        p.grad = None
+    fused_train_step(octree, dec, coord, label, weight, step_options(fx), perm=perm, slots=slots, touched=touched)
+    base = [p.grad.clone() for p in octree.hier_features]
+    idx = octree.get_indices(coord)
+    fused_regularization(octree, fx["cfg"]["lambda_forget"], touched)
+    L = cfg.tree_level_feat
+    for s in range(L):
+        u = idx[L - 1 - s].flatten().unique()
+        u = u[u >= 0]
+        expect = torch.zeros_like(base[s])
+        d = octree.hier_features[s].detach()[u] - octree.features_last_frame[s][u]
+        expect[u] = 2.0 * fx["cfg"]["lambda_forget"] * octree.importance_weight[s][u] * d
+        assert rel_err(octree.hier_features[s].grad - base[s], expect) <= 1e-5
+
+    # importance sweep vs the oracle restatement of utils/incre_learning.py:8-40
+    ocfg, oct_, mlp = oracle_from_golden(fx)
+    pool_c, pool_l = fx["coord"], fx["sdf_label"]
+    for t in oct_.importance_weight:
+        t.zero_()
+    so.importance_sweep(oct_, mlp, pool_c, pool_l, ocfg, 256, 2)
+    for t in octree.importance_weight:
+        t.zero_()
+    data = type("Pool", (), {"coord_pool": pool_c.cuda(), "sdf_label_pool": pool_l.cuda()})()
+    cal_feature_importance(data, octree, dec, fx["sigma"], 256, 2, "sum")
+    torch.cuda.synchronize()
+    for a, b in zip(octree.importance_weight, oct_.importance_weight):
+        assert rel_err(a, b) <= TOL
+        assert float(a[-1].abs().max()) == 0.0

@@ -44,19 +44,27 @@ def timeit(fn, n=20, warm=5):
 
 
 perms = [dp.morton_order(octree, b[0]) for b in batches]
+plans = [dp.plan_batch(octree, b[0]) for b in batches]
 state = {"i": 0}
 
 
-def step(variant, sorted_=True):
+def step(variant, sorted_=True, planned=True):
     i = state["i"] = (state["i"] + 1) % len(batches)
     c, l, w = batches[i]
     opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=cfg.ekional_loss_on, weight_e=cfg.weight_e,
                        kernel_variant=variant)
-    fused_train_step(octree, dec, c, l, w, opts, perm=perms[i] if sorted_ else None)
+    if not sorted_:
+        fused_train_step(octree, dec, c, l, w, opts)
+    elif planned:
+        fused_train_step(octree, dec, c, l, w, opts, perm=plans[i][0], slots=plans[i][1])
+    else:
+        fused_train_step(octree, dec, c, l, w, opts, perm=perms[i])
 
 
 print("points %d levels %d rows %s" % (args.points, args.levels, [int(p.shape[0]) for p in octree.hier_features]))
-print("sort only            : %8.1f us" % timeit(lambda: dp.morton_order(octree, batches[0][0])))
+print("radix sort only      : %8.1f us" % timeit(lambda: dp.morton_order(octree, batches[0][0])))
+print("plan (node sort) only: %8.1f us" % timeit(lambda: dp.plan_batch(octree, batches[0][0])))
+print("radix-ordered step   : %8.1f us" % timeit(lambda: step(0, planned=False)))
 print("zero grads           : %8.1f us" % timeit(red.zero_grads))
 rows = [("full", 0), ("unsorted input", 0), ("no atomics", 0x100), ("no weight-grad phase", 0x200),
         ("no scatter phase", 0x400), ("no row gathers", 0x800), ("no probe (all miss)", 0x1000),
