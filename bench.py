@@ -31,6 +31,19 @@ def algorithmic_bytes_per_point(levels: int, feat: int = 8) -> int:
     return 24 + levels * (40 + 2 * 8 * feat * 4)
 
 
+def measured_traffic(levels, points, eikonal):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected separately, gfx950 corrections applied — profiles/r01_pmc_traffic_*.json says how).  bench.py cannot run
+    the profiler on itself, so the figure is only reported for the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_v1_bce_2p18_L4.json")
+    if eikonal or levels != 4 or points != (1 << 18) or not os.path.isfile(path):
+        return None
+    try:
+        return float(json.load(open(path))["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, wl, seconds=12.0):
     """The oracle port of the reference's CPU path (same dict-lookup structure, torch CPU ops, Adam excluded
     like the GPU figure) on a bounded sample of the same workload: batches of 4096 points (the reference's own
@@ -254,7 +267,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kernel_ms,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(levels, points, bool(cfg.ekional_loss_on)), "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_point": bpp,
             },
             "final_loss": float(loss),

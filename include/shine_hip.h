@@ -150,6 +150,14 @@ int shine_regularize(int32_t n_levels, const float* const* feats, const float* c
                      const int64_t* rows, const int32_t* grad_on, float lambda_forget, double* reg_out, void* stream);
 int shine_importance_accumulate(float* importance, float* grad, int64_t rows, void* stream);
 
+/* ---- fused dense Adam (next row f-1): opt.step() [+ opt.zero_grad()] of shine_batch.py:208-210 for the optimiser of
+ *      setup_optimizer (utils/tools.py:57-83): torch.optim.Adam semantics (betas, eps, L2 weight decay added to the
+ *      grad, bias correction with the 1-based `step`), one lr / weight_decay per tensor, every element updated
+ *      (dense, like the reference).  n_tensors <= 16; all arrays are host arrays of n_tensors entries. ------------- */
+int shine_adam_step(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, const float* lr, const float* weight_decay,
+                    float beta1, float beta2, float eps, int64_t step, int32_t zero_grad, void* stream);
+
 /* ---- Batch plan: order a batch by octree node (counting sort) and remember every point's hash slots.
  *      shine_tables_set_ranks: per level, the rank of every node in ONE Z-order over all featured levels (a parent's
  *      own bucket right after its children's); n_buckets = number of nodes of all levels + 64 (miss buckets); call for every level

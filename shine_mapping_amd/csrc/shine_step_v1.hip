@@ -411,6 +411,9 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
     }
     SHINE_STAMP(1)  // query
 
+    float df4[4], J4[4] = {0.f, 0.f, 0.f, 0.f}, qv[3] = {0.f, 0.f, 0.f};
+    if (!EIK) {
+    // ---- BCE build: activations stay in registers until the transposed passes (fastest schedule measured)
     // ================================================================ phase 2: decoder forward (MFMA chain)
     f32x16 c1, c2;
 #pragma unroll
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
     if (valid && h == 0 && a.pred) a.pred[p] = y;
 
     // ---------------------------------------------------------------- eikonal: d pred / d coord (closed form)
-    float v1[16], J4[4], g[3] = {0.f, 0.f, 0.f};
+    float v1[16], g[3] = {0.f, 0.f, 0.f};
     if (EIK) {
       f32x16 ev = zero16(), ej = zero16();
 #pragma unroll
@@ -465,7 +468,6 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 
     // ================================================================ phase 3: loss
     float delta = 0.f;
-    float qv[3] = {0.f, 0.f, 0.f};
     if (valid) {
       const float zt = sigmoidf_acc(label / sigma);
       if (h == 0) {
@@ -515,7 +517,8 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) e0 = mfma32(s_opA[OP_A1T + t * 64 + lane], d1[t], e0);
     // rows 0..7 of e0 = d loss / d f ; lane (pt,h) holds rows 4h..4h+3 in regs 0..3
-    const float df4[4] = {e0[0], e0[1], e0[2], e0[3]};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) df4[q] = e0[q];
     SHINE_STAMP(3)  // loss + decoder backward
 
     // ================================================================ phase 5: decoder weight grads (transposed MFMA)
@@ -553,6 +556,169 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
         accW1 = wgrad_pass<F, false>(TL, TR, pt, h, accW1, nullptr);   // dW1 += v1 (x) r   (no bias term)
         wave_lds_fence();
       }
+    }
+    } else {
+    // ---- eikonal build: same maths, activations retired early (register budget: v1/a1 need the room)
+    // ================================================================ phase 2: decoder forward (MFMA chain)
+    // Activations are retired as early as possible (register budget): h1 goes to its transpose tile (TR) as soon as
+    // layer 2 has consumed it, d2 to TL right after the loss; only the ReLU masks stay, as 16-bit lane masks.
+    const bool wg = a.decoder_grad_on && !(a.ablate & 2);
+    f32x16 c1, c2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      c1[r] = s_bias[SB_B1 + rowidx(r, h)];
+      c2[r] = s_bias[SB_B2 + rowidx(r, h)];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c1 = mfma32(s_opA[OP_A1 + t * 64 + lane], f4[t], c1);
+    unsigned int m1 = 0, m2 = 0;  // bit r: channel rowidx(r,h) of this lane's point is active
+    {
+      float h1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        h1[r] = fmaxf(c1[r], 0.f);
+        m1 |= (h1[r] > 0.f ? 1u : 0u) << r;
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) c2 = mfma32(s_opA[OP_A2 + t * 64 + lane], h1[t], c2);
+      if (wg) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) TR[rowidx(r, h) * TP + pt] = h1[r];
+      }
+    }
+    float h2[16];
+    float yp = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      h2[r] = fmaxf(c2[r], 0.f);
+      m2 |= (h2[r] > 0.f ? 1u : 0u) << r;
+      yp = fmaf(s_bias[SB_W3 + rowidx(r, h)], h2[r], yp);
+    }
+    const float y = yp + __shfl_xor(yp, 32, 64) + b3;
+    if (valid && h == 0 && a.pred) a.pred[p] = y;
+    SHINE_STAMP(2)  // decoder forward
+
+    // ================================================================ phase 3: BCE loss
+    float delta = 0.f;
+    if (valid) {
+      const float zt = sigmoidf_acc(label / sigma);
+      if (h == 0) {
+        loss_acc += (double)(fmaxf(y, 0.f) - y * zt + log1pf(expf(-fabsf(y))));
+        cnt_acc += 1.0;
+      }
+      delta = (sigmoidf_acc(y) - zt) * a.inv_n;
+    }
+    if (h == 0) db3 += delta;
+
+    // ================================================================ phase 4: backward through the decoder
+    {
+      float d2[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        d2[r] = ((m2 >> r) & 1u) ? delta * s_bias[SB_W3 + rowidx(r, h)] : 0.f;
+        dw3c[r] = fmaf(delta, h2[r], dw3c[r]);
+      }
+      f32x16 e1 = zero16(), e0 = zero16();
+#pragma unroll
+      for (int t = 0; t < 16; ++t) e1 = mfma32(s_opA[OP_A2T + t * 64 + lane], d2[t], e1);
+      if (wg) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = d2[r];
+      }
+      float d1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d1[r] = ((m1 >> r) & 1u) ? e1[r] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) e0 = mfma32(s_opA[OP_A1T + t * 64 + lane], d1[t], e0);
+      // rows 0..7 of e0 = d loss / d f ; lane (pt,h) holds rows 4h..4h+3 in regs 0..3
+#pragma unroll
+      for (int q = 0; q < 4; ++q) df4[q] = e0[q];
+      SHINE_STAMP(3)  // loss + decoder backward
+
+      // ============================================================== phase 5: decoder weight grads (transposed MFMA)
+      if (wg) {
+        wave_lds_fence();
+        accW2 = wgrad_pass<32, false>(TL, TR, pt, h, accW2, &db2acc);  // dW2[out][in] += d2[out][k] h1[in][k]; db2 rides
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = d1[r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) TR[(4 * h + q) * TP + pt] = f4[q];
+        wave_lds_fence();
+        // B columns 0..7 = f, column 8 = ones: accW1[:,8] accumulates db1 = sum_k d1[ch][k] in the spare MFMA lanes
+        accW1 = wgrad_pass<F, true>(TL, TR, pt, h, accW1, nullptr);    // dW1[ch][feat] += d1[ch][k] f[feat][k]
+        wave_lds_fence();
+      }
+    }
+
+    // ---------------------------------------------------------------- eikonal term (closed form)
+    if (EIK) {
+      float v1[16], a1[16], r4[4], g[3];
+      {
+        f32x16 ev = zero16(), ej = zero16();
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          ev = mfma32(s_opA[OP_A2T + t * 64 + lane], ((m2 >> t) & 1u) ? s_bias[SB_W3 + rowidx(t, h)] : 0.f, ev);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v1[r] = ((m1 >> r) & 1u) ? ev[r] : 0.f;  // m1 .* (W2^T (m2 .* w3))
+#pragma unroll
+        for (int t = 0; t < 16; ++t) ej = mfma32(s_opA[OP_A1T + t * 64 + lane], v1[t], ej);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) J4[q] = ej[q];  // d y / d f_{4h+q}
+      }
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        float sm = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sm = fmaf(J4[q], A4[q][e], sm);
+        sm += __shfl_xor(sm, 32, 64);
+        g[e] = sigma * sm;  // get_gradient(coord, pred) * sigma   (utils/tools.py:175-185, shine_batch.py:141-142)
+      }
+      if (valid && h == 0 && a.grad_x) {
+        a.grad_x[3 * p] = g[0];
+        a.grad_x[3 * p + 1] = g[1];
+        a.grad_x[3 * p + 2] = g[2];
+      }
+      if (valid && wgt > 0.f) {  // surface samples only (shine_batch.py:137,183)
+        const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+        const float e = 1.0f - gn;
+        if (h == 0) eik_acc += (double)(e * e);
+        const float coef = gn > 0.f ? (-2.0f * e / gn) * (a.weight_e * inv_nsurf) : 0.f;  // norm's sub-gradient 0 at 0
+        qv[0] = coef * g[0];
+        qv[1] = coef * g[1];
+        qv[2] = coef * g[2];
+      }
+      {
+        f32x16 t1 = zero16(), t2 = zero16();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r4[q] = sigma * (A4[q][0] * qv[0] + A4[q][1] * qv[1] + A4[q][2] * qv[2]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) t1 = mfma32(s_opA[OP_A1 + t * 64 + lane], r4[t], t1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[r] = ((m1 >> r) & 1u) ? t1[r] : 0.f;  // (W1 r) .* m1
+#pragma unroll
+        for (int t = 0; t < 16; ++t) t2 = mfma32(s_opA[OP_A2 + t * 64 + lane], a1[t], t2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw3c[r] += ((m2 >> r) & 1u) ? t2[r] : 0.f;  // a2 = (W2 a1) .* m2
+      }
+      if (wg) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          TL[rowidx(r, h) * TP + pt] = ((m2 >> r) & 1u) ? s_bias[SB_W3 + rowidx(r, h)] : 0.f;  // v2
+          TR[rowidx(r, h) * TP + pt] = a1[r];
+        }
+        wave_lds_fence();
+        accW2 = wgrad_pass<32, false>(TL, TR, pt, h, accW2, nullptr);  // dW2 += v2 (x) a1
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = v1[r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) TR[(4 * h + q) * TP + pt] = r4[q];
+        wave_lds_fence();
+        accW1 = wgrad_pass<F, false>(TL, TR, pt, h, accW1, nullptr);   // dW1 += v1 (x) r   (no bias term)
+        wave_lds_fence();
+      }
+    }
     }
     SHINE_STAMP(5)  // weight grads
 
@@ -636,7 +802,6 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
                 if (rid >= 0 && !(a.ablate & 1)) atomic_add_f32(gbase + (long long)rid * F + sq, racc);
                 racc = 0.f;
                 rid = idr[p2];
-                if (a.touched[s] && sq == 0 && rid >= 0) a.touched[s][rid] = 1;  // idempotent plain store
               }
               float v = wr[p2] * dfr[p2];
               if (EIK) v = fmaf(cqr[p2], jr[p2], v);
@@ -753,6 +918,40 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
       atomicAdd(a.loss_parts + 2, s_loss[1]);
       atomicAdd(a.loss_parts + 3, bce + (double)a.weight_e * eik);
     }
+  }
+}
+
+// rows that receive gradient from this batch (= unique(hierarchical_indices) without -1, feature_octree.py:250):
+// one byte flag per row for shine_regularize.  Kept out of the fused kernel's hot loop (only config 4 needs it).
+__global__ __launch_bounds__(256) void k_mark_touched(V1Args a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const int L = a.n_levels;
+  float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+  if (!a.slots) {
+    const long long p = a.perm ? (long long)a.perm[i] : i;
+    x0 = a.coord[3 * p];
+    x1 = a.coord[3 * p + 1];
+    x2 = a.coord[3 * p + 2];
+  }
+  for (int s = 0; s < L; ++s) {
+    if (!a.touched[s]) continue;
+    int sl;
+    if (a.slots) {
+      sl = a.slots[i * L + s];
+    } else {
+      LevelDev Lv = {};
+      Lv.keys = a.lv[s].keys;
+      Lv.shift = a.lv[s].shift;
+      Lv.mask = a.lv[s].mask;
+      const float res = a.lv[s].res;
+      sl = probe(Lv, morton3(quantize(x0, res), quantize(x1, res), quantize(x2, res)));
+    }
+    if (sl < 0) continue;
+    const int4 v0 = a.lv[s].vals[2 * sl], v1 = a.lv[s].vals[2 * sl + 1];
+    unsigned char* t = a.touched[s];
+    t[v0.x] = 1; t[v0.y] = 1; t[v0.z] = 1; t[v0.w] = 1;
+    t[v1.x] = 1; t[v1.y] = 1; t[v1.z] = 1; t[v1.w] = 1;
   }
 }
 
@@ -954,6 +1153,10 @@ extern "C" int shine_train_step_v1(const shine_tables* t, const shine_step_confi
   hipStream_t st = (hipStream_t)stream;
   if (!a.partials && loss_parts) SHINE_HIP_CHECK(hipMemsetAsync(loss_parts, 0, 4 * sizeof(double), st));
   const dim3 grid((unsigned)g.blocks);
+  if (touched) {
+    hipLaunchKernelGGL(k_mark_touched, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    SHINE_HIP_CHECK(hipGetLastError());
+  }
   if (cfg->eikonal_on)
     launch_v1<true>(a, cfg->n_levels, grid, st);
   else
