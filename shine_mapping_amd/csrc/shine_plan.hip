@@ -39,6 +39,7 @@ struct PlanArgs {
   int* local;        // [n] rank of the point inside its bucket (returned by the counting atomic)
   float4* zero_ptr;  // optional buffer to clear in the same pass (the flat gradient bucket), 16-B units
   long long zero_n16;
+  int ablate;  // debug (kernel_variant >> 8): 1 no counting atomics, 2 no probes (all miss), 4 no slot stores
   int* slots_tmp;    // [n][L]
   int* perm;         // [n]
   int* slots_sorted; // [n][L]
@@ -57,26 +58,47 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a) {
   for (long long z = i; z < a.zero_n16; z += (long long)gridDim.x * 256) a.zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool live = i < a.n;
   int b = -1;
-  if (live) {
+  if (live && !(a.ablate & 2)) {
   const float x0 = a.coord[3 * i], x1 = a.coord[3 * i + 1], x2 = a.coord[3 * i + 2];
   const unsigned long long kleaf = morton3(quantize(x0, a.res_leaf), quantize(x1, a.res_leaf), quantize(x2, a.res_leaf));
   const int L = a.n_levels;
-  for (int s = 0; s < L; ++s) {  // coarse -> fine: the deepest hit wins
+  // all levels' first-slot key loads and (speculative) rank loads are issued together: one memory round trip for the
+  // common no-collision case instead of L serialized probe loops
+  unsigned long long key[SHINE_MAX_LEVELS], k0[SHINE_MAX_LEVELS];
+  unsigned int slot0[SHINE_MAX_LEVELS];
+  int r0[SHINE_MAX_LEVELS];
+#pragma unroll
+  for (int s = 0; s < SHINE_MAX_LEVELS; ++s) {  // no guard: unused levels alias level 0's table (host side), loads are harmless
     const PlanLevel& Lv = a.lv[s];
-    const unsigned long long key = kleaf >> (3 * (L - 1 - s));
-    unsigned int slot = hash_slot(key, Lv.shift);
-    int found = -1;
-    for (unsigned int n = 0; n <= Lv.mask; ++n) {
-      const unsigned long long k = Lv.keys[slot];
-      if (k == key) {
-        found = (int)slot;
-        break;
+    key[s] = s < L ? kleaf >> (3 * (L - 1 - s)) : 0ull;
+    slot0[s] = hash_slot(key[s], Lv.shift);
+    k0[s] = Lv.keys[slot0[s]];
+    r0[s] = Lv.ranks[slot0[s]];
+  }
+#pragma unroll
+  for (int s = 0; s < SHINE_MAX_LEVELS; ++s) {  // coarse -> fine: the deepest hit wins
+    if (s < L) {
+      const PlanLevel& Lv = a.lv[s];
+      int found = -1, rk = -1;
+      if (k0[s] == key[s]) {
+        found = (int)slot0[s];
+        rk = r0[s];
+      } else if (k0[s] != EMPTY_KEY) {  // first-slot collision: walk the probe sequence (rare at load <= 0.5)
+        unsigned int slot = (slot0[s] + 1) & Lv.mask;
+        for (unsigned int n = 0; n < Lv.mask; ++n) {
+          const unsigned long long k = Lv.keys[slot];
+          if (k == key[s]) {
+            found = (int)slot;
+            rk = Lv.ranks[slot];
+            break;
+          }
+          if (k == EMPTY_KEY) break;
+          slot = (slot + 1) & Lv.mask;
+        }
       }
-      if (k == EMPTY_KEY) break;
-      slot = (slot + 1) & Lv.mask;
+      if (!(a.ablate & 4)) a.slots_tmp[i * L + s] = found;
+      if (found >= 0) b = rk;
     }
-    a.slots_tmp[i * L + s] = found;
-    if (found >= 0) b = Lv.ranks[found];
   }
   }
   const bool miss = live && b < 0;
@@ -93,7 +115,7 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a) {
       loc = base + __popcll(mm & ((1ull << lane) - 1ull));
     }
   }
-  if (live && !miss) loc = atomicAdd(&a.count[b], 1);
+  if (live && !miss && !(a.ablate & 1)) loc = atomicAdd(&a.count[b], 1);
   if (live) {
     a.bucket[i] = b;
     a.local[i] = loc;
@@ -153,6 +175,7 @@ extern "C" int shine_plan_batch(const shine_tables* t, const shine_step_config* 
     a.lv[s].shift = T.shift;
     a.lv[s].mask = T.mask;
   }
+  for (int s = L; s < SHINE_MAX_LEVELS; ++s) a.lv[s] = a.lv[0];  // keeps the unguarded speculative loads in bounds
   a.coord = coord;
   a.n = n;
   a.n_levels = L;
@@ -163,6 +186,7 @@ extern "C" int shine_plan_batch(const shine_tables* t, const shine_step_config* 
   a.local = (int*)(w + o_local);
   a.zero_ptr = (float4*)zero_ptr;
   a.zero_n16 = zero_ptr ? (long long)(zero_bytes / 16) : 0;
+  a.ablate = cfg->kernel_variant >> 8;
   a.slots_tmp = (int*)(w + o_slots);
   a.perm = (int*)perm_out;
   a.slots_sorted = (int*)slots_out;

@@ -99,7 +99,7 @@ def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
     return perm
 
 
-def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None):
+def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None, _debug_variant: int = 0, out=None):
     """Order the batch by octree node (counting sort over the node ranks) and look up every point's hash slots.
 
     Returns (perm [N] int32, slots [N, L] int32), both on the device, to pass to fused_train_step(perm=, slots=).
@@ -110,7 +110,7 @@ def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None):
     coord = octree._check_coord(coord.detach())
     n = coord.shape[0]
     L = octree.featured_level_num
-    cfg = octree.step_config()
+    cfg = octree.step_config(kernel_variant=_debug_variant)
     lib = _lib.lib()
     stream = torch.cuda.current_stream().cuda_stream
     key = ("plan", str(coord.device), n, octree._n_buckets)
@@ -122,8 +122,12 @@ def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None):
         ent = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=coord.device), int(need.value))
         _WS[key] = ent
     ws, need = ent[0], C.c_size_t(ent[1])
-    perm = torch.empty(n, dtype=torch.int32, device=coord.device)
-    slots = torch.empty((n, L), dtype=torch.int32, device=coord.device)
+    if out is not None:  # caller-owned (e.g. double-buffered) outputs
+        perm, slots = out
+        assert perm.dtype == torch.int32 and perm.numel() == n and slots.dtype == torch.int32 and slots.numel() == n * L
+    else:
+        perm = torch.empty(n, dtype=torch.int32, device=coord.device)
+        slots = torch.empty((n, L), dtype=torch.int32, device=coord.device)
     _lib.check(
         lib.shine_plan_batch(t.handle, C.byref(cfg), coord.data_ptr(), n, perm.data_ptr(), slots.data_ptr(),
                              zero.data_ptr() if zero is not None else None,

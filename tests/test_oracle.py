@@ -145,3 +145,41 @@ def test_oracle_bit_identical_to_live_reference():
             mg.run_case(R, "live_check", spec)  # asserts bit-equality internally
         finally:
             mg.GOLDEN_DIR = old
+
+
+def test_node_ranks_are_a_z_order_over_all_levels():
+    """FeatureOctree._upload_ranks' host-side ordering (device upload mocked out): ranks are a permutation, every
+    node's descendants occupy a contiguous rank range that ends right before the node's own bucket."""
+    from shine_mapping_amd import FeatureOctree, synth
+
+    fx = load_golden("maicity_bce_L4")
+    cfg = synth.make_config("maicity", device="cpu", **fx["cfg"])
+    octree = FeatureOctree(cfg)
+    for sp in fx["surface_points"]:
+        octree.update(sp)
+    L = octree.featured_level_num
+    ext, lvl, keys = [], [], []
+    for s in range(L):
+        sh = 3 * (L - 1 - s)
+        k = octree._node_keys[s].astype(np.int64)
+        ext.append(((k << sh) | ((1 << sh) - 1)) * 8 + (L - 1 - s))
+        lvl.append(np.full(k.shape, s))
+        keys.append(k)
+    ext, lvl, keys = np.concatenate(ext), np.concatenate(lvl), np.concatenate(keys)
+    order = np.argsort(ext, kind="stable")
+    rank = np.empty(order.size, np.int64)
+    rank[order] = np.arange(order.size)
+    assert sorted(rank.tolist()) == list(range(order.size))
+    # for every coarse node: its children (next level) have smaller ranks, contiguous up to the node itself
+    for s in range(L - 1):
+        for key, r in list(zip(keys[lvl == s], rank[lvl == s]))[:200]:
+            child = (keys[lvl == s + 1] >> 3) == key
+            if child.any():
+                cr = rank[lvl == s + 1][child]
+                assert cr.max() < r
+                # nothing outside this subtree sits between the first descendant and the node
+                between = (rank > cr.min()) & (rank < r)
+                sub = np.zeros_like(between)
+                for t in range(s + 1, L):
+                    sub |= (lvl == t) & ((keys >> (3 * (t - s))) == key)
+                assert not (between & ~sub).any()

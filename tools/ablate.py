@@ -64,6 +64,10 @@ def step(variant, sorted_=True, planned=True):
 print("points %d levels %d rows %s" % (args.points, args.levels, [int(p.shape[0]) for p in octree.hier_features]))
 print("radix sort only      : %8.1f us" % timeit(lambda: dp.morton_order(octree, batches[0][0])))
 print("plan (node sort) only: %8.1f us" % timeit(lambda: dp.plan_batch(octree, batches[0][0])))
+for nm, v in (("plan: no count atomics", 0x100), ("plan: no probes", 0x200), ("plan: no slot stores", 0x400),
+              ("plan: none of the three", 0x700)):
+    print("%-21s: %8.1f us" % (nm, timeit(lambda: dp.plan_batch(octree, batches[0][0], _debug_variant=v))))
+print("plan + fused zero    : %8.1f us" % timeit(lambda: dp.plan_batch(octree, batches[0][0], zero=red.flat)))
 print("radix-ordered step   : %8.1f us" % timeit(lambda: step(0, planned=False)))
 print("zero grads           : %8.1f us" % timeit(red.zero_grads))
 rows = [("full", 0), ("unsorted input", 0), ("no atomics", 0x100), ("no weight-grad phase", 0x200),
