@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--order", default="plan", choices=["plan", "radix"],
                     help="plan: counting sort by octree node + slot hand-off (shine_plan_batch); radix: Morton radix sort")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the data-parallel code path even at world size 1")
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not overlap the plan of batch i+1 with the fused step of batch i (second stream)")
     args = ap.parse_args()
@@ -119,16 +121,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
 
     from shine_mapping_amd import StepOptions, fused_train_step, synth
     from shine_mapping_amd import dp as shine_dp
@@ -164,7 +169,7 @@ def main():
             reducer.all_reduce_scalar(n_surf)
         perm, slots = order(c, zero=reducer.flat)
         loss, pred, _ = fused_train_step(octree, decoder, c, l, w, opts, perm=perm, n_surf=n_surf, slots=slots)
-        if world > 1:
+        if use_dist:
             reducer.all_reduce_grads()
         return loss
 
@@ -183,8 +188,8 @@ def main():
     # of the first timed batch is produced by the last warm-up iteration, the last timed iteration plans one ahead).
     launch = "eager"
     graphs, graph_loss = [], []
-    pipelined = (not args.no_graph and not args.no_overlap and world == 1 and not args.no_sort and args.order == "plan"
-                 and len(batches) % 2 == 0)
+    pipelined = (not args.no_graph and not args.no_overlap and not use_dist and not args.no_sort
+                 and args.order == "plan" and len(batches) % 2 == 0)
     if pipelined:
         try:
             side = torch.cuda.Stream()
@@ -236,7 +241,7 @@ def main():
             for p in params:
                 p.grad = torch.zeros_like(p)
             reducer = shine_dp.GradReducer(params, dist)
-    if not pipelined and not args.no_graph and world == 1:
+    if not pipelined and not args.no_graph and not use_dist:
         try:
             for i in range(len(batches)):
                 step_body(i)  # warm caches / allocate workspaces outside capture
@@ -307,6 +312,33 @@ def main():
         times.append(e0.elapsed_time(e1) / R)
     kernel_ms = sorted(times)[len(times) // 2]
 
+    # the reference's whole iteration (timing(s)/total, shine_batch.py:225): step + optimiser.  Fused Adam clears the
+    # grads in the same pass, so the plan no longer has to.  Reported next to `value`, never instead of it.
+    iter_ms = None
+    if not use_dist:
+        from shine_mapping_amd.optim import setup_optimizer
+
+        cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio = True, 1e-15, 1.0
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        adam = setup_optimizer(cfg, list(octree.parameters()), decoder.fused_params())
+
+        def iteration(i):
+            c, l, w = batches[i % len(batches)]
+            ns = (w > 0).sum() if opts.ekional_loss_on else None
+            pm, sl = order(c)
+            fused_train_step(octree, decoder, c, l, w, opts, perm=pm, n_surf=ns, slots=sl)
+            adam.step(zero_grad=True)
+
+        for i in range(3):
+            iteration(i)
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        for i in range(args.steps):
+            iteration(i)
+        torch.cuda.synchronize()
+        iter_ms = (time.perf_counter() - ti) / args.steps * 1e3
+
     if rank == 0:
         bpp = algorithmic_bytes_per_point(levels)
         achieved = points * bpp / (kernel_ms * 1e-3) / 1e9
@@ -333,6 +365,9 @@ def main():
                 "algorithmic_bytes_per_point": bpp,
             },
             "final_loss": float(loss),
+            "iteration_with_fused_adam": None if iter_ms is None else {
+                "ms_per_iteration": iter_ms, "samples_per_s": points / (iter_ms * 1e-3), "launch": "eager",
+                "what": "plan + fused step + fused dense Adam (also clears grads); reference timing(s)/total"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, wl)
