@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--order", default="plan", choices=["plan", "radix"],
                     help="plan: counting sort by octree node + slot hand-off (shine_plan_batch); radix: Morton radix sort")
+    ap.add_argument("--sampler", default="pool", choices=["pool", "batch"],
+                    help="pool: the step draws its batch as sorted indices from the node-ordered pool (sampler + order "
+                         "fusion, f-3); batch: the step is handed pre-drawn unsorted batches and orders them itself")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the data-parallel code path even at world size 1")
@@ -160,6 +163,25 @@ def main():
             return (None if args.no_sort else shine_dp.morton_order(octree, c)), None
         return shine_dp.plan_batch(octree, c, zero=zero)  # the plan pass also clears the gradient bucket
 
+    spool = None
+    if args.sampler == "pool" and not args.no_sort:
+        from shine_mapping_amd.sampler import SortedPool
+
+        octree._require_tables(with_ranks=True)
+        spool = SortedPool(octree, pool.coord, pool.sdf_label, pool.weight, seed=1000 + rank)  # once per frame
+
+    def pool_step_body(i):
+        """draw a sorted batch from the node-ordered pool (+ clear grads in the same pass) -> fused step (-> all-reduce)"""
+        idx = spool.draw(points, zero=reducer.flat)
+        n_surf = None
+        if opts.ekional_loss_on:
+            n_surf = (spool.weight[idx.long()] > 0).sum()
+            reducer.all_reduce_scalar(n_surf)
+        loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx)
+        if use_dist:
+            reducer.all_reduce_grads()
+        return loss
+
     def step_body(i):
         """zero grads -> Morton order -> fused query+decode+loss+backward (-> all-reduce)"""
         c, l, w = batches[i % len(batches)]
@@ -188,7 +210,7 @@ def main():
     # of the first timed batch is produced by the last warm-up iteration, the last timed iteration plans one ahead).
     launch = "eager"
     graphs, graph_loss = [], []
-    pipelined = (not args.no_graph and not args.no_overlap and not use_dist and not args.no_sort
+    pipelined = (spool is None and not args.no_graph and not args.no_overlap and not use_dist and not args.no_sort
                  and args.order == "plan" and len(batches) % 2 == 0)
     if pipelined:
         try:
@@ -241,6 +263,12 @@ def main():
             for p in params:
                 p.grad = torch.zeros_like(p)
             reducer = shine_dp.GradReducer(params, dist)
+    if spool is not None:
+        step_body = pool_step_body  # noqa: F811  (the pool-mode body replaces the batch-mode one everywhere below)
+    if spool is not None and not args.no_graph and not use_dist:
+        # a replayed graph would replay the same random stream id; graphs are captured for a ring of stream ids instead
+        # (SortedPool.draws advances at capture time), i.e. the timed loop cycles through `len(batches)` distinct draws.
+        pass
     if not pipelined and not args.no_graph and not use_dist:
         try:
             for i in range(len(batches)):
@@ -281,12 +309,20 @@ def main():
     # (same sorted batch; the tiny partial-sum reduction rides along), averaged per launch.
     R = 10
     c0, l0, w0 = batches[0]
-    perm0, slots0 = order(c0)
-    ns0 = (w0 > 0).sum() if opts.ekional_loss_on else None
+    if spool is not None:
+        idx0 = spool.draw(points)
+        ns0 = (spool.weight[idx0.long()] > 0).sum() if opts.ekional_loss_on else None
 
-    def fused_only():
-        for _ in range(R):
-            fused_train_step(octree, decoder, c0, l0, w0, opts, perm=perm0, n_surf=ns0, slots=slots0)
+        def fused_only():
+            for _ in range(R):
+                fused_train_step(octree, decoder, None, None, None, opts, n_surf=ns0, pool=spool, idx=idx0)
+    else:
+        perm0, slots0 = order(c0)
+        ns0 = (w0 > 0).sum() if opts.ekional_loss_on else None
+
+        def fused_only():
+            for _ in range(R):
+                fused_train_step(octree, decoder, c0, l0, w0, opts, perm=perm0, n_surf=ns0, slots=slots0)
 
     fused_only()
     torch.cuda.synchronize()
@@ -324,10 +360,15 @@ def main():
         adam = setup_optimizer(cfg, list(octree.parameters()), decoder.fused_params())
 
         def iteration(i):
-            c, l, w = batches[i % len(batches)]
-            ns = (w > 0).sum() if opts.ekional_loss_on else None
-            pm, sl = order(c)
-            fused_train_step(octree, decoder, c, l, w, opts, perm=pm, n_surf=ns, slots=sl)
+            if spool is not None:
+                ix = spool.draw(points)
+                ns = (spool.weight[ix.long()] > 0).sum() if opts.ekional_loss_on else None
+                fused_train_step(octree, decoder, None, None, None, opts, n_surf=ns, pool=spool, idx=ix)
+            else:
+                c, l, w = batches[i % len(batches)]
+                ns = (w > 0).sum() if opts.ekional_loss_on else None
+                pm, sl = order(c)
+                fused_train_step(octree, decoder, c, l, w, opts, perm=pm, n_surf=ns, slots=sl)
             adam.step(zero_grad=True)
 
         for i in range(3):
@@ -355,7 +396,9 @@ def main():
                 "points_per_iter_per_gpu": points, "levels": levels, "frames": args.frames,
                 "pool_samples": int(pool.sdf_label.shape[0]),
                 "corner_rows": [int(p.shape[0]) for p in octree.hier_features],
-                "batch_order": "none" if args.no_sort else args.order, "parallelism": "dp%d" % world,
+                "batch_order": "none" if args.no_sort else ("sorted draw from the node-ordered pool (f-3)"
+                                                            if spool is not None else args.order),
+                "parallelism": "dp%d" % world,
                 "launch": launch,
             },
             "roofline": {

@@ -53,7 +53,9 @@ typedef struct shine_step_config {
   int32_t reduction_sum;   /* 0: "mean", 1: "sum"                      (utils/loss.py:17-24, shine_incre.py:77-78) */
   int32_t eikonal_on;      /* closed-form eikonal term                 (shine_batch.py:141-142,182-185) */
   int32_t decoder_grad_on; /* 0 when the decoder is frozen             (utils/tools.py:188-191) */
-  int32_t sorted_input;    /* points are visited through perm[] (Morton order) when non-zero */
+  int32_t sorted_input;    /* 0: visit the batch as given; 1: through perm[] (shine_plan_batch / shine_morton_sort);
+                              2: POOL mode — coord/label/weight/slots are a node-ordered sample pool, perm[] holds the
+                              batch's sorted sample indices (shine_sample_sorted), outputs are written at batch position */
   int32_t kernel_variant;  /* 0: auto (fastest kernel that supports the config), 1: force the simple v0 kernel */
   float sigma;             /* sigma_sigmoid = ratio*sigma_m*scale      (shine_batch.py:87) */
   float weight_e;          /* eikonal weight                           (config weight_e) */
@@ -172,6 +174,16 @@ int shine_tables_set_ranks(shine_tables* t, int32_t slot, const int64_t* keys, c
 int shine_plan_batch(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,
                      int32_t* perm_out, int32_t* slots_out, void* zero_ptr, size_t zero_bytes, void* workspace,
                      size_t* workspace_bytes, void* stream);
+
+/* ---- sampler + order fusion (next row f-3): LiDARDataset.get_batch (dataset/lidar_dataset.py:430-450) as SORTED i.i.d.
+ *      uniform indices (exact order statistics via exponential spacings: the same multiset distribution as
+ *      torch.randint, no sort).  With the pool kept in node order (shine_plan_batch on the whole pool, once per frame)
+ *      the drawn batch is already ordered: pass idx_out as `perm` to shine_train_step with cfg->sorted_input = 2.
+ *      idx_out [n] int32 ascending; (seed, stream_id) select the random stream (use the iteration number as
+ *      stream_id).  zero_ptr/zero_bytes: optional 16-B aligned buffer cleared in the same pass (the gradient bucket).
+ *      workspace == NULL returns the required bytes. ------------------------------------------------------------------ */
+int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,
+                        void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
 
 /* ---- device self-test: D[32,32] = A[32,2] . B[2,32] through ONE v_mfma_f32_32x32x2_f32, written back with the
  *      accumulator lane map the fused kernel relies on (pins the MFMA operand layouts on the hardware). --- */

@@ -91,6 +91,8 @@ struct V1Args {
   int reduction_sum;
   int decoder_grad_on;
   int poly;
+  int pool_mode;  // 1: coord/label/weight/slots are a node-ordered POOL indexed by perm[i] (sorted sample indices,
+                  //    shine_sample_sorted); pred / grad_x are written at the batch position i.  0: a batch.
   int ablate;  // debug only (kernel_variant >> 8): 1 no feature atomics, 2 no weight-grad phase, 4 no scatter phase,
                // 8 no row gathers, 16 no probe (every point misses)
   float sigma;
@@ -253,11 +255,12 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   for (int s = 0; s < LCAP; ++s) nslot[s] = -1;
   bool nvalid = begin + pt < end;
   if (nvalid) {
-    if (a.slots) {
-#pragma unroll
-      for (int s = 0; s < L; ++s) nslot[s] = a.slots[(begin + pt) * L + s];
-    }
     np = a.perm ? (long long)a.perm[begin + pt] : begin + pt;
+    if (a.slots) {
+      const long long si = a.pool_mode ? np : begin + pt;
+#pragma unroll
+      for (int s = 0; s < L; ++s) nslot[s] = a.slots[si * L + s];
+    }
     nx0 = a.coord[3 * np];
     nx1 = a.coord[3 * np + 1];
     nx2 = a.coord[3 * np + 2];
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   for (long long base = begin; base < end; base += 32) {
     const bool valid = nvalid;
     const long long p = np;
+    const long long po = a.pool_mode ? base + pt : p;  // where this point's outputs go
     const float x0 = nx0, x1 = nx1, x2 = nx2, label = nlabel, wgt = nweight;
     int pslot[LCAP];
 #pragma unroll
@@ -281,11 +285,12 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
       for (int s = 0; s < LCAP; ++s) nslot[s] = -1;
       if (nvalid) {
-        if (a.slots) {
-#pragma unroll
-          for (int s = 0; s < L; ++s) nslot[s] = a.slots[ni * L + s];
-        }
         np = a.perm ? (long long)a.perm[ni] : ni;
+        if (a.slots) {
+          const long long si = a.pool_mode ? np : ni;
+#pragma unroll
+          for (int s = 0; s < L; ++s) nslot[s] = a.slots[si * L + s];
+        }
         nx0 = a.coord[3 * np];
         nx1 = a.coord[3 * np + 1];
         nx2 = a.coord[3 * np + 2];
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
       yp = fmaf(s_bias[SB_W3 + rowidx(r, h)], h2[r], yp);
     }
     const float y = yp + __shfl_xor(yp, 32, 64) + b3;
-    if (valid && h == 0 && a.pred) a.pred[p] = y;
+    if (valid && h == 0 && a.pred) a.pred[po] = y;
 
     // ---------------------------------------------------------------- eikonal: d pred / d coord (closed form)
     float v1[16], g[3] = {0.f, 0.f, 0.f};
@@ -459,9 +464,9 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
         g[e] = sigma * s;
       }
       if (valid && h == 0 && a.grad_x) {
-        a.grad_x[3 * p] = g[0];
-        a.grad_x[3 * p + 1] = g[1];
-        a.grad_x[3 * p + 2] = g[2];
+        a.grad_x[3 * po] = g[0];
+        a.grad_x[3 * po + 1] = g[1];
+        a.grad_x[3 * po + 2] = g[2];
       }
     }
     SHINE_STAMP(2)  // decoder forward
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
       yp = fmaf(s_bias[SB_W3 + rowidx(r, h)], h2[r], yp);
     }
     const float y = yp + __shfl_xor(yp, 32, 64) + b3;
-    if (valid && h == 0 && a.pred) a.pred[p] = y;
+    if (valid && h == 0 && a.pred) a.pred[po] = y;
     SHINE_STAMP(2)  // decoder forward
 
     // ================================================================ phase 3: BCE loss
@@ -675,9 +680,9 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
         g[e] = sigma * sm;  // get_gradient(coord, pred) * sigma   (utils/tools.py:175-185, shine_batch.py:141-142)
       }
       if (valid && h == 0 && a.grad_x) {
-        a.grad_x[3 * p] = g[0];
-        a.grad_x[3 * p + 1] = g[1];
-        a.grad_x[3 * p + 2] = g[2];
+        a.grad_x[3 * po] = g[0];
+        a.grad_x[3 * po + 1] = g[1];
+        a.grad_x[3 * po + 2] = g[2];
       }
       if (valid && wgt > 0.f) {  // surface samples only (shine_batch.py:137,183)
         const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
@@ -1143,6 +1148,8 @@ extern "C" int shine_train_step_v1(const shine_tables* t, const shine_step_confi
   a.reduction_sum = cfg->reduction_sum;
   a.decoder_grad_on = cfg->decoder_grad_on;
   a.poly = cfg->poly_int_on;
+  a.pool_mode = cfg->sorted_input == 2 ? 1 : 0;
+  if (a.pool_mode && !perm) return set_error(SHINE_E_INVALID, "shine_train_step: pool mode needs the sample indices in perm");
   a.ablate = cfg->kernel_variant >> 8;
   a.prof = g_prof_buffer;
   a.sigma = cfg->sigma;

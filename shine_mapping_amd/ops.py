@@ -33,6 +33,10 @@ class StepOptions:
     kernel_variant: int = 0           # 0 auto; 1 forces the simple v0 kernel (kept as an on-device cross-check)
 
 
+def eik_needs_count(opts) -> bool:
+    return bool(opts.ekional_loss_on)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -84,7 +88,8 @@ def forward_sdf(octree, decoder, coord, want_feat=False, want_indices=False, wan
 
 
 def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
-                     n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None):
+                     n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None,
+                     pool=None, idx: Optional[torch.Tensor] = None):
     """One training iteration's forward+backward (no optimiser): the fused Tier-B step.
 
     coord [N,3], sdf_label [N], weight [N] (sign: + surface / - free space, utils/data_sampler.py:102-103).
@@ -93,8 +98,17 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     loss is a 0-dim float64 device tensor (no host sync) and g = get_gradient(coord,pred)*sigma or None.
     """
     t = octree._require_tables()
+    pool_mode = pool is not None
+    if pool_mode:  # batch = pool[idx] with idx sorted (sampler.SortedPool.draw): read straight out of the pool
+        if idx is None or not (idx.is_cuda and idx.dtype == torch.int32):
+            raise ValueError("pool mode needs idx = SortedPool.draw(n) (CUDA int32)")
+        if pool.tables_version != octree._n_buckets:
+            raise RuntimeError("the octree grew since the pool was planned: call SortedPool.rebuild()")
+        coord, sdf_label, weight, perm, slots = pool.coord, pool.sdf_label, pool.weight, idx, pool.slots
+        if eik_needs_count(opts) and n_surf is None:
+            n_surf = (pool.weight[idx.long()] > 0).sum()
     coord = octree._check_coord(coord.detach())
-    n = coord.shape[0]
+    n = idx.numel() if pool_mode else coord.shape[0]
     dev = coord.device
     sdf_label = _f32(sdf_label, "sdf_label")
     eik = bool(opts.ekional_loss_on)
@@ -110,7 +124,8 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     cfg = octree.step_config(
         sigma=float(opts.sigma), weight_e=float(opts.weight_e), eikonal_on=1 if eik else 0,
         reduction_sum=1 if opts.loss_reduction == "sum" else 0, decoder_grad_on=1 if dec_grad else 0,
-        sorted_input=0 if perm is None else 1, n_global=n_global, kernel_variant=int(opts.kernel_variant),
+        sorted_input=2 if pool_mode else (0 if perm is None else 1), n_global=n_global,
+        kernel_variant=int(opts.kernel_variant),
         inv_n=(1.0 if opts.loss_reduction == "sum" else 1.0 / max(n_global, 1)),
     )
     if eik and n_surf is None:
@@ -122,8 +137,8 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     gmlp = [_dense_grad(p) for p in params] if dec_grad else [None] * 6
     if perm is not None and not (perm.is_cuda and perm.dtype == torch.int32 and perm.numel() == n):
         raise ValueError("perm must be a CUDA int32 tensor of N entries")
-    if slots is not None and not (perm is not None and slots.is_cuda and slots.dtype == torch.int32
-                                  and slots.numel() == n * octree.featured_level_num):
+    if slots is not None and not pool_mode and not (perm is not None and slots.is_cuda and slots.dtype == torch.int32
+                                                    and slots.numel() == n * octree.featured_level_num):
         raise ValueError("slots must come with perm from dp.plan_batch: CUDA int32 [N, L]")
     ws = _workspace(dev, int(_lib.lib().shine_train_step_workspace_bytes(C.byref(cfg), n)))
     _lib.check(

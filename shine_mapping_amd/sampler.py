@@ -1,0 +1,59 @@
+"""SortedPool — LiDARDataset's sample pool kept in octree-node order, batches drawn as sorted indices (§8 f-3).
+
+The reference keeps (coord, sdf_label, weight) pools and draws ``torch.randint`` indices every iteration
+(dataset/lidar_dataset.py:430-450).  Here the pool is planned ONCE per frame (shine_plan_batch over the whole pool:
+node order + every sample's hash slots), stored in that order, and ``draw(n)`` returns n sorted i.i.d. uniform indices
+(shine_sample_sorted) — the same multiset distribution as randint.  ``fused_train_step(..., pool=sp, idx=idx)`` then
+reads an already node-ordered batch straight out of the pool: no per-batch sort, no hashing in the fused kernel.
+Re-plan (``rebuild``) whenever the octree grows: hash slots move when a table rehashes.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .dp import plan_batch
+
+
+class SortedPool:
+    def __init__(self, octree, coord, sdf_label, weight, seed=42):
+        self.octree = octree
+        self.seed = int(seed)
+        self.draws = 0
+        self._ws = None
+        self.rebuild(coord, sdf_label, weight)
+
+    def rebuild(self, coord, sdf_label, weight):
+        perm, slots = plan_batch(self.octree, coord)
+        p = perm.long()
+        self.coord = coord[p].contiguous()
+        self.sdf_label = sdf_label[p].contiguous()
+        self.weight = weight[p].contiguous()
+        self.slots = slots  # already in pool (= visiting) order
+        self.size = int(coord.shape[0])
+        self.tables_version = self.octree._n_buckets
+
+    def draw(self, n, out=None, zero=None):
+        """n sorted i.i.d. uniform sample indices (int32, device).  `zero`: optional contiguous float tensor cleared in
+        the same pass (the flat gradient bucket, i.e. opt.zero_grad())."""
+        dev = self.coord.device
+        lib = _lib.lib()
+        stream = torch.cuda.current_stream().cuda_stream
+        if self._ws is None or self._ws[1] != n:
+            need = C.c_size_t(0)
+            _lib.check(lib.shine_sample_sorted(self.size, n, self.seed, 0, None, None, 0, None, C.byref(need), stream),
+                       "shine_sample_sorted")
+            self._ws = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev), n, int(need.value))
+        idx = out if out is not None else torch.empty(n, dtype=torch.int32, device=dev)
+        need = C.c_size_t(self._ws[2])
+        _lib.check(lib.shine_sample_sorted(self.size, n, self.seed, self.draws, idx.data_ptr(),
+                                           zero.data_ptr() if zero is not None else None,
+                                           zero.numel() * zero.element_size() if zero is not None else 0,
+                                           self._ws[0].data_ptr(), C.byref(need), stream), "shine_sample_sorted")
+        self.draws += 1
+        return idx
+
+    def get_batch(self, idx):
+        """(coord, sdf_label, weight) of a drawn batch, for code that wants the tensors (Tier A / debugging)."""
+        i = idx.long()
+        return self.coord[i], self.sdf_label[i], self.weight[i]

@@ -477,3 +477,68 @@ def test_training_trajectory_matches_oracle(name):
         assert rel_err(octree.hier_features[k], r) <= 2e-4
     for p, r in zip(dec.fused_params(), mlp.params()):
         assert rel_err(p, r) <= 2e-4
+
+
+def test_sorted_sampler_is_sorted_uniform_and_reproducible():
+    """shine_sample_sorted: ascending indices in range, uniform over the pool (64-bin chi-square), a new stream id gives
+    a new draw, the same (seed, stream) reproduces it."""
+    from shine_mapping_amd import _lib
+    import ctypes as C
+
+    lib = _lib.lib()
+    pool, n = 1_000_003, 1 << 16
+    need = C.c_size_t(0)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.shine_sample_sorted(pool, n, 7, 0, None, None, 0, None, C.byref(need), st))
+    ws = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+    draws = []
+    for stream_id in (0, 1, 0):
+        idx = torch.empty(n, dtype=torch.int32, device="cuda")
+        _lib.check(lib.shine_sample_sorted(pool, n, 7, stream_id, idx.data_ptr(), None, 0, ws.data_ptr(), C.byref(need), st))
+        torch.cuda.synchronize()
+        draws.append(idx.cpu().long())
+    a, b, a2 = draws
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    for d in (a, b):
+        assert bool((d[1:] >= d[:-1]).all()) and int(d.min()) >= 0 and int(d.max()) < pool
+        hist = torch.bincount((d * 64) // pool, minlength=64).double()
+        chi2 = float(((hist - n / 64) ** 2 / (n / 64)).sum())
+        assert chi2 < 130.0, chi2  # 63 dof: mean 63, sd ~11
+    # gaps of sorted iid uniforms are ~geometric: about n*(1-exp(-n/pool)) / ... duplicates are expected and allowed
+    assert int((a[1:] == a[:-1]).sum()) > 0
+
+
+@pytest.mark.parametrize("name", ["maicity_bce_L4", "kitti_eik_L3"])
+def test_pool_mode_step_equals_batch_mode_on_the_drawn_batch(name):
+    """SortedPool: the fused step reading straight out of the node-ordered pool (sorted indices, pool slots) must equal
+    the step on the gathered batch, and the oracle on the same points."""
+    from oracle import shine_oracle as so
+    from shine_mapping_amd import fused_train_step
+    from shine_mapping_amd.sampler import SortedPool
+
+    fx = load_golden(name)
+    cfg, octree, dec = product_from_golden(fx)
+    octree._require_tables(with_ranks=True)
+    sp = SortedPool(octree, fx["coord"].cuda(), fx["sdf_label"].cuda(), fx["weight"].cuda(), seed=3)
+    idx = sp.draw(1500)
+    params = list(octree.hier_features) + dec.fused_params()
+    loss_p, pred_p, g_p = fused_train_step(octree, dec, None, None, None, step_options(fx), want_grad_x=True,
+                                           pool=sp, idx=idx)
+    grads_p = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    c, l, w = sp.get_batch(idx)
+    loss_b, pred_b, g_b = fused_train_step(octree, dec, c.contiguous(), l.contiguous(), w.contiguous(),
+                                           step_options(fx), want_grad_x=True)
+    torch.cuda.synchronize()
+    assert abs(float(loss_p) - float(loss_b)) <= 1e-6 * max(1.0, abs(float(loss_b)))
+    assert abs_err(pred_p, pred_b) <= 1e-5
+    if g_b is not None:
+        assert rel_err(g_p, g_b) <= 1e-5
+    for a, b in zip(grads_p, [p.grad for p in params]):
+        assert rel_err(a, b) <= 2e-5
+    ocfg, oct_, mlp = oracle_from_golden(fx)
+    ref = so.train_step(oct_, mlp, c.cpu(), l.cpu(), w.cpu(), ocfg)
+    assert abs_err(pred_p, ref["pred"]) <= TOL
+    for k, r in enumerate(ref["feat_grads"]):
+        assert rel_err(grads_p[k], r) <= TOL
