@@ -8,11 +8,7 @@
 //       E_0..E_n ~ Exp(1) i.i.d.,  S_k = E_0 + .. + E_k,   U_(k) = S_k / S_n   (k < n)  are the sorted uniforms,
 //       idx_k = floor(U_(k) * pool_size).
 // As a multiset this is exactly `randint` (sampling with replacement); only the order differs, which no loss term
-// depends on.  Three launches: Exp(1) variates from a counter-based generator, an inclusive scan (rocPRIM), the
-// scaling.  No atomics, ~n * 16 B of traffic.
-#include <cstring>
-#include <rocprim/device/device_scan.hpp>
-
+// depends on.  Two launches (block sums, then regenerate + scan + scale), no atomics, no scratch array.
 #include "shine_internal.hpp"
 
 namespace shine {
@@ -26,20 +22,78 @@ __device__ __forceinline__ double u01(unsigned long long seed, unsigned long lon
   return ((double)(z >> 11) + 1.0) * (1.0 / 9007199254740992.0);  // (0,1]
 }
 
-__global__ __launch_bounds__(256) void k_exp_variates(double* e, long long n1, unsigned long long seed,
-                                                      unsigned long long stream, float4* zero_ptr, long long zero_n16) {
-  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
-  // ride-along clear of the gradient bucket (opt.zero_grad for the fused step), as in shine_plan_batch
-  for (long long z = k; z < zero_n16; z += (long long)gridDim.x * 256) zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (k < n1) e[k] = -log(u01(seed, stream, (unsigned long long)k));
+// Two launches, no scratch array: the generator is counter-based, so pass 2 simply REGENERATES the variates of its
+// block instead of reading them back.
+//   pass 1  per block of SB draws: sum of its Exp(1) variates -> block_sum[b]   (also clears the gradient bucket)
+//   pass 2  every block adds up the (few hundred) block sums in front of it, regenerates its variates, scans them in
+//           LDS and writes idx_k = floor(S_k / S_total * pool).
+constexpr int SB = 1024;  // draws per block (256 threads x 4)
+
+__device__ __forceinline__ double block_sum_256(double v, double* s_red) {
+  v = wave_sum_d(v);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  __syncthreads();
+  return t;
 }
 
-__global__ __launch_bounds__(256) void k_scale_indices(const double* s, long long n, long long pool, int* idx) {
-  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
-  const double u = s[k] / s[n];  // s[n] = total of the n+1 variates
-  long long v = (long long)(u * (double)pool);
-  idx[k] = (int)(v < 0 ? 0 : (v >= pool ? pool - 1 : v));
+__global__ __launch_bounds__(256) void k_sample_pass1(double* block_sum, long long n1, unsigned long long seed,
+                                                      unsigned long long stream, float4* zero_ptr, long long zero_n16) {
+  __shared__ double s_red[4];
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  // ride-along clear of the gradient bucket (opt.zero_grad for the fused step), as in shine_plan_batch
+  for (long long z = g; z < zero_n16; z += (long long)gridDim.x * 256) zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long k0 = (long long)blockIdx.x * SB + threadIdx.x * 4;
+  double v = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (k0 + j < n1) v += -log(u01(seed, stream, (unsigned long long)(k0 + j)));
+  const double t = block_sum_256(v, s_red);
+  if (threadIdx.x == 0) block_sum[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, int nblocks, long long n, long long pool,
+                                                      unsigned long long seed, unsigned long long stream, int* idx) {
+  __shared__ double s_red[4];
+  __shared__ double s_wave_pre[4];
+  // prefix of the blocks in front of this one, and the grand total (nblocks is a few hundred)
+  double before = 0.0, total = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    const double v = block_sum[b];
+    total += v;
+    if (b < (int)blockIdx.x) before += v;
+  }
+  before = block_sum_256(before, s_red);
+  total = block_sum_256(total, s_red);
+  const long long k0 = (long long)blockIdx.x * SB + threadIdx.x * 4;
+  double e[4], run = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    e[j] = (k0 + j <= n) ? -log(u01(seed, stream, (unsigned long long)(k0 + j))) : 0.0;
+    run += e[j];
+  }
+  // exclusive scan of the per-thread sums across the block: within the wave by shuffles, across waves via LDS
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double inc = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) s_wave_pre[wv] = inc;
+  __syncthreads();
+  double wpre = 0.0;
+  for (int w = 0; w < wv; ++w) wpre += s_wave_pre[w];
+  double s = before + wpre + (inc - run);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s += e[j];
+    if (k0 + j < n) {
+      long long v = (long long)((s / total) * (double)pool);
+      idx[k0 + j] = (int)(v < 0 ? 0 : (v >= pool ? pool - 1 : v));
+    }
+  }
 }
 
 static size_t align256s(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -54,11 +108,9 @@ extern "C" int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, 
   if (!workspace_bytes || n < 0 || pool_size < 1 || pool_size > 0x7fffffffll)
     return set_error(SHINE_E_INVALID, "shine_sample_sorted: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  const size_t n1 = (size_t)n + 1;
-  size_t scan_bytes = 0;
-  SHINE_HIP_CHECK(rocprim::inclusive_scan(nullptr, scan_bytes, (double*)nullptr, (double*)nullptr, n1,
-                                          rocprim::plus<double>(), st));
-  const size_t o_e = 0, o_scan = align256s(n1 * 8), need = o_scan + align256s(scan_bytes);
+  const long long n1 = (long long)n + 1;  // n draws + the closing spacing
+  const long long nblocks = (n1 + SB - 1) / SB;
+  const size_t need = align256s((size_t)nblocks * sizeof(double));
   if (!workspace) {
     *workspace_bytes = need;
     return SHINE_OK;
@@ -71,13 +123,12 @@ extern "C" int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, 
     return SHINE_OK;
   }
   if (!idx_out) return set_error(SHINE_E_INVALID, "shine_sample_sorted: null output");
-  double* e = (double*)((char*)workspace + o_e);
-  const dim3 grid((unsigned)((n1 + 255) / 256)), block(256);
-  hipLaunchKernelGGL(k_exp_variates, grid, block, 0, st, e, (long long)n1, (unsigned long long)seed,
+  double* bs = (double*)workspace;
+  hipLaunchKernelGGL(k_sample_pass1, dim3((unsigned)nblocks), dim3(256), 0, st, bs, n1, (unsigned long long)seed,
                      (unsigned long long)stream_id, (float4*)zero_ptr, zero_ptr ? (long long)(zero_bytes / 16) : 0ll);
   SHINE_HIP_CHECK(hipGetLastError());
-  SHINE_HIP_CHECK(rocprim::inclusive_scan((char*)workspace + o_scan, scan_bytes, e, e, n1, rocprim::plus<double>(), st));
-  hipLaunchKernelGGL(k_scale_indices, grid, block, 0, st, e, (long long)n, (long long)pool_size, (int*)idx_out);
+  hipLaunchKernelGGL(k_sample_pass2, dim3((unsigned)nblocks), dim3(256), 0, st, bs, (int)nblocks, (long long)n,
+                     (long long)pool_size, (unsigned long long)seed, (unsigned long long)stream_id, (int*)idx_out);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }
