@@ -94,7 +94,7 @@ struct V1Args {
   int pool_mode;  // 1: coord/label/weight/slots are a node-ordered POOL indexed by perm[i] (sorted sample indices,
                   //    shine_sample_sorted); pred / grad_x are written at the batch position i.  0: a batch.
   int ablate;  // debug only (kernel_variant >> 8): 1 no feature atomics, 2 no weight-grad phase, 4 no scatter phase,
-               // 8 no row gathers, 16 no probe (every point misses)
+               // 8 no row gathers, 16 no probe (every point misses), 32 skip the partial-sum reduction launch
   float sigma;
   float inv_n;
   float weight_e;
@@ -1169,7 +1169,7 @@ extern "C" int shine_train_step_v1(const shine_tables* t, const shine_step_confi
   else
     launch_v1<false>(a, cfg->n_levels, grid, st);
   SHINE_HIP_CHECK(hipGetLastError());
-  if (a.partials) {
+  if (a.partials && !(a.ablate & 32)) {  // (ablate bit 32: measurement only — time the dominant kernel by itself)
     hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks);
     SHINE_HIP_CHECK(hipGetLastError());
   }

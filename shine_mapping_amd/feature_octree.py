@@ -137,6 +137,7 @@ class FeatureOctree(nn.Module):
         self._sort_box_cache = None
         self._ranks_uploaded = False
         self._n_buckets = 0
+        self._tables_epoch = 0  # bumped whenever nodes are added (hash slots may move): invalidates planned pools
         self._tables = None  # created at the first query (needs the GPU); update() itself is host-only
         self._pending = [[] for _ in range(L)]  # (node keys, corner ids) not yet inserted on the device
         # a level's regulariser contributes gradient only while its features_last_frame copy is detached
@@ -264,6 +265,7 @@ class FeatureOctree(nn.Module):
             self._node_ids[s] = np.concatenate((self._node_ids[s], ids))
             self._node_sorted[s] = np.sort(np.concatenate((known, fresh)))
             self._pending[s].append((fresh, ids))  # uploaded to the device hash table at the next query
+            self._tables_epoch += 1
 
     # ------------------------------------------------------------------ hot path plumbing
     def _require_tables(self, with_ranks=False):
@@ -419,6 +421,7 @@ class FeatureOctree(nn.Module):
         (after unpickling / device move)."""
         self._tables = None
         self._ranks_uploaded = False
+        self._tables_epoch = getattr(self, "_tables_epoch", 0) + 1
         self._pending = [[(self._node_keys[s], self._node_ids[s])] if self._node_keys[s].size else []
                          for s in range(self.featured_level_num)]
 

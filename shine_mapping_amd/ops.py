@@ -102,7 +102,7 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     if pool_mode:  # batch = pool[idx] with idx sorted (sampler.SortedPool.draw): read straight out of the pool
         if idx is None or not (idx.is_cuda and idx.dtype == torch.int32):
             raise ValueError("pool mode needs idx = SortedPool.draw(n) (CUDA int32)")
-        if pool.tables_version != octree._n_buckets:
+        if pool.tables_epoch != octree._tables_epoch:
             raise RuntimeError("the octree grew since the pool was planned: call SortedPool.rebuild()")
         coord, sdf_label, weight, perm, slots = pool.coord, pool.sdf_label, pool.weight, idx, pool.slots
         if eik_needs_count(opts) and n_surf is None:

@@ -31,7 +31,7 @@ class SortedPool:
         self.weight = weight[p].contiguous()
         self.slots = slots  # already in pool (= visiting) order
         self.size = int(coord.shape[0])
-        self.tables_version = self.octree._n_buckets
+        self.tables_epoch = self.octree._tables_epoch
 
     def draw(self, n, out=None, zero=None):
         """n sorted i.i.d. uniform sample indices (int32, device).  `zero`: optional contiguous float tensor cleared in

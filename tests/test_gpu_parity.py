@@ -542,3 +542,70 @@ def test_pool_mode_step_equals_batch_mode_on_the_drawn_batch(name):
     assert abs_err(pred_p, ref["pred"]) <= TOL
     for k, r in enumerate(ref["feat_grads"]):
         assert rel_err(grads_p[k], r) <= TOL
+
+
+def test_incremental_loop_end_to_end():
+    """shine_incre.py:86-195 on the fused path: per frame update() -> re-plan the pool -> iterations of
+    {sorted draw, fused step (sum reduction) + regulariser, fused Adam} -> importance sweep.  Checks the plumbing
+    that the piecewise parity tests do not: table growth + rehash between frames, pool re-planning, optimiser
+    re-creation (feature_octree.py:156 re-creates the Parameters), the regulariser actually restraining drift."""
+    from shine_mapping_amd import Decoder, FeatureOctree, StepOptions, fused_train_step, synth
+    from shine_mapping_amd.incre_learning import cal_feature_importance
+    from shine_mapping_amd.ops import fused_regularization, touched_flags
+    from shine_mapping_amd.optim import setup_optimizer
+    from shine_mapping_amd.sampler import SortedPool
+
+    cfg = synth.make_config("ncd", device="cuda", lr=0.01, opt_adam=True, adam_eps=1e-15, lr_level_reduce_ratio=1.0)
+    torch.manual_seed(0)
+    octree, dec = FeatureOctree(cfg), Decoder(cfg)
+    opts = StepOptions(sigma=cfg.sigma_sigmoid, loss_reduction="sum")
+    frames = list(synth.make_frames(cfg, frames=3, beams=16, azimuths=120, seed=4, device="cuda"))
+    first_loss = last_loss = None
+    for fi, (coord, label, weight) in enumerate(frames):
+        octree.update(coord[weight > 0], incremental_on=True)
+        opt = setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())  # shine_incre.py:108-109
+        octree._require_tables(with_ranks=True)
+        pool = SortedPool(octree, coord, label, weight, seed=fi)
+        touched = touched_flags(octree)
+        for it in range(15):
+            idx = pool.draw(2048)
+            loss, pred, _ = fused_train_step(octree, dec, None, None, None, opts, pool=pool, idx=idx, touched=touched)
+            reg = fused_regularization(octree, cfg.lambda_forget, touched)
+            opt.step(zero_grad=True)
+            total = float(loss) + cfg.lambda_forget * float(reg)
+            assert total == total and abs(total) < 1e12  # finite
+            if fi == 0 and it == 0:
+                first_loss = float(loss)
+            last_loss = float(loss)
+        data = type("Pool", (), {"coord_pool": coord, "sdf_label_pool": label})()
+        cal_feature_importance(data, octree, dec, cfg.sigma_sigmoid, 2048, 2, "sum")
+        assert all(float(t.abs().sum()) > 0 for t in octree.importance_weight)
+        assert all(float(t[-1].abs().max()) == 0 for t in octree.importance_weight)
+        if fi > 0:
+            assert octree._reg_grad_on == [False] * cfg.tree_level_feat  # attached-clone quirk from frame 2 on
+    assert last_loss < first_loss  # it learns
+    # the octree kept answering exactly like the reference tables would: indices of a probe batch are consistent
+    idx_lists = octree.get_indices(frames[-1][0][:512])
+    tab = octree.nodes_lookup_tables
+    from oracle import kaolin_shim as kal
+    for i, ix in enumerate(idx_lists):
+        lvl = octree.max_level - i
+        codes = kal.points_to_morton(kal.quantize_points(frames[-1][0][:512].cpu(), lvl)).tolist()
+        want = torch.tensor([tab[lvl].get(m, [-1] * 8) for m in codes])
+        assert torch.equal(ix.cpu(), want)
+
+
+def test_stale_pool_is_rejected_after_octree_growth():
+    from shine_mapping_amd import StepOptions, fused_train_step
+    from shine_mapping_amd.sampler import SortedPool
+
+    fx = load_golden("maicity_bce_L3")
+    cfg, octree, dec = product_from_golden(fx)
+    sp = SortedPool(octree, fx["coord"].cuda(), fx["sdf_label"].cuda(), fx["weight"].cuda())
+    idx = sp.draw(256)
+    fused_train_step(octree, dec, None, None, None, step_options(fx), pool=sp, idx=idx)  # fine
+    octree.update(torch.tensor([[0.31, 0.27, -0.11], [0.33, 0.27, -0.11]]))              # new nodes -> slots may move
+    with pytest.raises(RuntimeError, match="rebuild"):
+        fused_train_step(octree, dec, None, None, None, step_options(fx), pool=sp, idx=idx)
+    sp.rebuild(fx["coord"].cuda(), fx["sdf_label"].cuda(), fx["weight"].cuda())
+    fused_train_step(octree, dec, None, None, None, step_options(fx), pool=sp, idx=idx)
