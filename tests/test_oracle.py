@@ -183,3 +183,49 @@ def test_node_ranks_are_a_z_order_over_all_levels():
                 for t in range(s + 1, L):
                     sub |= (lvl == t) & ((keys >> (3 * (t - s))) == key)
                 assert not (between & ~sub).any()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_host_update_equals_oracle_update_over_random_frame_sequences(seed):
+    """FeatureOctree.update (vectorised) vs OracleOctree.update (the reference's loops restated, pinned bit-for-bit to
+    the real reference by make_golden): same node tables, same corner ids, same feature-row counts, same
+    features_last_frame refresh pattern (a level without new nodes keeps its old copy, feature_octree.py:129-130),
+    same attached/detached status of the copies (:146 vs :160) — over random multi-frame sequences."""
+    from shine_mapping_amd import FeatureOctree, synth
+
+    rng = np.random.default_rng(seed)
+    L = int(rng.integers(1, 5))
+    world = int(rng.integers(max(L, 5), 9))
+    over = dict(tree_level_world=world, tree_level_feat=L, leaf_vox_size=float(rng.choice([0.2, 0.5, 1.0])))
+    ocfg = so.make_config(**over)
+    cfg = synth.make_config("maicity", device="cpu", **over)
+    mine, ref = FeatureOctree(cfg), so.OracleOctree(ocfg)
+    incremental = bool(rng.integers(0, 2))
+    centre = rng.uniform(-0.5, 0.5, 3)
+    for frame in range(5):
+        n = int(rng.integers(1, 400))
+        spread = float(rng.choice([0.01, 0.1, 0.4]))
+        if frame == 3:  # a frame that adds nothing new: re-send old points
+            pts = prev
+        else:
+            pts = torch.from_numpy((centre + rng.normal(0, spread, (n, 3))).astype(np.float32)).clamp(-1.2, 1.2)
+        prev = pts
+        rs = torch.random.get_rng_state()
+        mine.update(pts, incremental)
+        torch.random.set_rng_state(rs)
+        ref.update(pts, incremental)
+        for s in range(L):
+            lvl = mine.free_level_num + s
+            assert mine.nodes_lookup_tables[lvl] == ref.node_table[lvl], (frame, lvl)
+            assert mine.corners_lookup_tables[lvl] == ref.corner_table[lvl], (frame, lvl)
+            assert torch.equal(mine.hier_features[s].detach(), ref.hier_features[s].detach())  # same randn stream
+            if incremental:
+                assert torch.equal(mine.features_last_frame[s].detach(), ref.features_last_frame[s].detach())
+                assert torch.equal(mine.importance_weight[s], ref.importance_weight[s])
+                assert mine.features_last_frame[s].requires_grad == ref.features_last_frame[s].requires_grad
+                assert mine._reg_grad_on[s] == (not ref.features_last_frame[s].requires_grad)
+        with torch.no_grad():  # let the parameters drift between frames so a missing refresh would show
+            for a, b in zip(mine.hier_features, ref.hier_features):
+                d = 0.01 * torch.randn_like(a)
+                a += d
+                b += d
