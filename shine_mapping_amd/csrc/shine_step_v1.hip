@@ -355,9 +355,9 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
     for (int s = 0; s < L; ++s) {  // the corner ids of every level in flight together
       const V1Level& Lv = a.lv[s];
-      const int sl = slot[s] >= 0 ? slot[s] : 0;
-      i0[s] = Lv.vals[2 * sl];
-      i1[s] = Lv.vals[2 * sl + 1];
+      const unsigned int sl = slot[s] >= 0 ? (unsigned int)slot[s] : 0u;
+      i0[s] = Lv.vals[2u * sl];
+      i1[s] = Lv.vals[2u * sl + 1u];
     }
     {
 #pragma unroll
@@ -393,8 +393,8 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             const float wz = hit ? w[c] : 0.f;
-            const long long row = hit ? (long long)ids[c] : 0;
-            const float4 r = *reinterpret_cast<const float4*>(Lv.feat + row * F + 4 * h);
+            const unsigned int off = (hit ? (unsigned int)ids[c] : 0u) * (unsigned int)F + 4u * (unsigned int)h;
+            const float4 r = *reinterpret_cast<const float4*>(Lv.feat + off);  // SGPR base + 32-bit lane offset
             f4[0] = fmaf(wz, r.x, f4[0]);
             f4[1] = fmaf(wz, r.y, f4[1]);
             f4[2] = fmaf(wz, r.z, f4[2]);
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
             for (int p2 = 0; p2 < CH; ++p2) {
               if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
-                if (rid >= 0 && !(a.ablate & 1)) atomic_add_f32(gbase + (long long)rid * F + sq, racc);
+                if (rid >= 0 && !(a.ablate & 1)) atomic_add_f32(gbase + ((unsigned int)rid * (unsigned int)F + (unsigned int)sq), racc);
                 racc = 0.f;
                 rid = idr[p2];
               }
@@ -1112,6 +1112,8 @@ extern "C" int shine_train_step_v1(const shine_tables* t, const shine_step_confi
   if (rc != SHINE_OK) return rc;
   for (int s = 0; s < cfg->n_levels; ++s) {
     if (!feats[s]) return set_error(SHINE_E_INVALID, "shine_train_step: null feature level");
+    // the kernel addresses feature/grad rows with 32-bit float offsets off an SGPR base (one VGPR per address)
+    if (ls.lv[s].rows >= (1ll << 29)) return set_error(SHINE_E_INVALID, "shine_train_step: level exceeds 2^29 rows");
     a.lv[s].keys = ls.lv[s].keys;
     a.lv[s].vals = ls.lv[s].vals;
     a.lv[s].feat = ls.lv[s].feat;
