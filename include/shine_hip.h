@@ -185,6 +185,15 @@ int shine_plan_batch(const shine_tables* t, const shine_step_config* cfg, const 
 int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,
                         void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
 
+/* ---- Mesher.query_points (utils/mesher.py:33-108): query_feature(coord, faster=True) (model/feature_octree.py:237-244,
+ *      :267-286) + Decoder.sdf (model/decoder.py:49-63) for n grid points in one launch.
+ *      sdf_out[n] f32 = (negate ? -1 : +1) * sdf   (the mesher negates, mesher.py:69,92), may be NULL;
+ *      mask_out[n] u8 = 1 iff hierarchical_indices[check_level] (BOTTOM-UP, 0 = leaf) has all 8 ids >= 0
+ *      (mesher.py:78-86, check_level = min(featured_level_num, mc_vis_level) - 1, :47), may be NULL. -------- */
+int shine_query_points(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,
+                       const float* const* feats, const int64_t* rows, const float* const* mlp, int32_t check_level,
+                       int32_t negate, float* sdf_out, uint8_t* mask_out, void* stream);
+
 /* ---- device self-test: D[32,32] = A[32,2] . B[2,32] through ONE v_mfma_f32_32x32x2_f32, written back with the
  *      accumulator lane map the fused kernel relies on (pins the MFMA operand layouts on the hardware). --- */
 int shine_selftest_mfma(const float* a, const float* b, float* d, void* stream);

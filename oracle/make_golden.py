@@ -214,6 +214,71 @@ def run_case(R, name, spec):
         os.path.getsize(path) / 1024))
 
 
+MESH_CASES = {
+    # name: source fixture, box [m], marching-cubes voxel [m], chunk size, mc_vis_level
+    "mesh_query_L3": dict(source="maicity_bce_L3", lo=(-6.0, -4.0, 0.0), hi=(6.0, 4.3, 3.0), voxel=0.17, bs=20000, vis=1),
+    "mesh_query_L4": dict(source="maicity_bce_L4", lo=(-5.0, -3.0, 0.0), hi=(5.0, 4.2, 2.5), voxel=0.23, bs=10 ** 9, vis=2),
+}
+
+
+class _Box:
+    """Duck-typed open3d AxisAlignedBoundingBox: get_query_from_bbx only reads the two corners (utils/mesher.py:124-125)."""
+
+    def __init__(self, lo, hi):
+        import numpy as np
+        self.lo, self.hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+
+    def get_min_bound(self):
+        return self.lo.copy()
+
+    def get_max_bound(self):
+        return self.hi.copy()
+
+
+def run_mesh_case(R, name, spec):
+    """The reference's Mesher.get_query_from_bbx + query_points on a fixture's map (utils/mesher.py:33-152)."""
+    import numpy as np
+
+    fx = torch.load(os.path.join(GOLDEN_DIR, spec["source"] + ".pt"), weights_only=False)
+    cfg = ref_config(R, fx["cfg"])
+    cfg.mc_vis_level = spec["vis"]
+    octree = R.FeatureOctree(cfg)
+    for s, (keys, ids) in enumerate(fx["tables"]):
+        octree.nodes_lookup_tables[octree.free_level_num + s] = dict(zip(keys.tolist(), ids.tolist()))
+    octree.hier_features = torch.nn.ParameterList([torch.nn.Parameter(f.clone()) for f in fx["features"]])
+    mlp = R.Decoder(cfg)
+    mlp.load_state_dict(fx["decoder"], strict=False)
+    mesher = R.Mesher(cfg, octree, mlp, None)
+    coord, num, origin = mesher.get_query_from_bbx(_Box(spec["lo"], spec["hi"]), spec["voxel"])
+    sdf_pred, sem_pred, mc_mask = mesher.query_points(coord, spec["bs"], True, False, True)
+    assert sem_pred is None
+
+    ocfg = so.make_config(**fx["cfg"])
+    oct2 = so.OracleOctree(ocfg)
+    for s, (keys, ids) in enumerate(fx["tables"]):
+        oct2.node_table[oct2.free_level_num + s] = dict(zip(keys.tolist(), ids.tolist()))
+    oct2.hier_features = [f.clone() for f in fx["features"]]
+    mlp2 = so.OracleDecoder(ocfg)
+    mlp2.load_state_dict(fx["decoder"])
+    c2, n2, o2 = so.grid_query_coords(spec["lo"], spec["hi"], spec["voxel"], ocfg.scale, cfg.pad_voxel)
+    assert torch.equal(coord, c2) and np.array_equal(num, n2) and np.array_equal(origin, o2), "grid restatement drifted"
+    s2, m2 = so.mesher_query_points(oct2, mlp2, c2, spec["bs"], spec["vis"])
+    assert sdf_pred.dtype == s2.dtype and np.array_equal(sdf_pred, s2), "mesher query restatement drifted (sdf)"
+    assert mc_mask.dtype == m2.dtype and np.array_equal(mc_mask, m2), "mesher query restatement drifted (mask)"
+
+    fixture = dict(name=name, source=spec["source"], lo=spec["lo"], hi=spec["hi"], voxel=spec["voxel"], bs=spec["bs"],
+                   mc_vis_level=spec["vis"], pad_voxel=cfg.pad_voxel, voxel_num_xyz=torch.from_numpy(num.astype("int64")),
+                   voxel_origin=torch.from_numpy(origin), n=int(coord.shape[0]),
+                   sdf_dtype=str(sdf_pred.dtype), mask_dtype=str(mc_mask.dtype),
+                   sdf_pred=torch.from_numpy(sdf_pred.astype("float32")),  # values are fp32 either way: lossless
+                   mc_mask=torch.from_numpy(mc_mask.astype("uint8")),
+                   provenance="reference Mesher @ /root/reference on CPU by oracle/make_golden.py, torch %s" % torch.__version__)
+    path = os.path.join(GOLDEN_DIR, name + ".pt")
+    torch.save(fixture, path)
+    print("%-18s N=%d grid=%s masked-in=%d -> %s (%.0f kB)" % (name, coord.shape[0], num.tolist(), int(mc_mask.sum()),
+                                                              os.path.relpath(path), os.path.getsize(path) / 1024))
+
+
 class SimpleDataset:
     """Duck-typed stand-in for LiDARDataset: cal_feature_importance only reads the two pools (utils/incre_learning.py:14-26)."""
 
@@ -227,8 +292,12 @@ def main():
         sys.exit("needs /root/reference (authoring container only)")
     R = ref_import.install()
     torch.set_num_threads(1)  # bit-stable reductions
-    for name, spec in CASES.items():
-        run_case(R, name, spec)
+    only_mesh = "--mesh-only" in sys.argv  # leaves the step fixtures untouched
+    if not only_mesh:
+        for name, spec in CASES.items():
+            run_case(R, name, spec)
+    for name, spec in MESH_CASES.items():
+        run_mesh_case(R, name, spec)
 
 
 if __name__ == "__main__":

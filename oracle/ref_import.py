@@ -60,7 +60,10 @@ def install():
     from utils.data_sampler import dataSampler  # noqa: E402
     from utils.incre_learning import cal_feature_importance  # noqa: E402
 
+    from utils.mesher import Mesher  # noqa: E402  (only query_points / get_query_from_bbx run; open3d/skimage are stubs)
+
     return types.SimpleNamespace(
+        Mesher=Mesher,
         FeatureOctree=FeatureOctree,
         Decoder=Decoder,
         SHINEConfig=SHINEConfig,

@@ -368,3 +368,58 @@ def sample_along_rays(points, origin, cfg, generator=None):
     label = label.reshape(S, -1).transpose(0, 1).reshape(-1)
     w = w.reshape(S, -1).transpose(0, 1).reshape(-1)
     return xyz.contiguous(), label.contiguous(), w.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# meshing query
+def grid_query_coords(min_bound, max_bound, voxel_size, scale, pad_voxel=2):
+    """Mesher.get_query_from_bbx (utils/mesher.py:110-152) for a box given by its two corners [m].
+
+    Returns (coord [N,3] f32 scaled to [-1,1], voxel_num_xyz int array, voxel_origin [m]); point order x-major
+    ([0,0,0],[0,0,1],...), one extra voxel layer below the box (:128-130)."""
+    import numpy as np
+
+    min_bound = np.asarray(min_bound, dtype=np.float64).copy()
+    max_bound = np.asarray(max_bound, dtype=np.float64)
+    num = (np.ceil((max_bound - min_bound) / voxel_size) + pad_voxel * 2).astype(np.int_)
+    origin = min_bound - pad_voxel * voxel_size
+    origin[2] -= voxel_size
+    num[2] += 1
+    x = torch.arange(int(num[0]), dtype=torch.int16)
+    y = torch.arange(int(num[1]), dtype=torch.int16)
+    z = torch.arange(int(num[2]), dtype=torch.int16)
+    x, y, z = torch.meshgrid(x, y, z, indexing="ij")
+    coord = torch.stack((x.flatten(), y.flatten(), z.flatten())).transpose(0, 1).float()
+    coord *= voxel_size
+    coord += torch.tensor(origin, dtype=torch.float32)
+    coord *= scale
+    return coord, num, origin
+
+
+def mesher_query_points(octree: OracleOctree, mlp: OracleDecoder, coord, bs, mc_vis_level=1):
+    """Mesher.query_points (utils/mesher.py:33-108) with query_sdf=True, query_sem=False, query_mask=True.
+
+    sdf_pred = -Decoder.sdf(query_feature(coord, faster=True)) (:69,:92; get_indices_fast returns what get_indices
+    returns), mc_mask = all(hierarchical_indices[check_level] >= 0, dim=1) (:78-86), chunked by bs: float64 numpy
+    buffers when more than one chunk (:43-53), the tensors' own dtype otherwise (:90-104)."""
+    import math
+
+    import numpy as np
+
+    n = coord.shape[0]
+    iter_n = math.ceil(n / bs)
+    check_level = min(octree.featured_level_num, mc_vis_level) - 1
+    with torch.no_grad():
+        if iter_n > 1:
+            sdf_pred = np.zeros(n)
+            mc_mask = np.zeros(n)
+            for i in range(iter_n):
+                head, tail = i * bs, min((i + 1) * bs, n)
+                feat = octree.query_feature(coord[head:tail])
+                sdf_pred[head:tail] = (-mlp.sdf(feat)).numpy()
+                mc_mask[head:tail] = torch.all(octree.hierarchical_indices[check_level] >= 0, dim=1).numpy()
+        else:
+            feat = octree.query_feature(coord)
+            sdf_pred = (-mlp.sdf(feat)).numpy()
+            mc_mask = torch.all(octree.hierarchical_indices[check_level] >= 0, dim=1).numpy()
+    return sdf_pred, mc_mask

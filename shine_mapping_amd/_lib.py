@@ -51,6 +51,11 @@ _SIGNATURES = {
         [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, _P,
          C.POINTER(_P), _P, _P],
     ),
+    "shine_query_points": (
+        C.c_int,
+        [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.c_int32,
+         C.c_int32, _P, _P, _P],
+    ),
     "shine_train_step": (
         C.c_int,
         [_P, C.POINTER(StepConfig), _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64),

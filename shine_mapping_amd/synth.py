@@ -40,6 +40,7 @@ def make_config(kind: str, device="cuda", **over) -> SimpleNamespace:
         feature_dim=8, feature_std=0.05, poly_int_on=True, geo_mlp_level=2, geo_mlp_hidden_dim=32,
         geo_mlp_bias_on=True, sem_mlp_level=2, sem_mlp_hidden_dim=32, sem_mlp_bias_on=True, sem_class_count=20,
         logistic_gaussian_ratio=0.55, lambda_forget=0.0, device=device, bs=4096, weight_decay=1e-7,
+        mc_vis_level=1, pad_voxel=2, dtype=torch.float32, time_conditioned=False,  # utils/config.py:140-146,27
     )
     c.__dict__.update(PRESETS[kind])
     c.__dict__.update(over)

@@ -640,3 +640,65 @@ def test_batch_training_learns_the_synthetic_map():
     near = l.abs() > 0.3 * cfg.surface_sample_range_m * cfg.scale  # skip labels too close to zero to have a sign
     agree = ((pred > 0) == (l > 0))[near].float().mean()
     assert float(agree) > 0.85, float(agree)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# meshing query: Mesher.get_query_from_bbx + query_points, utils/mesher.py:33-152
+class _Box:
+    def __init__(self, lo, hi):
+        self.lo, self.hi = lo, hi
+
+    def get_min_bound(self):
+        import numpy as np
+        return np.asarray(self.lo, dtype=np.float64)
+
+    def get_max_bound(self):
+        import numpy as np
+        return np.asarray(self.hi, dtype=np.float64)
+
+
+@pytest.mark.parametrize("name", ["mesh_query_L3", "mesh_query_L4"])
+def test_mesher_query_points_matches_reference(name):
+    import numpy as np
+    from oracle import shine_oracle as so
+    from shine_mapping_amd.mesher import Mesher
+
+    fx = load_golden(name)
+    cfg, octree, dec = product_from_golden(load_golden(fx["source"]))
+    cfg.mc_vis_level = fx["mc_vis_level"]
+    cfg.pad_voxel = fx["pad_voxel"]
+    mesher = Mesher(cfg, octree, dec.cuda(), None)
+    coord, num, origin = mesher.get_query_from_bbx(_Box(fx["lo"], fx["hi"]), fx["voxel"])
+    ref_coord, ref_num, ref_origin = so.grid_query_coords(fx["lo"], fx["hi"], fx["voxel"], cfg.scale, fx["pad_voxel"])
+    assert coord.is_cuda and torch.equal(coord.cpu(), ref_coord), "grid coordinates must be bit-identical"
+    assert np.array_equal(num, ref_num) and np.array_equal(origin, ref_origin)
+    sdf, sem, mask = mesher.query_points(coord, fx["bs"], True, False, True)
+    assert sem is None
+    assert str(sdf.dtype) == fx["sdf_dtype"]  # float64 buffers when chunked, float32 otherwise (mesher.py:43-53,90-104)
+    assert np.array_equal(mask.astype("uint8"), fx["mc_mask"].numpy()), "marching-cubes mask must be exact"
+    assert np.abs(sdf.astype("float32") - fx["sdf_pred"].numpy()).max() <= TOL
+    # options: mask only / sdf only
+    s2, _, m2 = mesher.query_points(coord, 10 ** 9, True, False, False)
+    assert m2 is None and np.abs(s2 - fx["sdf_pred"].numpy()).max() <= TOL
+    s3, _, m3 = mesher.query_points(coord, 10 ** 9, False, False, True)
+    assert s3 is None and np.array_equal(m3.astype("uint8"), fx["mc_mask"].numpy())
+
+
+def test_mesher_query_matches_forward_at_scale():
+    """2^21 grid points: the meshing kernel against the step kernel's forward (same tables, different code)."""
+    from shine_mapping_amd import forward_sdf, synth
+    from shine_mapping_amd.mesher import query_points_device
+
+    wl = synth.build_workload("maicity", frames=8, device="cuda", seed=5, tree_level_feat=4, azimuths=300)
+    octree, dec = wl.octree, wl.decoder.cuda()
+    with torch.no_grad():
+        for p in octree.hier_features:
+            p.mul_(6.0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    lo, hi = wl.pool.coord.min(0).values, wl.pool.coord.max(0).values
+    coord = lo + (hi - lo) * torch.rand((1 << 21, 3), device="cuda", generator=g)
+    out = forward_sdf(octree, dec, coord, want_indices=True)
+    for lvl in range(4):
+        sdf, mask = query_points_device(octree, dec, coord, check_level=lvl)
+        assert torch.equal(mask, (out["indices"][lvl] >= 0).all(1))
+        assert (sdf + out["pred"]).abs().max().item() <= TOL

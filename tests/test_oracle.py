@@ -229,3 +229,20 @@ def test_host_update_equals_oracle_update_over_random_frame_sequences(seed):
                 d = 0.01 * torch.randn_like(a)
                 a += d
                 b += d
+
+
+@pytest.mark.parametrize("name", ["mesh_query_L3", "mesh_query_L4"])
+def test_oracle_mesher_query_matches_reference_fixture(name):
+    """Mesher.get_query_from_bbx + query_points (utils/mesher.py:33-152) as run by the real reference."""
+    import numpy as np
+
+    fx = load_golden(name)
+    cfg, oct_, mlp = oracle_from_golden(load_golden(fx["source"]))
+    coord, num, origin = so.grid_query_coords(fx["lo"], fx["hi"], fx["voxel"], cfg.scale, fx["pad_voxel"])
+    assert coord.shape[0] == fx["n"] and np.array_equal(num, fx["voxel_num_xyz"].numpy())
+    assert np.array_equal(origin, fx["voxel_origin"].numpy())
+    sdf, mask = so.mesher_query_points(oct_, mlp, coord, fx["bs"], fx["mc_vis_level"])
+    assert str(sdf.dtype) == fx["sdf_dtype"] and str(mask.dtype) == fx["mask_dtype"]
+    assert np.array_equal(sdf.astype("float32"), fx["sdf_pred"].numpy())
+    assert np.array_equal(mask.astype("uint8"), fx["mc_mask"].numpy())
+    assert 0 < int(mask.sum()) < mask.size

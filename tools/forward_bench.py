@@ -24,3 +24,49 @@ for want_idx in (False, True):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     print("forward_sdf N=%d indices=%s: %.3f ms  %.2f G pts/s" % (n, want_idx, dt * 1e3, n / dt / 1e9))
+
+# the meshing kernel proper (csrc/shine_query.hip): reference grid order (z fastest, utils/mesher.py:139-141) and
+# the reference's per-chunk contract (sdf + marching-cubes mask), timed with HIP events on the current stream
+from shine_mapping_amd.mesher import Mesher
+
+
+class _Box:
+    def get_min_bound(self):
+        import numpy as np
+        return np.array([-20.0, -8.0, -0.5])
+
+    def get_max_bound(self):
+        import numpy as np
+        return np.array([20.0, 8.0, 5.5])
+
+
+mesher = Mesher(cfg, octree, dec, None)
+coord, num, origin = mesher.get_query_from_bbx(_Box(), 0.1)
+from shine_mapping_amd.mesher import query_points_device
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+print("  mask only (no decoder): %.3f ms;  sdf only: %.3f ms;  random order sdf+mask: %.3f ms" % (
+    timed(lambda: query_points_device(octree, dec, coord, query_sdf=False)),
+    timed(lambda: query_points_device(octree, dec, coord, query_mask=False)),
+    timed(lambda c=coord[torch.randperm(coord.shape[0], device="cuda")]: query_points_device(octree, dec, c))))
+for _ in range(3):
+    sdf, mask = query_points_device(octree, dec, coord)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    sdf, mask = query_points_device(octree, dec, coord)
+e1.record()
+torch.cuda.synchronize()
+dt = e0.elapsed_time(e1) / 10 * 1e-3
+print("shine_query_points N=%d grid=%s: %.3f ms  %.2f G pts/s  (mask-in %.1f %%)" % (
+    coord.shape[0], num.tolist(), dt * 1e3, coord.shape[0] / dt / 1e9, 100.0 * mask.float().mean().item()))
