@@ -80,6 +80,28 @@ int shine_tables_insert(shine_tables* t, int32_t slot, const int64_t* keys, cons
                         int64_t n, void* stream);
 int shine_tables_stats(const shine_tables* t, int32_t slot, int64_t* capacity, int64_t* count);
 
+/* ---- octree growth on the device: FeatureOctree.update (model/feature_octree.py:114-166), SURVEY.md §8 f-2.
+ *      points[n,3] f32 (device, scaled to [-1,1]) = the frame's surface points.  Inserts every node the frame
+ *      creates (all featured levels) with its 8 corner ids; corner ids are assigned exactly as the reference does
+ *      (new corners in lexicographic (x,y,z) order after the existing rows, :132-151).  Writes to HOST arrays
+ *      fresh_counts[L] (new nodes per level, top-down) and added_counts[L] (new feature rows per level): the caller
+ *      appends that many rows to hier_features (:139,153).  Synchronises the stream twice (it runs per frame).
+ *      The corner tables (corners_lookup_tables, :47-52) live in the handle; shine_tables_insert_corners seeds them
+ *      when nodes were inserted with shine_tables_insert (corner_keys = x<<42 | y<<21 | z at that level). ------- */
+int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, const float* points, int64_t n,
+                      int64_t* fresh_counts, int64_t* added_counts, void* stream);
+/* copy out what the last shine_tables_grow added to one level (any pointer may be NULL): node keys [fresh] in
+ * insertion (= Morton) order, their corner ids [fresh,8], the new corners' keys [added] in row-id order.
+ * Valid until the next shine_tables_grow / shine_tables_rank_nodes on this handle. */
+int shine_tables_grow_fetch(const shine_tables* t, int32_t slot, int64_t* fresh_keys, int32_t* fresh_ids,
+                            int64_t* new_corner_keys, void* stream);
+int shine_tables_insert_corners(shine_tables* t, int32_t slot, const int64_t* corner_keys, const int32_t* ids,
+                                int64_t n, void* stream);
+int shine_tables_corner_count(const shine_tables* t, int32_t slot, int64_t* count);
+/* rank every node of every featured level in one Z-order on the device (what shine_tables_set_ranks uploads when the
+ * host computes it); n_buckets_out (host, may be NULL) = nodes + 64 miss buckets. */
+int shine_tables_rank_nodes(shine_tables* t, int64_t* n_buckets_out, void* stream);
+
 /* ---- FeatureOctree.get_indices (model/feature_octree.py:199-218):
  *      idx_out[i] for i = 0..L-1 BOTTOM-UP (i = 0 leaf) each [N,8] int64, -1 on miss --------- */
 int shine_query_indices(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,

@@ -51,6 +51,12 @@ _SIGNATURES = {
         [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, _P,
          C.POINTER(_P), _P, _P],
     ),
+    "shine_tables_grow": (C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64), _P]),
+    "shine_tables_grow_fetch": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
+    "shine_tables_insert_corners": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, _P]),
+    "shine_tables_corner_count": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64)]),
+    "shine_tables_rank_nodes": (C.c_int, [_P, C.POINTER(C.c_int64), _P]),
     "shine_query_points": (
         C.c_int,
         [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.c_int32,

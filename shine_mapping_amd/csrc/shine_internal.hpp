@@ -18,6 +18,31 @@ struct TableLevel {
   unsigned int mask = 0;
 };
 
+// corners_lookup_tables[level] (model/feature_octree.py:47-52,135-152): corner (x,y,z) -> feature row id.
+// Open addressing like TableLevel; key = x<<42 | y<<21 | z (ascending = the lexicographic order of
+// torch.unique(dim=0), :132).  Only shine_tables_grow reads it (octree growth, once per frame).
+struct CornerLevel {
+  unsigned long long* keys = nullptr;
+  int* vals = nullptr;
+  long long cap = 0;
+  long long count = 0;
+  unsigned int shift = 0;
+  unsigned int mask = 0;
+};
+
+// device scratch of one shine_tables_grow call; results stay readable for shine_tables_grow_fetch
+struct GrowScratch {
+  void* a = nullptr;  // phase A: leaf keys, flags, fresh node keys
+  size_t a_bytes = 0;
+  void* b = nullptr;  // phase B/C: corner keys, new corners, ids
+  size_t b_bytes = 0;
+  long long n_fresh[SHINE_MAX_LEVELS] = {};
+  long long n_added[SHINE_MAX_LEVELS] = {};
+  unsigned long long* fresh_keys[SHINE_MAX_LEVELS] = {};  // [n_fresh] Morton order
+  int* fresh_ids[SHINE_MAX_LEVELS] = {};                  // [n_fresh][8]
+  unsigned long long* new_corners[SHINE_MAX_LEVELS] = {}; // [n_added] lexicographic = id order
+};
+
 int set_error(int code, const char* msg);
 int set_hip_error(hipError_t e, const char* what);
 
@@ -27,6 +52,8 @@ struct shine_tables {
   int n_levels = 0;
   long long n_buckets = 0;  // nodes of all featured levels + 1 ("misses everywhere"); 0: ranks not set
   shine::TableLevel lv[SHINE_MAX_LEVELS];
+  shine::CornerLevel cl[SHINE_MAX_LEVELS];
+  shine::GrowScratch grow;
 };
 
 #define SHINE_HIP_CHECK(expr)                                      \

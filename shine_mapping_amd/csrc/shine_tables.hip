@@ -119,7 +119,11 @@ extern "C" int shine_tables_destroy(shine_tables* t) {
     if (t->lv[s].keys) (void)hipFree(t->lv[s].keys);
     if (t->lv[s].vals) (void)hipFree(t->lv[s].vals);
     if (t->lv[s].ranks) (void)hipFree(t->lv[s].ranks);
+    if (t->cl[s].keys) (void)hipFree(t->cl[s].keys);
+    if (t->cl[s].vals) (void)hipFree(t->cl[s].vals);
   }
+  if (t->grow.a) (void)hipFree(t->grow.a);
+  if (t->grow.b) (void)hipFree(t->grow.b);
   delete t;
   return SHINE_OK;
 }

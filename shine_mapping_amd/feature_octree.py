@@ -140,6 +140,11 @@ class FeatureOctree(nn.Module):
         self._tables_epoch = 0  # bumped whenever nodes are added (hash slots may move): invalidates planned pools
         self._tables = None  # created at the first query (needs the GPU); update() itself is host-only
         self._pending = [[] for _ in range(L)]  # (node keys, corner ids) not yet inserted on the device
+        # device growth (shine_tables_grow): per level the (node keys, corner ids, new corner keys) device tensors of
+        # every frame, not yet merged into the host copies above (_sync_host does that when a host view is needed)
+        self._dev_log = [[] for _ in range(L)]
+        self._corners_on_device = False  # the handle's corner tables hold every corner of every level
+        self._box = None  # running (lo, hi) of the coarsest featured level's node coords, for _sort_box
         # a level's regulariser contributes gradient only while its features_last_frame copy is detached
         # (first-frame branch :146); the later branch :160 stores an attached clone -> zero net gradient.
         self._reg_grad_on = [True] * L
@@ -152,6 +157,7 @@ class FeatureOctree(nn.Module):
 
     # ------------------------------------------------------------------ dict views (compat)
     def _build_dicts(self):
+        self._sync_host()
         nodes = [dict() for _ in range(self.max_level + 1)]
         corners = [dict() for _ in range(self.max_level + 1)]
         for s in range(self.featured_level_num):
@@ -193,6 +199,7 @@ class FeatureOctree(nn.Module):
 
     # ------------------------------------------------------------------ :94-101
     def get_octree_nodes(self, level):
+        self._sync_host()
         s = level - self.free_level_num
         xyz = morton_decode(self._node_keys[s]).astype(np.float64) if 0 <= s < self.featured_level_num else \
             np.zeros((0, 3))
@@ -201,6 +208,13 @@ class FeatureOctree(nn.Module):
 
     # ------------------------------------------------------------------ :114-166
     def update(self, surface_points: torch.Tensor, incremental_on: bool = False):
+        """CUDA points grow the tree on the device (shine_tables_grow); host points take the
+        vectorised numpy path below.  Both produce the reference's tables bit for bit."""
+        if surface_points.is_cuda:
+            return self._update_device(surface_points, incremental_on)
+        self._sync_host()
+        if self._corners_on_device:  # the handle's corner tables would go stale: rebuild it from the host copies
+            self.rebuild_device_tables()
         dev = self.hier_features[0].device if len(self.hier_features) else torch.device(self.device)
         res = 2 ** self.max_level
         # kaolin quantize_points, fp32, on whatever device the points live on
@@ -239,27 +253,9 @@ class FeatureOctree(nn.Module):
             self._corner_id_of_lex[s] = merged_ids[order]
             self._corner_count[s] = base + new_lex.size
             added = int(new_lex.size)
-
-            if first:  # :135-146
-                fts = self.feature_std * torch.randn(added + 1, self.feature_dim, device=dev)
-                fts[-1] = 0.0
-                self.hier_features.append(nn.Parameter(fts))
-                if incremental_on:
-                    self.importance_weight.append(torch.zeros(added + 1, self.feature_dim, device=dev))
-                    self.features_last_frame.append(fts.clone())
-                    self._reg_grad_on[s] = True
-            else:  # :147-160
-                new_fts = self.feature_std * torch.randn(added + 1, self.feature_dim, device=dev)
-                new_fts[-1] = 0.0
-                self.hier_features[s] = nn.Parameter(torch.cat((self.hier_features[s].detach()[:-1], new_fts), 0))
-                if incremental_on:
-                    new_w = torch.zeros(added + 1, self.feature_dim, device=dev)
-                    self.importance_weight[s] = torch.cat((self.importance_weight[s][:-1], new_w), 0)
-                    # the reference clones the Parameter itself (attached to the graph, :160): the regulariser
-                    # then adds to the loss value but its gradient cancels.  Kept.
-                    self.features_last_frame[s] = self.hier_features[s].clone()
-                    self._reg_grad_on[s] = False
-
+            if s == 0:
+                self._grow_box(fresh)
+            self._append_rows(s, first, added, incremental_on, dev)
             ids = self._corner_id_of_lex[s][np.searchsorted(self._corner_lex[s], lex)].reshape(-1, 8).astype(np.int32)
             self._node_keys[s] = np.concatenate((self._node_keys[s], fresh))
             self._node_ids[s] = np.concatenate((self._node_ids[s], ids))
@@ -267,50 +263,171 @@ class FeatureOctree(nn.Module):
             self._pending[s].append((fresh, ids))  # uploaded to the device hash table at the next query
             self._tables_epoch += 1
 
-    # ------------------------------------------------------------------ hot path plumbing
-    def _require_tables(self, with_ranks=False):
-        if len(self.hier_features) != self.featured_level_num:
-            raise RuntimeError("FeatureOctree is empty: call update() before querying")
+    def _append_rows(self, s, first, added, incremental_on, dev):
+        """The feature-side half of update() for one level that received new nodes (:135-160)."""
+        if first:  # :135-146
+            fts = self.feature_std * torch.randn(added + 1, self.feature_dim, device=dev)
+            fts[-1] = 0.0
+            self.hier_features.append(nn.Parameter(fts))
+            if incremental_on:
+                self.importance_weight.append(torch.zeros(added + 1, self.feature_dim, device=dev))
+                self.features_last_frame.append(fts.clone())
+                self._reg_grad_on[s] = True
+        else:  # :147-160
+            new_fts = self.feature_std * torch.randn(added + 1, self.feature_dim, device=dev)
+            new_fts[-1] = 0.0
+            self.hier_features[s] = nn.Parameter(torch.cat((self.hier_features[s].detach()[:-1], new_fts), 0))
+            if incremental_on:
+                new_w = torch.zeros(added + 1, self.feature_dim, device=dev)
+                self.importance_weight[s] = torch.cat((self.importance_weight[s][:-1], new_w), 0)
+                # the reference clones the Parameter itself (attached to the graph, :160): the regulariser
+                # then adds to the loss value but its gradient cancels.  Kept (SURVEY §8b quirk).
+                self.features_last_frame[s] = self.hier_features[s].clone()
+                self._reg_grad_on[s] = False
+
+    def _grow_box(self, coarse_keys: np.ndarray):
+        if coarse_keys.size == 0:
+            return
+        xyz = morton_decode(coarse_keys)
+        lo, hi = xyz.min(0), xyz.max(0)
+        if self._box is not None:
+            lo, hi = np.minimum(lo, self._box[0]), np.maximum(hi, self._box[1])
+        self._box = (lo, hi)
+        self._sort_box_cache = None
+
+    # ------------------------------------------------------------------ :114-166 on the device (SURVEY.md §8 f-2)
+    def _update_device(self, surface_points: torch.Tensor, incremental_on: bool):
+        pts = surface_points.detach()
+        if pts.dtype != torch.float32 or pts.dim() != 2 or pts.shape[1] != 3:
+            raise ValueError("surface_points must be a float32 tensor of shape [M,3]")
+        pts = pts.contiguous()
+        dev = pts.device
+        L = self.featured_level_num
+        t = self._ensure_handle(dev)
+        if not self._corners_on_device:
+            self._upload_corners(dev)
+        fresh, added = (C.c_int64 * L)(), (C.c_int64 * L)()
+        cfg = _lib.StepConfig()
+        cfg.n_levels, cfg.max_level = L, self.max_level
+        lib = _lib.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.shine_tables_grow(t.handle, C.byref(cfg), pts.data_ptr(), pts.shape[0], fresh, added, stream),
+                   "shine_tables_grow")
+        grew = False
+        for s in range(L):
+            nf, na = int(fresh[s]), int(added[s])
+            if nf == 0:
+                continue  # :129-130
+            grew = True
+            keys = torch.empty(nf, dtype=torch.int64, device=dev)
+            ids = torch.empty((nf, 8), dtype=torch.int32, device=dev)
+            newc = torch.empty(na, dtype=torch.int64, device=dev)
+            _lib.check(lib.shine_tables_grow_fetch(t.handle, s, keys.data_ptr(), ids.data_ptr(), newc.data_ptr(),
+                                                   stream), "shine_tables_grow_fetch")
+            self._dev_log[s].append((keys, ids, newc))
+            first = self._corner_count[s] == 0
+            self._corner_count[s] += na
+            if s == 0:
+                self._grow_box(keys.cpu().numpy())
+            self._append_rows(s, first, na, incremental_on, dev)
+        if grew:
+            self._dict_cache = None
+            self._ranks_uploaded = False
+            self._tables_epoch += 1
+
+    def _sync_host(self):
+        """Merge what the device added (shine_tables_grow) into the host copies the dict views / pickles read."""
+        if not any(self._dev_log):
+            return
+        for s in range(self.featured_level_num):
+            if not self._dev_log[s]:
+                continue
+            keys = torch.cat([e[0] for e in self._dev_log[s]]).cpu().numpy()
+            ids = torch.cat([e[1] for e in self._dev_log[s]]).cpu().numpy()
+            newc = torch.cat([e[2] for e in self._dev_log[s]]).cpu().numpy()
+            base = self._corner_lex[s].size
+            self._node_keys[s] = np.concatenate((self._node_keys[s], keys))
+            self._node_ids[s] = np.concatenate((self._node_ids[s], ids))
+            self._node_sorted[s] = np.sort(self._node_keys[s])
+            merged = np.concatenate((self._corner_lex[s], newc))
+            merged_ids = np.concatenate((self._corner_id_of_lex[s], np.arange(base, base + newc.size, dtype=np.int64)))
+            order = np.argsort(merged, kind="stable")
+            self._corner_lex[s], self._corner_id_of_lex[s] = merged[order], merged_ids[order]
+            assert self._corner_lex[s].size == self._corner_count[s]
+            self._dev_log[s] = []
+        self._dict_cache = None
+
+    def _ensure_handle(self, dev):
+        """The library handle with every host-side node inserted (works on an empty tree too)."""
         if self._tables is None:
             self._tables = _DeviceTables(self.featured_level_num)
             self._ranks_uploaded = False
-        dev = self.hier_features[0].device
+            self._corners_on_device = False
         for s in range(self.featured_level_num):
             for keys, ids in self._pending[s]:
                 self._tables.insert(s, torch.from_numpy(keys).to(dev), torch.from_numpy(ids).to(dev))
                 self._ranks_uploaded = False
             self._pending[s] = []
+        return self._tables
+
+    def _upload_corners(self, dev):
+        """Seed the handle's corner tables from the host copies (after host-side updates / load_tables / unpickling)."""
+        lib = _lib.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for s in range(self.featured_level_num):
+            cnt = C.c_int64()
+            _lib.check(lib.shine_tables_corner_count(self._tables.handle, s, C.byref(cnt)), "shine_tables_corner_count")
+            if cnt.value:
+                raise RuntimeError("corner tables partially present: rebuild_device_tables() first")
+            if self._corner_lex[s].size == 0:
+                continue
+            keys_d = torch.from_numpy(self._corner_lex[s]).to(dev)
+            ids_d = torch.from_numpy(self._corner_id_of_lex[s].astype(np.int32)).to(dev)
+            _lib.check(lib.shine_tables_insert_corners(self._tables.handle, s, keys_d.data_ptr(), ids_d.data_ptr(),
+                                                       keys_d.numel(), stream), "shine_tables_insert_corners")
+            torch.cuda.current_stream(dev).synchronize()
+        self._corners_on_device = True
+
+    # ------------------------------------------------------------------ hot path plumbing
+    def _require_tables(self, with_ranks=False):
+        if len(self.hier_features) != self.featured_level_num:
+            raise RuntimeError("FeatureOctree is empty: call update() before querying")
+        dev = self.hier_features[0].device
+        t = self._ensure_handle(dev)
         if with_ranks and not self._ranks_uploaded:
             self._upload_ranks(dev)
-        return self._tables
+        return t
 
     def _upload_ranks(self, dev):
         """Rank every node of every featured level in ONE Z-order (a parent's own bucket right after its
-        children's) for shine_plan_batch's counting sort.  Host-side argsort, once per tree growth."""
+        children's) for shine_plan_batch / shine_sample_sorted: sorted on the device, once per tree growth."""
+        n_buckets = C.c_int64()
+        _lib.check(_lib.lib().shine_tables_rank_nodes(self._tables.handle, C.byref(n_buckets),
+                                                      torch.cuda.current_stream(dev).cuda_stream),
+                   "shine_tables_rank_nodes")
+        self._n_buckets = int(n_buckets.value)
+        self._ranks_uploaded = True
+
+    def _host_node_ranks(self):
+        """The same ranking on the host (numpy): per featured slot an int32 array aligned with _node_keys.
+        Test oracle for shine_tables_rank_nodes and feeder of shine_tables_set_ranks."""
+        self._sync_host()
         L = self.featured_level_num
-        ext, lvl = [], []
+        ext = []
         for s in range(L):
             sh = 3 * (L - 1 - s)
             k = self._node_keys[s].astype(np.int64)
             ext.append(((k << sh) | ((1 << sh) - 1)) * 8 + (L - 1 - s))  # end of the subtree range; deeper first
-            lvl.append(np.full(k.shape, s, np.int64))
-        ext_all, lvl_all = np.concatenate(ext), np.concatenate(lvl)
+        ext_all = np.concatenate(ext)
         order = np.argsort(ext_all, kind="stable")
         rank_all = np.empty(order.size, np.int32)
         rank_all[order] = np.arange(order.size, dtype=np.int32)
-        self._n_buckets = int(order.size) + 64  # + the miss buckets (shine_plan.hip MISS_BUCKETS)
-        off = 0
-        lib = _lib.lib()
-        stream = torch.cuda.current_stream().cuda_stream
+        out, off = [], 0
         for s in range(L):
             n = self._node_keys[s].size
-            keys_d = torch.from_numpy(self._node_keys[s]).to(dev)
-            ranks_d = torch.from_numpy(rank_all[off:off + n].copy()).to(dev)
-            _lib.check(lib.shine_tables_set_ranks(self._tables.handle, s, keys_d.data_ptr(), ranks_d.data_ptr(), n,
-                                                  self._n_buckets, stream), "shine_tables_set_ranks")
-            torch.cuda.current_stream().synchronize()
+            out.append(rank_all[off:off + n].copy())
             off += n
-        self._ranks_uploaded = True
+        return out
 
     def step_config(self, **kw) -> _lib.StepConfig:
         cfg = _lib.StepConfig()
@@ -327,17 +444,15 @@ class FeatureOctree(nn.Module):
         return cfg
 
     def _sort_box(self):
-        """Leaf-level voxel bounding box of the map (from the coarsest featured level's nodes, so it is cheap):
-        lets shine_morton_sort use bx+by+bz-bit keys instead of 3*tree_level_world."""
+        """Leaf-level voxel bounding box of the map (from the coarsest featured level's nodes, tracked as the tree
+        grows): lets shine_morton_sort use bx+by+bz-bit keys instead of 3*tree_level_world."""
         if self._sort_box_cache is None:
-            keys = self._node_keys[0]
-            if keys.size == 0:
+            if self._box is None:
                 self._sort_box_cache = ((0, 0, 0), (0, 0, 0))
             else:
                 shift = self.featured_level_num - 1  # coarsest featured level -> leaf voxel units
-                xyz = morton_decode(keys)
-                lo = (xyz.min(0) << shift) - (1 << shift)  # one coarse cell of margin for free-space samples
-                hi = ((xyz.max(0) + 2) << shift)
+                lo = (self._box[0] << shift) - (1 << shift)  # one coarse cell of margin for free-space samples
+                hi = ((self._box[1] + 2) << shift)
                 lo = np.maximum(lo, 0)
                 bits = tuple(min(self.max_level, max(1, int(int(e) - 1).bit_length())) for e in (hi - lo))
                 self._sort_box_cache = (tuple(int(v) for v in lo), bits)
@@ -406,10 +521,12 @@ class FeatureOctree(nn.Module):
 
     # ------------------------------------------------------------------ checkpoints (utils/tools.py:200-213 pickles the module)
     def __getstate__(self):
+        self._sync_host()
         state = self.__dict__.copy()
         state["_tables"] = None
         state["_dict_cache"] = None
         state["_pending"] = None
+        state["_dev_log"] = None
         return state
 
     def __setstate__(self, state):
@@ -417,8 +534,15 @@ class FeatureOctree(nn.Module):
         self.rebuild_device_tables()
 
     def rebuild_device_tables(self):
-        """Drop the library handle; it is re-created from the host copies at the next query
-        (after unpickling / device move)."""
+        """Drop the library handle; it is re-created from the host copies at the next query / device update
+        (after unpickling, a device move, or a host-side update that follows device-side ones)."""
+        if getattr(self, "_dev_log", None):
+            self._sync_host()
+        self._dev_log = [[] for _ in range(self.featured_level_num)]
+        self._corners_on_device = False
+        if getattr(self, "_box", None) is None:
+            self._box = None
+            self._grow_box(self._node_keys[0])
         self._tables = None
         self._ranks_uploaded = False
         self._tables_epoch = getattr(self, "_tables_epoch", 0) + 1
@@ -431,6 +555,8 @@ class FeatureOctree(nn.Module):
         self._tables = None
         self._dict_cache = None
         self._sort_box_cache = None
+        self._dev_log = [[] for _ in range(self.featured_level_num)]
+        self._box = None
         for s, (keys, ids) in enumerate(tables):
             keys_np = keys.cpu().numpy().astype(np.int64)
             ids_np = ids.cpu().numpy().astype(np.int32).reshape(-1, 8)
@@ -442,4 +568,5 @@ class FeatureOctree(nn.Module):
             self._corner_lex[s] = uniq
             self._corner_id_of_lex[s] = ids_np.reshape(-1)[first_idx].astype(np.int64)
             self._corner_count[s] = int(ids_np.max()) + 1 if ids_np.size else 0
+        self._grow_box(self._node_keys[0])
         self.rebuild_device_tables()

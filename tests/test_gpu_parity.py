@@ -702,3 +702,141 @@ def test_mesher_query_matches_forward_at_scale():
         sdf, mask = query_points_device(octree, dec, coord, check_level=lvl)
         assert torch.equal(mask, (out["indices"][lvl] >= 0).all(1))
         assert (sdf + out["pred"]).abs().max().item() <= TOL
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GPU octree growth: FeatureOctree.update on CUDA points = shine_tables_grow
+@pytest.mark.parametrize("name", ["maicity_bce_L3", "maicity_bce_L4", "kitti_eik_L3", "ncd_reg_L3", "linear_L2_nopoly"])
+def test_device_octree_build_matches_reference_tables(name):
+    """The frames the real reference built its tables from (fixture surface_points), grown on the device: the same
+    node -> corner-id tables, in the same insertion order, and queries through them hit the reference's indices."""
+    from shine_mapping_amd import FeatureOctree, synth
+
+    fx = load_golden(name)
+    cfg = synth.make_config("maicity", device="cuda", **fx["cfg"])
+    octree = FeatureOctree(cfg)
+    for sp in fx["surface_points"]:
+        octree.update(sp.cuda(), incremental_on=bool(fx["regularize"]))
+    assert any(octree._dev_log), "CUDA points must take the device path"
+    idx = octree.get_indices(fx["coord"].cuda())  # straight through the device tables, before any host sync
+    for k, r in enumerate(fx["out"]["indices"]):
+        assert torch.equal(idx[k].cpu(), r)
+    for s, (keys, ids) in enumerate(fx["tables"]):
+        lvl = octree.free_level_num + s
+        mine = octree.nodes_lookup_tables[lvl]
+        assert list(mine.keys()) == keys.tolist(), "level %d insertion order differs" % lvl
+        assert mine == dict(zip(keys.tolist(), ids.tolist())), "level %d tables differ" % lvl
+        assert octree.hier_features[s].shape == fx["features"][s].shape
+        assert torch.count_nonzero(octree.hier_features[s][-1]) == 0
+    if fx["regularize"]:
+        assert octree._reg_grad_on == [False] * cfg.tree_level_feat
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_device_update_equals_oracle_update_over_random_frame_sequences(seed):
+    """shine_tables_grow vs OracleOctree.update (the reference's loops, pinned to the real reference) over random
+    multi-frame sequences: duplicates, points outside the cube, an empty frame, a frame that adds nothing, a
+    host-side update in the middle (mixed mode), a pickle round trip."""
+    import pickle
+    import numpy as np
+    from oracle import shine_oracle as so
+    from shine_mapping_amd import FeatureOctree, synth
+
+    rng = np.random.default_rng(100 + seed)
+    L = int(rng.integers(1, 5))
+    world = int(rng.integers(max(L, 5), 10))
+    over = dict(tree_level_world=world, tree_level_feat=L, leaf_vox_size=float(rng.choice([0.2, 0.5, 1.0])))
+    ocfg = so.make_config(**over)
+    cfg = synth.make_config("maicity", device="cuda", **over)
+    mine, ref = FeatureOctree(cfg), so.OracleOctree(ocfg)
+    incremental = bool(rng.integers(0, 2))
+    centre = rng.uniform(-0.5, 0.5, 3)
+    prev = None
+    for frame in range(7):
+        n = int(rng.integers(1, 3000))
+        spread = float(rng.choice([0.01, 0.1, 0.4]))
+        if frame == 3 and prev is not None:  # adds nothing new
+            pts = prev
+        elif frame == 4:
+            pts = torch.zeros((0, 3))
+        else:
+            pts = torch.from_numpy((centre + rng.normal(0, spread, (n, 3))).astype(np.float32)).clamp(-1.2, 1.2)
+            pts = torch.cat((pts, pts[: n // 3]))  # duplicates
+        prev = pts
+        on_host = frame == 5 and seed % 2 == 0  # mixed mode: one host-side update between device-side ones
+        torch.manual_seed(1000 + frame)
+        if pts.shape[0]:
+            mine.update(pts if on_host else pts.cuda(), incremental)
+        torch.manual_seed(1000 + frame)
+        if pts.shape[0]:  # (the oracle draws its rows from the CPU generator: shapes and tables are compared)
+            ref.update(pts, incremental)
+        if frame == 2 and seed % 3 == 0:
+            mine = pickle.loads(pickle.dumps(mine))
+        for s in range(L):
+            lvl = mine.free_level_num + s
+            assert mine.nodes_lookup_tables[lvl] == ref.node_table[lvl], (frame, lvl)
+            assert list(mine.nodes_lookup_tables[lvl].keys()) == list(ref.node_table[lvl].keys()), (frame, lvl)
+            assert mine.corners_lookup_tables[lvl] == ref.corner_table[lvl], (frame, lvl)
+            if len(ref.hier_features) > s:
+                assert mine.hier_features[s].shape == ref.hier_features[s].shape
+                assert torch.count_nonzero(mine.hier_features[s][-1]) == 0
+                if incremental:
+                    assert mine.features_last_frame[s].shape == ref.features_last_frame[s].shape
+                    assert mine.importance_weight[s].shape == ref.importance_weight[s].shape
+                    assert mine.features_last_frame[s].requires_grad == ref.features_last_frame[s].requires_grad
+                    assert mine._reg_grad_on[s] == (not ref.features_last_frame[s].requires_grad)
+    # the grown tables serve queries: indices against the oracle's dict lookups
+    q = torch.from_numpy((centre + rng.normal(0, 0.2, (4000, 3))).astype(np.float32))
+    mine_idx = mine.get_indices(q.cuda())
+    ref_idx = ref.get_indices(q)
+    for a, b in zip(mine_idx, ref_idx):
+        assert torch.equal(a.cpu(), b)
+
+
+def test_device_update_draws_the_same_rows_as_host_update():
+    """Same torch seed, same frames: device-side growth appends bit-identical feature rows (same randn calls in the
+    same order) and reports the same sort box as the host path."""
+    from shine_mapping_amd import FeatureOctree, synth
+
+    fx = load_golden("ncd_reg_L3")
+    cfg = synth.make_config("maicity", device="cuda", **fx["cfg"])
+    a, b = FeatureOctree(cfg), FeatureOctree(cfg)
+    for i, sp in enumerate(fx["surface_points"]):
+        torch.manual_seed(7 + i)
+        a.update(sp, True)          # host path (CPU points), rows drawn on cuda
+        torch.manual_seed(7 + i)
+        b.update(sp.cuda(), True)   # device path
+    for s in range(cfg.tree_level_feat):
+        assert torch.equal(a.hier_features[s], b.hier_features[s])
+        assert torch.equal(a.features_last_frame[s], b.features_last_frame[s])
+    assert a._sort_box() == b._sort_box()
+
+
+def test_device_node_ranks_equal_host_ranks():
+    """shine_tables_rank_nodes (device sort) against FeatureOctree._host_node_ranks uploaded with
+    shine_tables_set_ranks: the planned order of a batch must not change."""
+    import ctypes as C
+    from shine_mapping_amd import _lib, dp, synth
+
+    wl = synth.build_workload("maicity", frames=5, device="cuda", seed=9, tree_level_feat=4, azimuths=300)
+    octree = wl.octree
+    coord, _, _ = synth.draw_batch(wl.pool, 1 << 16)
+    perm_dev, slots_dev = dp.plan_batch(octree, coord)
+    perm_dev, slots_dev = perm_dev.clone(), slots_dev.clone()
+    n_buckets = octree._n_buckets
+    ranks = octree._host_node_ranks()
+    assert n_buckets == sum(r.size for r in ranks) + 64
+    lib = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    for s in range(octree.featured_level_num):
+        k = torch.from_numpy(octree._node_keys[s]).cuda()
+        r = torch.from_numpy(ranks[s]).cuda()
+        _lib.check(lib.shine_tables_set_ranks(octree._tables.handle, s, k.data_ptr(), r.data_ptr(), k.numel(),
+                                              n_buckets, stream), "shine_tables_set_ranks")
+        torch.cuda.synchronize()
+    perm_host, slots_host = dp.plan_batch(octree, coord)
+    # the order inside a bucket comes from returning atomics (not deterministic); the bucket sequence is: every sorted
+    # position must see the same node slots on all levels
+    assert torch.equal(slots_dev, slots_host)
+    assert torch.equal(perm_dev.sort().values, perm_host.sort().values)
+    assert (slots_dev[1:, -1] != slots_dev[:-1, -1]).sum().item() > 100  # slots are in planned order, many runs

@@ -148,7 +148,7 @@ def test_oracle_bit_identical_to_live_reference():
 
 
 def test_node_ranks_are_a_z_order_over_all_levels():
-    """FeatureOctree._upload_ranks' host-side ordering (device upload mocked out): ranks are a permutation, every
+    """FeatureOctree._host_node_ranks (the host statement of shine_tables_rank_nodes): ranks are a permutation, every
     node's descendants occupy a contiguous rank range that ends right before the node's own bucket."""
     from shine_mapping_amd import FeatureOctree, synth
 
@@ -158,18 +158,11 @@ def test_node_ranks_are_a_z_order_over_all_levels():
     for sp in fx["surface_points"]:
         octree.update(sp)
     L = octree.featured_level_num
-    ext, lvl, keys = [], [], []
-    for s in range(L):
-        sh = 3 * (L - 1 - s)
-        k = octree._node_keys[s].astype(np.int64)
-        ext.append(((k << sh) | ((1 << sh) - 1)) * 8 + (L - 1 - s))
-        lvl.append(np.full(k.shape, s))
-        keys.append(k)
-    ext, lvl, keys = np.concatenate(ext), np.concatenate(lvl), np.concatenate(keys)
-    order = np.argsort(ext, kind="stable")
-    rank = np.empty(order.size, np.int64)
-    rank[order] = np.arange(order.size)
-    assert sorted(rank.tolist()) == list(range(order.size))
+    ranks = octree._host_node_ranks()
+    keys = np.concatenate([octree._node_keys[s].astype(np.int64) for s in range(L)])
+    lvl = np.concatenate([np.full(octree._node_keys[s].shape, s) for s in range(L)])
+    rank = np.concatenate(ranks).astype(np.int64)
+    assert sorted(rank.tolist()) == list(range(rank.size))
     # for every coarse node: its children (next level) have smaller ranks, contiguous up to the node itself
     for s in range(L - 1):
         for key, r in list(zip(keys[lvl == s], rank[lvl == s]))[:200]:
