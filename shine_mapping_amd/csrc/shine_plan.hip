@@ -3,8 +3,8 @@
 // dataset/lidar_dataset.py:430-450).
 //
 // Every node of every featured level has a rank in one global Z-order (a parent's own bucket sits right after
-// its children's; FeatureOctree computes the ranks on the host whenever the tree grows and uploads them with
-// shine_tables_set_ranks).  A point's bucket is the rank of the DEEPEST node that contains it (or one of the 64
+// its children's; shine_tables_rank_nodes sorts them on the device whenever the tree grows, or the caller uploads
+// them with shine_tables_set_ranks).  A point's bucket is the rank of the DEEPEST node that contains it (or one of the 64
 // trailing miss buckets if it misses at every level).  Then
 //     k_plan_count    probe all L levels once (light kernel, 8 waves/SIMD hide the dependent loads), remember the
 //                     slots, count the buckets with RETURNING atomics (the old value is the point's rank in its
