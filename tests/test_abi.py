@@ -49,3 +49,24 @@ def test_host_side_argument_errors_do_not_need_a_gpu():
     assert lib.shine_tables_stats(out, 7, ctypes.byref(cap), ctypes.byref(cnt)) == -1
     assert b"slot" in lib.shine_error_string(-1)
     assert lib.shine_tables_destroy(out) == 0
+
+
+def test_dropin_registers_the_reference_import_paths():
+    """`import shine_mapping_amd.dropin` makes `from model.feature_octree import FeatureOctree` /
+    `from model.decoder import Decoder` (shine_batch.py:13-14) resolve to this package, and nothing else."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import shine_mapping_amd.dropin as d\n"
+        "from model.feature_octree import FeatureOctree\n"
+        "from model.decoder import Decoder\n"
+        "import shine_mapping_amd as s\n"
+        "assert FeatureOctree is s.FeatureOctree and Decoder is s.Decoder\n"
+        "d.uninstall()\n"
+        "assert 'model.feature_octree' not in sys.modules\n"
+        "print('ok')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
