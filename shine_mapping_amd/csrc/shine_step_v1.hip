@@ -972,6 +972,19 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
   if (idx < PART_FLOATS) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = part;
+    if (nblocks == 256) {  // the full-chip launch: all 16 loads of this thread in flight at once (one round trip)
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = a.partials[(long long)(part + 16 * k) * PART_STRIDE + idx];
+#pragma unroll
+      for (int k = 0; k < 16; k += 4) {  // same association as the generic loop below
+        s0 += v[k];
+        s1 += v[k + 1];
+        s2 += v[k + 2];
+        s3 += v[k + 3];
+      }
+      b = nblocks;
+    }
     for (; b + 48 < nblocks; b += 64) {
       s0 += a.partials[(long long)b * PART_STRIDE + idx];
       s1 += a.partials[(long long)(b + 16) * PART_STRIDE + idx];
@@ -984,7 +997,17 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
   s_red[part][lane] = s;
   if (blockIdx.x == 0 && lane < 3) {  // loss / count / eikonal doubles ride along in block 0
     double d = 0.0;
-    for (int b = part; b < nblocks; b += 16)
+    int b = part;
+    if (nblocks == 256) {  // 16 independent loads instead of 16 dependent round trips (this was the kernel's tail)
+      double v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        v[k] = reinterpret_cast<const double*>(a.partials + (long long)(part + 16 * k) * PART_STRIDE + PART_LOSS)[lane];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) d += v[k];
+      b = nblocks;
+    }
+    for (; b < nblocks; b += 16)
       d += reinterpret_cast<const double*>(a.partials + (long long)b * PART_STRIDE + PART_LOSS)[lane];
     s_dred[part][lane] = d;
   }
