@@ -15,7 +15,7 @@ from . import _lib
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream_handle()
 
 
 def _null_ptrs(n):

@@ -80,7 +80,7 @@ def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
     n = coord.shape[0]
     cfg = octree.step_config()
     lib = _lib.lib()
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = _lib.current_stream_handle()
     wide = sum(cfg.sort_bits) > 32 or min(cfg.sort_bits) <= 0
     key = (str(coord.device), n, wide)
     ent = _WS.get(key)
@@ -112,7 +112,7 @@ def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None, _debug_va
     L = octree.featured_level_num
     cfg = octree.step_config(kernel_variant=_debug_variant)
     lib = _lib.lib()
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = _lib.current_stream_handle()
     key = ("plan", str(coord.device), n, octree._n_buckets)
     ent = _WS.get(key)
     if ent is None:

@@ -458,11 +458,21 @@ class FeatureOctree(nn.Module):
                 self._sort_box_cache = (tuple(int(v) for v in lo), bits)
         return self._sort_box_cache
 
+    def feature_list(self):
+        """hier_features as a plain list (top-down).  nn.ParameterList.__getitem__ costs ~2 us per access; the small-batch
+        loop touches the levels a dozen times per iteration.  Re-read whenever an entry was replaced."""
+        cache = self.__dict__.get("_feat_list")
+        hf = self.hier_features
+        if cache is None or len(cache) != len(hf) or any(a is not b for a, b in zip(cache, hf._parameters.values())):
+            cache = list(hf._parameters.values())
+            self.__dict__["_feat_list"] = cache
+        return cache
+
     def feature_ptrs(self):
-        return _lib.ptr_array([p.data_ptr() for p in self.hier_features])
+        return _lib.ptr_array([p.data_ptr() for p in self.feature_list()])
 
     def row_counts(self):
-        return _lib.i64_array([p.shape[0] - 1 for p in self.hier_features])
+        return _lib.i64_array([p.shape[0] - 1 for p in self.feature_list()])
 
     @staticmethod
     def _check_coord(coord):
@@ -527,6 +537,7 @@ class FeatureOctree(nn.Module):
         state["_dict_cache"] = None
         state["_pending"] = None
         state["_dev_log"] = None
+        state.pop("_feat_list", None)
         return state
 
     def __setstate__(self, state):

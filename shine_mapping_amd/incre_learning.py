@@ -22,7 +22,7 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
     batch_interval = bs * down_rate
     iter_n = math.ceil(sample_count / batch_interval)
     opts = StepOptions(sigma=float(sigma), loss_reduction=loss_reduction, decoder_grad_on=False)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = _lib.current_stream_handle()
     for p in octree.hier_features:
         if p.grad is not None:
             p.grad.zero_()

@@ -38,7 +38,7 @@ def eik_needs_count(opts) -> bool:
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream_handle()
 
 
 def _f32(t, name):
@@ -133,7 +133,7 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     pred = torch.empty(n, dtype=torch.float32, device=dev)
     gx = torch.empty((n, 3), dtype=torch.float32, device=dev) if (want_grad_x and eik) else None
     loss_parts = torch.empty(4, dtype=torch.float64, device=dev)  # overwritten by the step; set_zero is in-kernel
-    gfeat = [_dense_grad(p) if p.requires_grad else None for p in octree.hier_features]
+    gfeat = [_dense_grad(p) if p.requires_grad else None for p in octree.feature_list()]
     gmlp = [_dense_grad(p) for p in params] if dec_grad else [None] * 6
     if perm is not None and not (perm.is_cuda and perm.dtype == torch.int32 and perm.numel() == n):
         raise ValueError("perm must be a CUDA int32 tensor of N entries")
@@ -224,12 +224,11 @@ def fused_regularization(octree, lambda_forget: float, touched):
     import ctypes as _C
 
     L = octree.featured_level_num
-    dev = octree.hier_features[0].device
-    out = torch.empty(1, dtype=torch.float64, device=dev)
-    feats = [p.detach() for p in octree.hier_features]
+    out = torch.empty(1, dtype=torch.float64, device=octree.feature_list()[0].device)
+    feats = octree.feature_list()
     last = [t.detach().contiguous() for t in octree.features_last_frame]
     imp = [t.contiguous() for t in octree.importance_weight]
-    grads = [_dense_grad(p) for p in octree.hier_features]
+    grads = [_dense_grad(p) for p in feats]
     grad_on = (_C.c_int32 * L)(*[1 if g else 0 for g in octree._reg_grad_on])
     _lib.check(
         _lib.lib().shine_regularize(

@@ -69,7 +69,7 @@ class FusedAdam:
                 n, _lib.ptr_array([t[0].data_ptr() for t in ts]), _lib.ptr_array([t[0].grad.data_ptr() for t in ts]),
                 _lib.ptr_array([t[1].data_ptr() for t in ts]), _lib.ptr_array([t[2].data_ptr() for t in ts]),
                 _lib.i64_array([t[0].numel() for t in ts]), lr, wd, float(self.betas[0]), float(self.betas[1]),
-                float(self.eps), self.step_count, 1 if zero_grad else 0, torch.cuda.current_stream().cuda_stream,
+                float(self.eps), self.step_count, 1 if zero_grad else 0, _lib.current_stream_handle(),
             ),
             "shine_adam_step",
         )

@@ -38,7 +38,7 @@ class SortedPool:
         the same pass (the flat gradient bucket, i.e. opt.zero_grad())."""
         dev = self.coord.device
         lib = _lib.lib()
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.current_stream_handle()
         if self._ws is None or self._ws[1] != n:
             need = C.c_size_t(0)
             _lib.check(lib.shine_sample_sorted(self.size, n, self.seed, 0, None, None, 0, None, C.byref(need), stream),
