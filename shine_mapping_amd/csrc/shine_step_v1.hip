@@ -233,13 +233,18 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   double loss_acc = 0.0, cnt_acc = 0.0, eik_acc = 0.0;
   int run_id[LCAP];      // corner id (this lane's corner) of the node run in progress, -1: none / a run of misses
   int last_slot[LCAP];   // node (hash slot) of the previous point, wave-uniform: carries runs across tiles
-  float run_acc[LCAP], trash_acc[LCAP];
+  float run_acc[LCAP];
+  int run_hit[LCAP];     // wave-uniform: the run in progress belongs to an allocated node (else: a run of misses)
+  // trash row (index -1, model/feature_octree.py:78-81,209): all 8 corners of a missed node address it and the corner
+  // weights sum to one, so its gradient is the plain sum of df over the points that miss this level.  Lane
+  // (sc, sq) keeps the sum for level sc, feature sq; lanes with sc >= L idle.
+  float trash_sum = 0.f;
 #pragma unroll
   for (int s = 0; s < LCAP; ++s) {
     run_id[s] = -1;
     last_slot[s] = -2;
     run_acc[s] = 0.f;
-    trash_acc[s] = 0.f;
+    run_hit[s] = 0;
   }
   const int sc = lane >> 3, sq = lane & 7;  // scatter role: corner, feature
 
@@ -374,9 +379,9 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
              Z = axis_weight_rt(poly, x2, Lv.res);
         float w[8];
         corner_weights(X.t, Y.t, Z.t, w);
-        if (!valid) {
+        if (!valid || !hit) {
 #pragma unroll
-          for (int c = 0; c < 8; ++c) w[c] = 0.f;  // padding lanes contribute nothing anywhere
+          for (int c = 0; c < 8; ++c) w[c] = 0.f;  // padding lanes and misses contribute nothing to f or to the scatter
         }
         // staging for the scatter (h = 0 writes corners 0-3, h = 1 corners 4-7), point-contiguous rows
         {
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
           const int ids[8] = {i0[s].x, i0[s].y, i0[s].z, i0[s].w, i1[s].x, i1[s].y, i1[s].z, i1[s].w};
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            const float wz = hit ? w[c] : 0.f;
+            const float wz = w[c];
             const unsigned int off = (hit ? (unsigned int)ids[c] : 0u) * (unsigned int)F + 4u * (unsigned int)h;
             const float4 r = *reinterpret_cast<const float4*>(Lv.feat + off);  // SGPR base + 32-bit lane offset
             f4[0] = fmaf(wz, r.x, f4[0]);
@@ -748,12 +753,18 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
             corner_dw(X, Y, Z, 4 + c, d1);
             const float v = h == 0 ? (d0[0] * qv[0] + d0[1] * qv[1] + d0[2] * qv[2])
                                    : (d1[0] * qv[0] + d1[1] * qv[1] + d1[2] * qv[2]);
-            R2[R2_CQ + (s * 8 + 4 * h + c) * WP + pt] = sigma * v;
+            // a miss stages 0: its 8 terms would all land on the trash row, where they cancel (sum_c dw_c/dx = 0)
+            R2[R2_CQ + (s * 8 + 4 * h + c) * WP + pt] = ((hitmask[s] >> pt) & 1u) ? sigma * v : 0.f;
           }
         }
       }
       wave_lds_fence();
       constexpr int CH = EIK ? 8 : 16;  // points per chunk (register budget)
+      // this lane's trash level: the points that miss level sc (valid points only; padding lanes carry df = 0 anyway)
+      unsigned int mymiss = 0u;
+#pragma unroll
+      for (int s = 0; s < L; ++s)
+        if (sc == s) mymiss = ~hitmask[s] & validmask;
 #pragma unroll 1
       for (int ch = 0; ch < 32 / CH; ++ch) {
         float dfr[CH], jr[EIK ? CH : 1];
@@ -770,6 +781,15 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
             jr[4 * j + 1] = u.y;
             jr[4 * j + 2] = u.z;
             jr[4 * j + 3] = u.w;
+          }
+        }
+        {  // trash rows: one masked add per point, outside the per-level loop
+          const unsigned int mm = mymiss >> (CH * ch);
+#pragma unroll
+          for (int p2 = 0; p2 < CH; ++p2) {
+            // (0 - bit) is all-ones for a miss: AND keeps the float's bits or gives +0.0
+            const unsigned int keep = 0u - ((mm >> p2) & 1u);
+            trash_sum += __uint_as_float(__float_as_uint(dfr[p2]) & keep);
           }
         }
 #pragma unroll
@@ -798,26 +818,25 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
                 cqr[4 * j + 3] = c4.w;
               }
             }
-            int rid = run_id[s];
-            float racc = run_acc[s], tacc = trash_acc[s];
+            int rid = run_id[s], rhit = run_hit[s];
+            float racc = run_acc[s];
             const unsigned int cm = (chgmask[s] & validmask) >> (CH * ch), hm = hitmask[s] >> (CH * ch);
 #pragma unroll
             for (int p2 = 0; p2 < CH; ++p2) {
               if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
-                if (rid >= 0 && !(a.ablate & 1)) atomic_add_f32(gbase + ((unsigned int)rid * (unsigned int)F + (unsigned int)sq), racc);
+                if (rhit && !(a.ablate & 1))  // scalar branch: rhit comes from the wave-uniform hit mask
+                  atomic_add_f32(gbase + ((unsigned int)rid * (unsigned int)F + (unsigned int)sq), racc);
                 racc = 0.f;
                 rid = idr[p2];
+                rhit = (int)((hm >> p2) & 1u);
               }
-              float v = wr[p2] * dfr[p2];
-              if (EIK) v = fmaf(cqr[p2], jr[p2], v);
-              if (hm & (1u << p2))
-                racc += v;
-              else
-                tacc += v;  // padding lanes carry w = 0 (and q = 0)
+              // misses and padding lanes staged w = 0 (and cq = 0): they leave racc alone
+              racc = fmaf(wr[p2], dfr[p2], racc);
+              if (EIK) racc = fmaf(cqr[p2], jr[p2], racc);
             }
             run_id[s] = rid;
+            run_hit[s] = rhit;
             run_acc[s] = racc;
-            trash_acc[s] = tacc;
           }
         }
       }
@@ -830,21 +849,13 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
   for (int s = 0; s < L; ++s) {
     float* gbase = a.lv[s].grad;
-    if (gbase && run_id[s] >= 0) atomic_add_f32(gbase + (long long)run_id[s] * F + sq, run_acc[s]);
+    if (gbase && run_hit[s]) atomic_add_f32(gbase + (long long)run_id[s] * F + sq, run_acc[s]);
   }
   __syncthreads();  // every wave is done with its staging region: it now holds the wave's partial vector
   // Each wave writes its sums with plain stores into ITS OWN region (no LDS atomics: 8 waves adding into the
   // same 1377 addresses cost ~40k cycles), then the workgroup adds the 8 vectors in one pass.
   float* wvec = s_wave[wv];
-#pragma unroll
-  for (int s = 0; s < L; ++s) {
-    // trash row: sum the 8 corner lanes of each feature
-    float tsum = trash_acc[s];
-    tsum += __shfl_xor(tsum, 8, 64);
-    tsum += __shfl_xor(tsum, 16, 64);
-    tsum += __shfl_xor(tsum, 32, 64);
-    if (sc == 0) wvec[PART_TRASH + s * 8 + sq] = tsum;
-  }
+  if (sc < L) wvec[PART_TRASH + sc * 8 + sq] = trash_sum;  // lane (sc, sq) owns level sc, feature sq
   if (a.decoder_grad_on) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
