@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   for (int r = 0; r < 16; ++r) dw3c[r] = 0.f;
   float db3 = 0.f;
   double loss_acc = 0.0, cnt_acc = 0.0, eik_acc = 0.0;
-  int run_id[LCAP];      // corner id (this lane's corner) of the node run in progress, -1: none / a run of misses
+  int run_id[LCAP];      // float offset (corner row * 8 + feature) of this lane's target in the node run in progress
   int last_slot[LCAP];   // node (hash slot) of the previous point, wave-uniform: carries runs across tiles
   float run_acc[LCAP];
   int run_hit[LCAP];     // wave-uniform: the run in progress belongs to an allocated node (else: a run of misses)
@@ -820,14 +820,15 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
             }
             int rid = run_id[s], rhit = run_hit[s];
             float racc = run_acc[s];
-            const unsigned int cm = (chgmask[s] & validmask) >> (CH * ch), hm = hitmask[s] >> (CH * ch);
+            const unsigned int cm = (chgmask[s] & validmask) >> (CH * ch);
+            // (debug bit 1, "no atomics", is folded into the hit mask: no test inside the loop)
+            const unsigned int hm = (a.ablate & 1) ? 0u : hitmask[s] >> (CH * ch);
 #pragma unroll
             for (int p2 = 0; p2 < CH; ++p2) {
               if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
-                if (rhit && !(a.ablate & 1))  // scalar branch: rhit comes from the wave-uniform hit mask
-                  atomic_add_f32(gbase + ((unsigned int)rid * (unsigned int)F + (unsigned int)sq), racc);
+                if (rhit) atomic_add_f32(gbase + (unsigned int)rid, racc);  // scalar branch (wave-uniform hit mask)
                 racc = 0.f;
-                rid = idr[p2];
+                rid = (idr[p2] << 3) | sq;  // float offset of this lane's (corner row, feature)
                 rhit = (int)((hm >> p2) & 1u);
               }
               // misses and padding lanes staged w = 0 (and cq = 0): they leave racc alone
@@ -849,7 +850,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
   for (int s = 0; s < L; ++s) {
     float* gbase = a.lv[s].grad;
-    if (gbase && run_hit[s]) atomic_add_f32(gbase + (long long)run_id[s] * F + sq, run_acc[s]);
+    if (gbase && run_hit[s]) atomic_add_f32(gbase + (unsigned int)run_id[s], run_acc[s]);
   }
   __syncthreads();  // every wave is done with its staging region: it now holds the wave's partial vector
   // Each wave writes its sums with plain stores into ITS OWN region (no LDS atomics: 8 waves adding into the

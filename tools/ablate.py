@@ -87,7 +87,7 @@ lib.shine_debug_set_profile_buffer.restype = None
 nw = 4096
 buf = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
 lib.shine_debug_set_profile_buffer(buf.data_ptr())
-for variant in (0, 0x1E00):
+for variant in ([int(v, 0) for v in os.environ['SHINE_PROF_VARIANTS'].split(',')] if os.environ.get('SHINE_PROF_VARIANTS') else (0, 0x1E00)):
     buf.zero_()
     step(variant)
     torch.cuda.synchronize()
