@@ -165,6 +165,17 @@ __device__ __forceinline__ f32x16 wgrad_pass(const float* TL, const float* TR, i
   return acc;
 }
 
+// the 8 row gathers of one level for lane (pt, h): 16 B (features 4h..4h+3) of each corner row; a miss reads row 0
+__device__ __forceinline__ void issue_row_gathers(const float* feat, const int4& a0, const int4& a1, bool hit, int h,
+                                                  float4 (&dst)[8]) {
+  const int ids[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned int off = (hit ? (unsigned int)ids[c] : 0u) * (unsigned int)F + 4u * (unsigned int)h;
+    dst[c] = *reinterpret_cast<const float4*>(feat + off);  // SGPR base + 32-bit lane offset
+  }
+}
+
 template <int L, bool EIK, bool PROF>
 __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   __shared__ float s_opA[OP_TOTAL];
@@ -259,6 +270,10 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
   for (int s = 0; s < LCAP; ++s) nslot[s] = -1;
   bool nvalid = begin + pt < end;
+  // the index chain perm -> {coord, label, slots} is two dependent round trips: the index itself is fetched TWO tiles
+  // ahead (np2), so that at a tile's top only the second stage for tile t+1 is issued, with its address in hand
+  int np2 = 0;
+  if (a.perm && begin + 32 + pt < end) np2 = a.perm[begin + 32 + pt];
   if (nvalid) {
     np = a.perm ? (long long)a.perm[begin + pt] : begin + pt;
     if (a.slots) {
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
       for (int s = 0; s < LCAP; ++s) nslot[s] = -1;
       if (nvalid) {
-        np = a.perm ? (long long)a.perm[ni] : ni;
+        np = a.perm ? (long long)np2 : ni;
         if (a.slots) {
           const long long si = a.pool_mode ? np : ni;
 #pragma unroll
@@ -302,6 +317,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
         nlabel = a.label[np];
         if (EIK) nweight = a.weight[np];
       }
+      if (a.perm && ni + 32 < end) np2 = a.perm[ni + 32];
     }
 
     // ================================================================ phase 1: query (all levels)
@@ -365,6 +381,10 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
       i1[s] = Lv.vals[2u * sl + 1u];
     }
     {
+      // All 8 gathers of a level are issued before the first is consumed (issue_row_gathers).  Issuing level s+1's
+      // as well before level s is consumed (a second row buffer) spills: +6 % time on the BCE build (A/B, tools/ab_build.py).
+      float4 rowbuf[8];
+      const bool gather_on = !(a.ablate & 8);
 #pragma unroll
       for (int s = 0; s < L; ++s) {
         const V1Level& Lv = a.lv[s];
@@ -393,13 +413,12 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) U_w[(s * 8 + 4 * h + c) * WP + pt] = h == 0 ? w[c] : w[4 + c];
-        if (!(a.ablate & 8)) {
-          const int ids[8] = {i0[s].x, i0[s].y, i0[s].z, i0[s].w, i1[s].x, i1[s].y, i1[s].z, i1[s].w};
+        if (gather_on) {
+          issue_row_gathers(Lv.feat, i0[s], i1[s], hit, h, rowbuf);
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             const float wz = w[c];
-            const unsigned int off = (hit ? (unsigned int)ids[c] : 0u) * (unsigned int)F + 4u * (unsigned int)h;
-            const float4 r = *reinterpret_cast<const float4*>(Lv.feat + off);  // SGPR base + 32-bit lane offset
+            const float4 r = rowbuf[c];
             f4[0] = fmaf(wz, r.x, f4[0]);
             f4[1] = fmaf(wz, r.y, f4[1]);
             f4[2] = fmaf(wz, r.z, f4[2]);
