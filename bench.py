@@ -101,8 +101,8 @@ def cpu_baseline(args, wl, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="maicity", choices=["maicity", "kitti"])
     ap.add_argument("--points", type=int, default=0, help="points per iteration per GPU (default: 2^18 maicity, 2^20 kitti)")
     ap.add_argument("--levels", type=int, default=0, help="tree_level_feat (default: 4 for maicity per BASELINE.json config 2, 3 for kitti)")

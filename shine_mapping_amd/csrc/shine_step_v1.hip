@@ -290,6 +290,9 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   SHINE_STAMP(0)  // setup
 
   for (long long base = begin; base < end; base += 32) {
+    // the phases that ISSUE memory traffic (query, scatter) run at raised wave priority: when both waves of a SIMD are
+    // ready, the one that can put loads / atomics in flight goes first.  (A/B: -2 % on the eikonal build, BCE neutral.)
+    __builtin_amdgcn_s_setprio(2);
     const bool valid = nvalid;
     const long long p = np;
     const long long po = a.pool_mode ? base + pt : p;  // where this point's outputs go
@@ -438,6 +441,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     SHINE_STAMP(1)  // query
 
     float df4[4], J4[4] = {0.f, 0.f, 0.f, 0.f}, qv[3] = {0.f, 0.f, 0.f};
@@ -778,6 +782,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
         }
       }
       wave_lds_fence();
+      __builtin_amdgcn_s_setprio(2);
       constexpr int CH = EIK ? 8 : 16;  // points per chunk (register budget)
       // this lane's trash level: the points that miss level sc (valid points only; padding lanes carry df = 0 anyway)
       unsigned int mymiss = 0u;
@@ -862,6 +867,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
       }
       wave_lds_fence();
     }
+    __builtin_amdgcn_s_setprio(0);
     SHINE_STAMP(4)  // scatter
   }
 
