@@ -216,6 +216,18 @@ int shine_query_points(const shine_tables* t, const shine_step_config* cfg, cons
                        const float* const* feats, const int64_t* rows, const float* const* mlp, int32_t check_level,
                        int32_t negate, float* sdf_out, uint8_t* mask_out, void* stream);
 
+/* ---- graph-replayable forms of the two calls whose per-iteration scalars are otherwise baked into a captured HIP
+ *      graph: the scalars live in device memory and the kernels advance them, so ONE captured iteration
+ *      {draw, shine_train_step, [shine_regularize], Adam} can be replayed for every iteration of a frame.
+ *      stream_state: device uint64[2] = {stream id (read, then +1 by the launch), 0};  step_state: device int64[2] =
+ *      {optimiser steps taken so far (this launch performs step [0]+1 and stores it), scratch};  lr_dev: device float[n_tensors]
+ *      (step_lr_decay, utils/tools.py:135-155, becomes a small device copy outside the graph). --------------------- */
+int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t seed, uint64_t* stream_state, int32_t* idx_out,
+                            void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
+int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const float* weight_decay,
+                        float beta1, float beta2, float eps, int64_t* step_state, int32_t zero_grad, void* stream);
+
 /* ---- device self-test: D[32,32] = A[32,2] . B[2,32] through ONE v_mfma_f32_32x32x2_f32, written back with the
  *      accumulator lane map the fused kernel relies on (pins the MFMA operand layouts on the hardware). --- */
 int shine_selftest_mfma(const float* a, const float* b, float* d, void* stream);

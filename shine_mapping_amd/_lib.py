@@ -75,6 +75,11 @@ _SIGNATURES = {
         C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_int64, C.c_int32,
                   _P]),
+    "shine_adam_step_dev": (
+        C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
+                  _P, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _P, C.c_int32, _P]),
+    "shine_sample_sorted_dev": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, _P, _P, _P, C.c_size_t, _P,
+                                          C.POINTER(C.c_size_t), _P]),
     "shine_train_step_workspace_bytes": (C.c_size_t, [C.POINTER(StepConfig), C.c_int64]),
     "shine_morton_sort": (C.c_int, [C.POINTER(StepConfig), _P, C.c_int64, _P, _P, C.POINTER(C.c_size_t), _P]),
     "shine_selftest_mfma": (C.c_int, [_P, _P, _P, _P]),

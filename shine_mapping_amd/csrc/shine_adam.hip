@@ -29,9 +29,15 @@ struct AdamArgs {
   long long total4;  // float4 units over all segments
   float b1, b2, eps, bc1, bc2_sqrt;  // bc1 = 1 - b1^t ; bc2_sqrt = sqrt(1 - b2^t)
   int zero_grad;
+  // graph-replayable form (shine_adam_step_dev): step counter and learning rates live in device memory
+  long long* step_state;  // [0] = steps taken so far (k_adam_prep makes it [0]+1), [1] = the two bias corrections (floats)
+  const float* lr_dev;    // [n_seg] or null
 };
 
-__device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, const AdamArgs& a, float lr, float wd) {
+struct AdamScalars {
+  float b1, b2, eps, bc1, bc2_sqrt;
+};
+__device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, const AdamScalars& a, float lr, float wd) {
   const float gg = g + wd * p;
   m = a.b1 * m + (1.0f - a.b1) * gg;
   v = a.b2 * v + (1.0f - a.b2) * gg * gg;
@@ -39,19 +45,40 @@ __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, co
   p -= (lr / a.bc1) * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+// graph-replayable form: one thread counts the step and derives the bias corrections in double, like the host path
+// (a double pow per workgroup inside k_adam cost 100+ us)
+__global__ void k_adam_prep(long long* step_state, float b1, float b2) {
+  const long long t = step_state[0] + 1;
+  step_state[0] = t;
+  float* bc = reinterpret_cast<float*>(step_state + 1);
+  bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+  bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+
+__global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
+  __shared__ float s_lr[ADAM_MAX_SEG];
+  // (the kernel argument itself is never written: a modified by-value struct would be copied to scratch memory)
+  AdamScalars sc = {a.b1, a.b2, a.eps, a.bc1, a.bc2_sqrt};
+  if (a.step_state) {  // wave-uniform: k_adam_prep counted the step and left the two bias corrections in step_state[1]
+    const float* bc = reinterpret_cast<const float*>(a.step_state + 1);
+    sc.bc1 = bc[0];
+    sc.bc2_sqrt = bc[1];
+    if (threadIdx.x < a.n_seg) s_lr[threadIdx.x] = a.lr_dev ? a.lr_dev[threadIdx.x] : a.seg[threadIdx.x].lr;
+    __syncthreads();
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long long)gridDim.x * 256) {
     int s = 0;
     while (s + 1 < a.n_seg && i >= a.seg[s + 1].start) ++s;
     const AdamSeg& S = a.seg[s];
+    const float lr_s = a.step_state ? s_lr[s] : S.lr;
     const long long e = (i - S.start) * 4;
     if (e + 4 <= S.n && ((((size_t)S.p | (size_t)S.g | (size_t)S.m | (size_t)S.v) & 15) == 0)) {
       float4 p = *reinterpret_cast<float4*>(S.p + e), g = *reinterpret_cast<float4*>(S.g + e),
              m = *reinterpret_cast<float4*>(S.m + e), v = *reinterpret_cast<float4*>(S.v + e);
-      adam1(p.x, g.x, m.x, v.x, a, S.lr, S.wd);
-      adam1(p.y, g.y, m.y, v.y, a, S.lr, S.wd);
-      adam1(p.z, g.z, m.z, v.z, a, S.lr, S.wd);
-      adam1(p.w, g.w, m.w, v.w, a, S.lr, S.wd);
+      adam1(p.x, g.x, m.x, v.x, sc, lr_s, S.wd);
+      adam1(p.y, g.y, m.y, v.y, sc, lr_s, S.wd);
+      adam1(p.z, g.z, m.z, v.z, sc, lr_s, S.wd);
+      adam1(p.w, g.w, m.w, v.w, sc, lr_s, S.wd);
       *reinterpret_cast<float4*>(S.p + e) = p;
       *reinterpret_cast<float4*>(S.m + e) = m;
       *reinterpret_cast<float4*>(S.v + e) = v;
@@ -59,7 +86,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     } else {
       for (long long k = e; k < S.n && k < e + 4; ++k) {
         float p = S.p[k], g = S.g[k], m = S.m[k], v = S.v[k];
-        adam1(p, g, m, v, a, S.lr, S.wd);
+        adam1(p, g, m, v, sc, lr_s, S.wd);
         S.p[k] = p;
         S.m[k] = m;
         S.v[k] = v;
@@ -73,12 +100,12 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
 
 using namespace shine;
 
-extern "C" int shine_adam_step(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
-                               float* const* exp_avg_sq, const int64_t* numel, const float* lr,
-                               const float* weight_decay, float beta1, float beta2, float eps, int64_t step,
-                               int32_t zero_grad, void* stream) {
-  if (n_tensors < 1 || n_tensors > ADAM_MAX_SEG || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr ||
-      !weight_decay || step < 1)
+static int adam_impl(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                     float* const* exp_avg_sq, const int64_t* numel, const float* lr, const float* lr_dev,
+                     const float* weight_decay, float beta1, float beta2, float eps, int64_t step, long long* step_state,
+                     int32_t zero_grad, void* stream) {
+  if (n_tensors < 1 || n_tensors > ADAM_MAX_SEG || !params || !grads || !exp_avg || !exp_avg_sq || !numel ||
+      (!lr && !lr_dev) || !weight_decay || (step < 1 && !step_state))
     return set_error(SHINE_E_INVALID, "shine_adam_step: bad argument");
   AdamArgs a = {};
   long long start = 0;
@@ -91,7 +118,7 @@ extern "C" int shine_adam_step(int32_t n_tensors, float* const* params, float* c
     a.seg[s].v = exp_avg_sq[s];
     a.seg[s].n = numel[s];
     a.seg[s].start = start;
-    a.seg[s].lr = lr[s];
+    a.seg[s].lr = lr ? lr[s] : 0.f;
     a.seg[s].wd = weight_decay[s];
     start += (numel[s] + 3) / 4;
   }
@@ -100,13 +127,33 @@ extern "C" int shine_adam_step(int32_t n_tensors, float* const* params, float* c
   a.b1 = beta1;
   a.b2 = beta2;
   a.eps = eps;
-  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.bc1 = step_state ? 1.f : (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2_sqrt = step_state ? 1.f : (float)sqrt(1.0 - pow((double)beta2, (double)step));
   a.zero_grad = zero_grad;
+  a.step_state = step_state;
+  a.lr_dev = lr_dev;
   if (start == 0) return SHINE_OK;
   long long blocks = (start + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  if (step_state) hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, beta1, beta2);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
+}
+
+extern "C" int shine_adam_step(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int64_t* numel, const float* lr,
+                               const float* weight_decay, float beta1, float beta2, float eps, int64_t step,
+                               int32_t zero_grad, void* stream) {
+  return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr, nullptr, weight_decay, beta1, beta2, eps, step,
+                   nullptr, zero_grad, stream);
+}
+
+extern "C" int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                                   float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev,
+                                   const float* weight_decay, float beta1, float beta2, float eps, int64_t* step_state,
+                                   int32_t zero_grad, void* stream) {
+  if (!lr_dev || !step_state) return set_error(SHINE_E_INVALID, "shine_adam_step_dev: null lr_dev/step_state");
+  return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, nullptr, lr_dev, weight_decay, beta1, beta2, eps, 0,
+                   (long long*)step_state, zero_grad, stream);
 }

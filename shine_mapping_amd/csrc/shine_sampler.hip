@@ -38,9 +38,12 @@ __device__ __forceinline__ double block_sum_256(double v, double* s_red) {
   return t;
 }
 
+// stream_dev != nullptr: the stream id is read from device memory (graph-replayable form, shine_sample_sorted_dev)
 __global__ __launch_bounds__(256) void k_sample_pass1(double* block_sum, long long n1, unsigned long long seed,
-                                                      unsigned long long stream, float4* zero_ptr, long long zero_n16) {
+                                                      unsigned long long stream, const unsigned long long* stream_dev,
+                                                      float4* zero_ptr, long long zero_n16) {
   __shared__ double s_red[4];
+  if (stream_dev) stream = stream_dev[0];
   const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
   // ride-along clear of the gradient bucket (opt.zero_grad for the fused step), as in shine_plan_batch
   for (long long z = g; z < zero_n16; z += (long long)gridDim.x * 256) zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -54,9 +57,11 @@ __global__ __launch_bounds__(256) void k_sample_pass1(double* block_sum, long lo
 }
 
 __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, int nblocks, long long n, long long pool,
-                                                      unsigned long long seed, unsigned long long stream, int* idx) {
+                                                      unsigned long long seed, unsigned long long stream,
+                                                      unsigned long long* stream_dev, int* idx) {
   __shared__ double s_red[4];
   __shared__ double s_wave_pre[4];
+  if (stream_dev) stream = stream_dev[0];
   // prefix of the blocks in front of this one, and the grand total (nblocks is a few hundred)
   double before = 0.0, total = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 256) {
@@ -94,6 +99,17 @@ __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, i
       idx[k0 + j] = (int)(v < 0 ? 0 : (v >= pool ? pool - 1 : v));
     }
   }
+  if (stream_dev) {  // the last block to finish advances the stream for the next replay (every block has read it by then)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(&stream_dev[1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
+        stream_dev[1] = 0ull;
+        __threadfence();
+        atomicAdd(&stream_dev[0], 1ull);
+      }
+    }
+  }
 }
 
 static size_t align256s(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -102,9 +118,9 @@ static size_t align256s(size_t v) { return (v + 255) & ~(size_t)255; }
 
 using namespace shine;
 
-extern "C" int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,
-                                   void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes,
-                                   void* stream) {
+static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id,
+                              unsigned long long* stream_dev, int32_t* idx_out, void* zero_ptr, size_t zero_bytes,
+                              void* workspace, size_t* workspace_bytes, void* stream) {
   if (!workspace_bytes || n < 0 || pool_size < 1 || pool_size > 0x7fffffffll)
     return set_error(SHINE_E_INVALID, "shine_sample_sorted: bad argument");
   hipStream_t st = (hipStream_t)stream;
@@ -125,10 +141,27 @@ extern "C" int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, 
   if (!idx_out) return set_error(SHINE_E_INVALID, "shine_sample_sorted: null output");
   double* bs = (double*)workspace;
   hipLaunchKernelGGL(k_sample_pass1, dim3((unsigned)nblocks), dim3(256), 0, st, bs, n1, (unsigned long long)seed,
-                     (unsigned long long)stream_id, (float4*)zero_ptr, zero_ptr ? (long long)(zero_bytes / 16) : 0ll);
+                     (unsigned long long)stream_id, (const unsigned long long*)stream_dev, (float4*)zero_ptr,
+                     zero_ptr ? (long long)(zero_bytes / 16) : 0ll);
   SHINE_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_sample_pass2, dim3((unsigned)nblocks), dim3(256), 0, st, bs, (int)nblocks, (long long)n,
-                     (long long)pool_size, (unsigned long long)seed, (unsigned long long)stream_id, (int*)idx_out);
+                     (long long)pool_size, (unsigned long long)seed, (unsigned long long)stream_id, stream_dev,
+                     (int*)idx_out);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
+}
+
+extern "C" int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,
+                                   void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes,
+                                   void* stream) {
+  return sample_sorted_impl(pool_size, n, seed, stream_id, nullptr, idx_out, zero_ptr, zero_bytes, workspace,
+                            workspace_bytes, stream);
+}
+
+extern "C" int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t seed, uint64_t* stream_state,
+                                       int32_t* idx_out, void* zero_ptr, size_t zero_bytes, void* workspace,
+                                       size_t* workspace_bytes, void* stream) {
+  if (workspace && !stream_state) return set_error(SHINE_E_INVALID, "shine_sample_sorted_dev: null stream_state");
+  return sample_sorted_impl(pool_size, n, seed, 0, (unsigned long long*)stream_state, idx_out, zero_ptr, zero_bytes,
+                            workspace, workspace_bytes, stream);
 }

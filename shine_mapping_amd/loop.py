@@ -1,0 +1,56 @@
+"""GraphedIteration — one training iteration captured in a HIP graph and replayed (launch-bound inner loops belong in
+hipGraphs).
+
+The reference's inner loop (shine_batch.py:105-210, shine_incre.py:114-181) at its own batch size (4096) is bound by the
+host: ~7 kernel launches per iteration at ~100 us of Python/driver time against ~75 us of GPU time.  This helper captures
+
+    idx = pool.draw(n)                                       sorted batch from the node-ordered pool
+    loss = fused_train_step(..., pool=pool, idx=idx)          query + decode + loss + backward
+    [reg = fused_regularization(...)]                         incremental mapping only
+    opt.step(zero_grad=True)                                  fused dense Adam, also clears the grads
+
+once and replays it.  The scalars that change per iteration — the sampler's stream id and Adam's step count — live in
+device memory and are advanced by the kernels themselves (shine_sample_sorted_dev / shine_adam_step_dev), so every
+replay draws a fresh batch and applies the right bias correction.  Learning-rate decay stays outside the graph
+(`opt.sync_lr()` after changing `param_groups`).  Re-create after `octree.update()` (parameters are re-allocated, like
+the optimiser itself, shine_incre.py:108-109).
+"""
+import torch
+
+from .ops import StepOptions, fused_regularization, fused_train_step, touched_flags
+
+
+class GraphedIteration:
+    def __init__(self, octree, decoder, pool, opt, opts: StepOptions, n: int, lambda_forget: float = 0.0):
+        self.octree, self.decoder, self.pool, self.opt, self.opts, self.n = octree, decoder, pool, opt, opts, int(n)
+        self.lambda_forget = float(lambda_forget)
+        self.regularize = self.lambda_forget != 0.0
+        self.touched = touched_flags(octree) if self.regularize else None
+        self._epoch = octree._tables_epoch
+        self._idx = torch.empty(self.n, dtype=torch.int32, device=pool.coord.device)
+        self._nsurf = torch.zeros((), dtype=torch.int64, device=pool.coord.device)
+        self.loss = self.reg = None
+        self._body()  # eager warm-up: allocates workspaces, optimiser state and device counters outside the capture
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.reg = self._body()
+
+    def _body(self):
+        idx = self.pool.draw(self.n, out=self._idx, graph_safe=True)
+        n_surf = None
+        if self.opts.ekional_loss_on:
+            self._nsurf.copy_((self.pool.weight[idx.long()] > 0).sum())
+            n_surf = self._nsurf
+        loss, _, _ = fused_train_step(self.octree, self.decoder, None, None, None, self.opts, n_surf=n_surf, pool=self.pool,
+                                      idx=idx, touched=self.touched)
+        reg = fused_regularization(self.octree, self.lambda_forget, self.touched) if self.regularize else None
+        self.opt.step(zero_grad=True, graph_safe=True)
+        return loss, reg
+
+    def __call__(self):
+        """Run one iteration; returns the loss of the fused terms as a 0-dim device tensor (no host sync)."""
+        if self.octree._tables_epoch != self._epoch:
+            raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
+        self.graph.replay()
+        return self.loss

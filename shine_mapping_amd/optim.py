@@ -26,6 +26,7 @@ class FusedAdam:
         self.eps = eps
         self.step_count = 0
         self.state = {}
+        self._dev = None  # (step_state int64[2], lr float[n]) for graph-replayable steps
 
     def _tensors(self):
         out = []
@@ -50,13 +51,50 @@ class FusedAdam:
                     else:
                         p.grad.zero_()
 
+    def sync_lr(self):
+        """Graph-replayable mode: push the param_groups' learning rates to the device copy the captured step reads
+        (call after step_lr_decay, utils/tools.py:135-155; outside the graph)."""
+        if self._dev is not None:
+            ts = self._tensors()
+            self._dev[1].copy_(torch.tensor([t[3] for t in ts], dtype=torch.float32), non_blocking=False)
+
+    def steps_taken(self) -> int:
+        """Optimiser steps so far (host counter, or the device counter once graph-replayable steps were used)."""
+        return int(self._dev[0][0].item()) if self._dev is not None else self.step_count
+
     @torch.no_grad()
-    def step(self, zero_grad=False):
+    def step(self, zero_grad=False, graph_safe=False):
+        """`graph_safe`: step counter and learning rates are read from device memory (shine_adam_step_dev), so a captured
+        HIP graph of this call performs step t, t+1, ... on successive replays.  Do not mix with eager steps afterwards
+        without reading steps_taken()."""
         ts = self._tensors()
         if not ts:
             return
-        self.step_count += 1
         n = len(ts)
+        if graph_safe:
+            dev = ts[0][0].device
+            if self._dev is None or self._dev[1].numel() != n:
+                self._dev = (torch.tensor([self.step_count, 0], dtype=torch.int64, device=dev),
+                             torch.tensor([t[3] for t in ts], dtype=torch.float32, device=dev))
+            for p, m, v, _, _ in ts:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                    raise ValueError("FusedAdam needs contiguous CUDA float32 parameters and grads")
+            wd = (C.c_float * n)(*[t[4] for t in ts])
+            _lib.check(
+                _lib.lib().shine_adam_step_dev(
+                    n, _lib.ptr_array([t[0].data_ptr() for t in ts]), _lib.ptr_array([t[0].grad.data_ptr() for t in ts]),
+                    _lib.ptr_array([t[1].data_ptr() for t in ts]), _lib.ptr_array([t[2].data_ptr() for t in ts]),
+                    _lib.i64_array([t[0].numel() for t in ts]), self._dev[1].data_ptr(), wd, float(self.betas[0]),
+                    float(self.betas[1]), float(self.eps), self._dev[0].data_ptr(), 1 if zero_grad else 0,
+                    _lib.current_stream_handle(),
+                ),
+                "shine_adam_step_dev",
+            )
+            return
+        if self._dev is not None:  # continue the count a graph advanced on the device
+            self.step_count = self.steps_taken()
+            self._dev = None
+        self.step_count += 1
         if n > 16:
             raise NotImplementedError("FusedAdam handles up to 16 tensors (decoder 6 + feature levels)")
         for p, m, v, _, _ in ts:

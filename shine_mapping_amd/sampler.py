@@ -21,6 +21,7 @@ class SortedPool:
         self.seed = int(seed)
         self.draws = 0
         self._ws = None
+        self._stream_state = None  # device uint64[2] for graph-replayable draws (loop.GraphedIteration)
         self.rebuild(coord, sdf_label, weight)
 
     def rebuild(self, coord, sdf_label, weight):
@@ -33,9 +34,10 @@ class SortedPool:
         self.size = int(coord.shape[0])
         self.tables_epoch = self.octree._tables_epoch
 
-    def draw(self, n, out=None, zero=None):
+    def draw(self, n, out=None, zero=None, graph_safe=False):
         """n sorted i.i.d. uniform sample indices (int32, device).  `zero`: optional contiguous float tensor cleared in
-        the same pass (the flat gradient bucket, i.e. opt.zero_grad())."""
+        the same pass (the flat gradient bucket, i.e. opt.zero_grad()).  `graph_safe`: the stream id is read from (and
+        advanced in) device memory, so a captured HIP graph of this call draws a fresh batch at every replay."""
         dev = self.coord.device
         lib = _lib.lib()
         stream = _lib.current_stream_handle()
@@ -46,6 +48,15 @@ class SortedPool:
             self._ws = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev), n, int(need.value))
         idx = out if out is not None else torch.empty(n, dtype=torch.int32, device=dev)
         need = C.c_size_t(self._ws[2])
+        if graph_safe:
+            if self._stream_state is None:
+                self._stream_state = torch.tensor([self.draws, 0], dtype=torch.int64, device=dev)
+            _lib.check(lib.shine_sample_sorted_dev(self.size, n, self.seed, self._stream_state.data_ptr(), idx.data_ptr(),
+                                                   zero.data_ptr() if zero is not None else None,
+                                                   zero.numel() * zero.element_size() if zero is not None else 0,
+                                                   self._ws[0].data_ptr(), C.byref(need), stream),
+                       "shine_sample_sorted_dev")
+            return idx
         _lib.check(lib.shine_sample_sorted(self.size, n, self.seed, self.draws, idx.data_ptr(),
                                            zero.data_ptr() if zero is not None else None,
                                            zero.numel() * zero.element_size() if zero is not None else 0,

@@ -840,3 +840,75 @@ def test_device_node_ranks_equal_host_ranks():
     assert torch.equal(slots_dev, slots_host)
     assert torch.equal(perm_dev.sort().values, perm_host.sort().values)
     assert (slots_dev[1:, -1] != slots_dev[:-1, -1]).sum().item() > 100  # slots are in planned order, many runs
+
+
+# ---------------------------------------------------------------------------------------------------------
+# graph-replayable iteration (loop.GraphedIteration): device-resident sampler stream id and Adam step count
+@pytest.mark.parametrize("mode", ["bce", "incremental"])
+def test_graphed_iteration_matches_eager_loop(mode):
+    """K iterations through ONE captured HIP graph == K eager iterations: same batches (the stream id advances on the
+    device), same Adam bias corrections (the step count advances on the device), same parameters."""
+    from shine_mapping_amd import StepOptions, fused_train_step, synth
+    from shine_mapping_amd.loop import GraphedIteration
+    from shine_mapping_amd.ops import fused_regularization, touched_flags
+    from shine_mapping_amd.optim import setup_optimizer
+    from shine_mapping_amd.sampler import SortedPool
+
+    incremental = mode == "incremental"
+    K, N = 12, 4096
+
+    def make():
+        fx = load_golden("ncd_reg_L3" if incremental else "maicity_bce_L3")
+        cfg, octree, dec = product_from_golden(fx)
+        dec = dec.cuda()
+        cfg.lr, cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio, cfg.weight_decay = 0.01, True, 1e-15, 1.0, 1e-7
+        if incremental:
+            octree._reg_grad_on = [True] * cfg.tree_level_feat  # exercise the regulariser's gradient path too
+        opt = setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())
+        octree._require_tables(with_ranks=True)
+        pool = SortedPool(octree, fx["coord"].cuda().repeat(8, 1), fx["sdf_label"].cuda().repeat(8),
+                          fx["weight"].cuda().repeat(8), seed=5)
+        opts = StepOptions(sigma=fx["sigma"], loss_reduction="sum" if incremental else "mean")
+        return cfg, octree, dec, opt, pool, opts
+
+    # eager reference loop (host-side stream ids 0..K-1, host-side step count)
+    cfg, octree, dec, opt, pool, opts = make()
+    touched = touched_flags(octree) if incremental else None
+    eager_idx = []
+    for it in range(K):
+        idx = pool.draw(N)
+        eager_idx.append(idx.clone())
+        fused_train_step(octree, dec, None, None, None, opts, pool=pool, idx=idx, touched=touched)
+        if incremental:
+            fused_regularization(octree, 1e3, touched)
+        opt.step(zero_grad=True)
+    eager_feats = [p.detach().clone() for p in octree.hier_features]
+    eager_mlp = [p.detach().clone() for p in dec.fused_params()]
+
+    # the same K iterations: 1 eager inside the constructor + K-1 replays of the captured graph
+    cfg, octree2, dec2, opt2, pool2, opts2 = make()
+    step = GraphedIteration(octree2, dec2, pool2, opt2, opts2, N, lambda_forget=1e3 if incremental else 0.0)
+    assert torch.equal(step._idx, eager_idx[0])
+    seen = []
+    for it in range(1, K):
+        loss = step()
+        seen.append(step._idx.clone())
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(seen, eager_idx[1:])), "replays must draw the eager loop's batches"
+    assert not torch.equal(seen[0], seen[1])
+    assert opt2.steps_taken() == K and float(loss) == float(loss)
+    # Parameters are NOT compared element-wise: Adam's first steps move an element by lr * sign(g), and for elements whose
+    # gradient is a near-cancelling sum the sign is decided by the order of the atomics — two runs of the SAME eager loop
+    # differ by 0.1 of max-abs after one step (the reference on CUDA has the same property).  What must agree: the
+    # well-conditioned decoder weights and the loss both models reach on a common probe batch.
+    for a, b in zip(eager_mlp, dec2.fused_params()):
+        assert rel_err(b.detach(), a) <= 5e-2
+    probe = eager_idx[0]
+    opts_probe = StepOptions(sigma=opts.sigma, loss_reduction=opts.loss_reduction)
+    l1, _, _ = fused_train_step(octree, dec, None, None, None, opts_probe, pool=pool, idx=probe)
+    l2, _, _ = fused_train_step(octree2, dec2, None, None, None, opts_probe, pool=pool2, idx=probe)
+    assert abs(float(l1) - float(l2)) <= 0.05 * abs(float(l1))
+    # growth invalidates the captured pointers
+    octree2.update(torch.tensor([[0.31, 0.27, -0.11], [0.33, 0.27, -0.11]]).cuda())
+    with pytest.raises(RuntimeError, match="GraphedIteration"):
+        step()

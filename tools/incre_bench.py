@@ -25,6 +25,7 @@ ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--bs", type=int, default=4096)
 ap.add_argument("--oracle", type=int, default=0)
 ap.add_argument("--freeze-after", type=int, default=20)
+ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per iteration (loop.GraphedIteration)")
 args = ap.parse_args()
 
 cfg = synth.make_config("ncd", device="cuda", lr=0.01, opt_adam=True, adam_eps=1e-15, lr_level_reduce_ratio=1.0)
@@ -56,7 +57,12 @@ def run():
         pool = SortedPool(octree, coord, label, weight, seed=fi)
         touched = touched_flags(octree)
         t2 = sync()
-        for it in range(args.iters):
+        if args.graph:
+            from shine_mapping_amd.loop import GraphedIteration
+            step = GraphedIteration(octree, dec, pool, opt, opts, args.bs, lambda_forget=cfg.lambda_forget)  # = iteration 1
+            for it in range(args.iters - 1):
+                loss = step()
+        for it in range(0 if args.graph else args.iters):
             idx = pool.draw(args.bs)
             loss, pred, _ = fused_train_step(octree, dec, None, None, None, opts, pool=pool, idx=idx, touched=touched)
             reg = fused_regularization(octree, cfg.lambda_forget, touched)
