@@ -410,11 +410,15 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(levels, points, bool(cfg.ekional_loss_on)), "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_point": bpp,
+                # also against the measured copy bandwidth, and the compulsory traffic of one launch
+                # (every feature row read once + its gradient row written once + the batch in/out)
+                "frac_of_measured_copy_6290GBs": achieved / 6290.0,
+                "compulsory_bytes": int(sum(int(p.shape[0]) for p in octree.hier_features) * 32 * 2 + 24 * points),
             },
             "final_loss": float(loss),
             "iteration_with_fused_adam": None if iter_ms is None else {
                 "ms_per_iteration": iter_ms, "samples_per_s": points / (iter_ms * 1e-3), "launch": "eager",
-                "what": "plan + fused step + fused dense Adam (also clears grads); reference timing(s)/total"},
+                "what": "sorted draw (or plan) + fused step + fused dense Adam (also clears grads); reference timing(s)/total"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, wl)
