@@ -228,6 +228,12 @@ int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* g
                         float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const float* weight_decay,
                         float beta1, float beta2, float eps, int64_t* step_state, int32_t zero_grad, void* stream);
 
+/* ---- measurement aid (tools/ablate.py): per-wave phase cycle counters of the fused kernel.  buffer = device
+ *      int64 [waves][8] (setup, query, decoder forward, loss+backward, scatter, weight grads, flush, block wait) that
+ *      the next 4-level shine_train_step launches fill through s_memtime stamps; NULL switches it off again.
+ *      The stamped build is a separate template instantiation: the product kernel carries no profiling code. -------- */
+void shine_debug_set_profile_buffer(int64_t* buffer);
+
 /* ---- device self-test: D[32,32] = A[32,2] . B[2,32] through ONE v_mfma_f32_32x32x2_f32, written back with the
  *      accumulator lane map the fused kernel relies on (pins the MFMA operand layouts on the hardware). --- */
 int shine_selftest_mfma(const float* a, const float* b, float* d, void* stream);

@@ -1144,8 +1144,8 @@ extern "C" size_t shine_train_step_workspace_bytes(const shine_step_config* cfg,
 }
 
 static long long* g_prof_buffer = nullptr;
-// debug hook (not part of the public ABI): per-wave phase cycle counters, [waves][8] int64, or NULL to disable
-extern "C" void shine_debug_set_profile_buffer(long long* p) { g_prof_buffer = p; }
+// measurement aid (include/shine_hip.h): per-wave phase cycle counters, [waves][8] int64, or NULL to disable
+extern "C" void shine_debug_set_profile_buffer(int64_t* p) { g_prof_buffer = reinterpret_cast<long long*>(p); }
 
 extern "C" int shine_selftest_mfma(const float* a, const float* b, float* d, void* stream) {
   if (!a || !b || !d) return set_error(SHINE_E_INVALID, "shine_selftest_mfma: null argument");

@@ -82,8 +82,6 @@ for name, v in rows:
 import ctypes
 from shine_mapping_amd import _lib
 lib = _lib.lib()
-lib.shine_debug_set_profile_buffer.argtypes = [ctypes.c_void_p]
-lib.shine_debug_set_profile_buffer.restype = None
 nw = 4096
 buf = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
 lib.shine_debug_set_profile_buffer(buf.data_ptr())
