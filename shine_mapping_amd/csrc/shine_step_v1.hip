@@ -165,6 +165,29 @@ __device__ __forceinline__ f32x16 wgrad_pass(const float* TL, const float* TR, i
   return acc;
 }
 
+// software prefetch of the next tile's {index -> coord, label, weight, slots}; the index itself comes two tiles ahead
+#define SHINE_PREFETCH_NEXT_TILE() \
+    { \
+      const long long ni = base + 32 + pt; \
+      nvalid = ni < end; \
+      np = 0; \
+      nx0 = nx1 = nx2 = nlabel = nweight = 0.f; \
+      _Pragma("unroll") for (int s = 0; s < LCAP; ++s) nslot[s] = -1; \
+      if (nvalid) { \
+        np = a.perm ? (long long)np2 : ni; \
+        if (a.slots) { \
+          const long long si = a.pool_mode ? np : ni; \
+          _Pragma("unroll") for (int s = 0; s < L; ++s) nslot[s] = a.slots[si * L + s]; \
+        } \
+        nx0 = a.coord[3 * np]; \
+        nx1 = a.coord[3 * np + 1]; \
+        nx2 = a.coord[3 * np + 2]; \
+        nlabel = a.label[np]; \
+        if (EIK) nweight = a.weight[np]; \
+      } \
+      if (a.perm && ni + 32 < end) np2 = a.perm[ni + 32]; \
+    }
+
 // the 8 row gathers of one level for lane (pt, h): 16 B (features 4h..4h+3) of each corner row; a miss reads row 0
 __device__ __forceinline__ void issue_row_gathers(const float* feat, const int4& a0, const int4& a1, bool hit, int h,
                                                   float4 (&dst)[8]) {
@@ -300,29 +323,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
     int pslot[LCAP];
 #pragma unroll
     for (int s = 0; s < LCAP; ++s) pslot[s] = nslot[s];
-    {
-      const long long ni = base + 32 + pt;
-      nvalid = ni < end;
-      np = 0;
-      nx0 = nx1 = nx2 = nlabel = nweight = 0.f;
-#pragma unroll
-      for (int s = 0; s < LCAP; ++s) nslot[s] = -1;
-      if (nvalid) {
-        np = a.perm ? (long long)np2 : ni;
-        if (a.slots) {
-          const long long si = a.pool_mode ? np : ni;
-#pragma unroll
-          for (int s = 0; s < L; ++s) nslot[s] = a.slots[si * L + s];
-        }
-        nx0 = a.coord[3 * np];
-        nx1 = a.coord[3 * np + 1];
-        nx2 = a.coord[3 * np + 2];
-        nlabel = a.label[np];
-        if (EIK) nweight = a.weight[np];
-      }
-      if (a.perm && ni + 32 < end) np2 = a.perm[ni + 32];
-    }
-
+    if (EIK) SHINE_PREFETCH_NEXT_TILE()
     // ================================================================ phase 1: query (all levels)
     float f4[4] = {0.f, 0.f, 0.f, 0.f};
     float A4[4][3];  // EIK: d f_{4h+q} / d x_a
@@ -441,6 +442,11 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
         }
       }
     }
+    // Prefetch of tile t+1's point data (BCE build).  Issued HERE, after every gather of this tile has been issued: vmcnt
+    // counts in order, so loads put in flight at the tile's top have to return before the first corner ids can be
+    // consumed — and these are random reads into the pool (HBM misses).  Their data is not needed before the next
+    // tile's top.  -8 % kernel time; the eikonal build is 1 % faster with the prefetch at the top (A/B, both ways).
+    if (!EIK) SHINE_PREFETCH_NEXT_TILE()
     __builtin_amdgcn_s_setprio(0);
     SHINE_STAMP(1)  // query
 
