@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-frame cost of FeatureOctree.update (model/feature_octree.py:114-166): device growth (shine_tables_grow) vs
-the vectorised host path, on the synthetic MaiCity-like frames bench.py uses; plus the CPU oracle (the reference's
-Python loops restated) on the first frames as the baseline."""
+the vectorised host path, on the synthetic MaiCity-like frames bench.py uses.  (The CPU-oracle baseline for the same
+frames is timed by tests/cpu_baselines.py: only tests/ may touch oracle/.)"""
 import os, sys, time
 import numpy as np
 import torch
@@ -34,12 +34,3 @@ for name, move in (("device (shine_tables_grow)", lambda d: d), ("host (numpy)",
     octree, t = run(move)
     print("%-28s first frame %.2f ms, median later frames %.2f ms, total %.1f ms; rows %s" % (
         name, t[0], float(np.median(t[1:])), t.sum(), [int(p.shape[0]) for p in octree.hier_features]))
-
-if "--oracle" in sys.argv:
-    from oracle import shine_oracle as so
-    ocfg = so.make_config(tree_level_world=cfg.tree_level_world, tree_level_feat=3, leaf_vox_size=cfg.leaf_vox_size)
-    ref = so.OracleOctree(ocfg)
-    for i, d in enumerate(data[:3]):
-        t0 = time.perf_counter()
-        ref.update(d.cpu(), True)
-        print("oracle (reference loops restated, CPU) frame %d: %.0f ms" % (i, (time.perf_counter() - t0) * 1e3))

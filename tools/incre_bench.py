@@ -6,8 +6,8 @@
                 importance sweep (cal_feature_importance, utils/incre_learning.py:8-40)
 
 NCD-like synthetic quad (40 m, circular trajectory), N=4096, 50 iterations per frame, lambda_forget 1e4
-(config/ncd/ncd_incre_reg.yaml).  Prints the per-frame time split and frames/s; `--oracle K` times the CPU oracle
-(the reference's Python restated) on the first K frames as the baseline.
+(config/ncd/ncd_incre_reg.yaml).  Prints the per-frame time split and frames/s.  (The CPU-oracle baseline for the same
+frames is timed by tests/cpu_baselines.py: only tests/ may touch oracle/.)
 """
 import argparse, os, sys, time
 import numpy as np
@@ -23,7 +23,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=30)
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--bs", type=int, default=4096)
-ap.add_argument("--oracle", type=int, default=0)
 ap.add_argument("--freeze-after", type=int, default=20)
 ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per iteration (loop.GraphedIteration)")
 args = ap.parse_args()
@@ -83,28 +82,3 @@ print("per frame (median, ms): update+ranks %.2f | optimiser+pool plan %.2f | %d
           med[0], med[1], args.iters, med[2], med[2] / args.iters * 1e3, med[3], med[4], 1e3 / med[4],
           args.iters * args.bs / med[2] / 1e3))
 print("rows %s final loss %.4f" % ([int(p.shape[0]) for p in octree.hier_features], loss))
-
-if args.oracle:
-    from oracle import shine_oracle as so
-    over = dict(tree_level_world=cfg.tree_level_world, tree_level_feat=cfg.tree_level_feat, leaf_vox_size=cfg.leaf_vox_size,
-                sigma_sigmoid_m=cfg.sigma_sigmoid_m, loss_reduction="sum", lambda_forget=cfg.lambda_forget)
-    ocfg = so.make_config(**over)
-    torch.set_num_threads(1)
-    ref, mlp = so.OracleOctree(ocfg), so.OracleDecoder(ocfg)
-    for fi, (coord, label, weight) in enumerate(frames[:args.oracle]):
-        c, l, w = coord.cpu(), label.cpu(), weight.cpu()
-        t0 = time.perf_counter()
-        ref.update(c[w > 0], True)
-        t1 = time.perf_counter()
-        opt = so.adam_param_groups(ref, mlp, 0.01)
-        n_it = min(args.iters, 10)
-        for it in range(n_it):
-            idx = torch.randint(0, c.shape[0], (args.bs,))
-            out = so.train_step(ref, mlp, c[idx], l[idx], w[idx], ocfg, regularize=True)
-            opt.step()
-            opt.zero_grad(set_to_none=True)
-        t2 = time.perf_counter()
-        so.importance_sweep(ref, mlp, c, l, ocfg, args.bs, 2)
-        t3 = time.perf_counter()
-        print("oracle frame %d: update %.0f ms | iteration %.1f ms (x%d = %.0f ms) | importance sweep %.0f ms" % (
-            fi, (t1 - t0) * 1e3, (t2 - t1) / n_it * 1e3, args.iters, (t2 - t1) / n_it * args.iters * 1e3, (t3 - t2) * 1e3))
