@@ -912,3 +912,43 @@ def test_graphed_iteration_matches_eager_loop(mode):
     octree2.update(torch.tensor([[0.31, 0.27, -0.11], [0.33, 0.27, -0.11]]).cuda())
     with pytest.raises(RuntimeError, match="GraphedIteration"):
         step()
+
+
+@pytest.mark.parametrize("kind,levels,n", [("maicity", 4, (1 << 18) + 37), ("kitti", 3, (1 << 17) + 1)])
+def test_pool_mode_at_scale_equals_planned_batch_mode(kind, levels, n):
+    """BASELINE-size pool-mode launch (4 tiles per wave, ragged tail, indices prefetched two tiles ahead) against the
+    same points pushed through the planned-batch path and through the v0 checker kernel."""
+    from shine_mapping_amd import StepOptions, dp, fused_train_step, synth
+    from shine_mapping_amd.sampler import SortedPool
+
+    wl = synth.build_workload(kind, frames=8, device="cuda", seed=21, tree_level_feat=levels, azimuths=300)
+    octree, dec, cfg = wl.octree, wl.decoder.cuda(), wl.cfg
+    with torch.no_grad():
+        for p in octree.hier_features:
+            p.mul_(5.0)
+    octree._require_tables(with_ranks=True)
+    sp = SortedPool(octree, wl.pool.coord, wl.pool.sdf_label, wl.pool.weight, seed=2)
+    idx = sp.draw(n)
+    params = list(octree.hier_features) + dec.fused_params()
+
+    def run(**kw):
+        for p in params:
+            p.grad = None
+        opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=cfg.ekional_loss_on, weight_e=cfg.weight_e,
+                           kernel_variant=kw.pop("variant", 0))
+        loss, pred, g = fused_train_step(octree, dec, *kw.pop("batch"), opts, want_grad_x=True, **kw)
+        torch.cuda.synchronize()
+        return float(loss), pred.clone(), None if g is None else g.clone(), [p.grad.clone() for p in params]
+
+    c, l, w = (t.contiguous() for t in sp.get_batch(idx))
+    lp, pp, gp, grp = run(batch=(None, None, None), pool=sp, idx=idx)
+    perm, slots = dp.plan_batch(octree, c)
+    lb, pb, gb, grb = run(batch=(c, l, w), perm=perm, slots=slots)
+    l0, p0, g0, gr0 = run(batch=(c, l, w), variant=1)  # v0: lane = point, per-lane atomics
+    for other_loss, other_pred, other_g, other_gr in ((lb, pb, gb, grb), (l0, p0, g0, gr0)):
+        assert abs(lp - other_loss) <= 2e-5 * max(1.0, abs(other_loss))
+        assert abs_err(pp, other_pred) <= 2e-5
+        if gp is not None:
+            assert rel_err(gp, other_g) <= 5e-5
+        for a, b in zip(grp, other_gr):
+            assert rel_err(a, b) <= 1e-4
