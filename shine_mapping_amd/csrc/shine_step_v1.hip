@@ -37,14 +37,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int LCAP = 4;        // featured levels handled by this kernel (tree_level_feat <= 4 in every yaml)
 constexpr int WAVES = 8;       // waves per workgroup
 constexpr int NT = WAVES * 64;
-constexpr int TP = 33;         // transpose tile pitch (floats)
+constexpr int TP = 36;         // transpose tile pitch (floats): 16-B aligned rows for the b128 operand reads
 constexpr int WP = 36;         // pitch of the [corner][point] / [feature][point] staging rows (conflict-free b128 reads)
 constexpr int U_IDS = LCAP * 8 * WP;             // ids  [LCAP][8 corners][WP]  int32 (point-contiguous)
 constexpr int U_W = LCAP * 8 * WP;               // w    [LCAP][8 corners][WP]
 constexpr int R2_TL = 0, R2_TR = 32 * TP;        // region 2, first life: the two transpose tiles
 constexpr int R2_DF = 0, R2_J = 8 * WP, R2_CQ = 16 * WP;  // second life: df [8][WP], J [8][WP], cq [LCAP][8][WP]
-constexpr int R2_FLOATS = 2 * 32 * TP;           // 2112
-constexpr int WAVE_FLOATS = U_IDS + U_W + R2_FLOATS;  // 4416 floats = 17,664 B per wave
+constexpr int R2_FLOATS = 2 * 32 * TP;           // 2304
+constexpr int WAVE_FLOATS = U_IDS + U_W + R2_FLOATS;  // 4608 floats = 18,432 B per wave
 constexpr int OP_A1 = 0, OP_A2 = 4 * 64, OP_A2T = 20 * 64, OP_A1T = 36 * 64, OP_TOTAL = 52 * 64;
 constexpr int SB_B1 = 0, SB_B2 = 32, SB_W3 = 64, SB_B3 = 96;
 constexpr int PART_TRASH = SHINE_MLP_PARAMS;                     // + s*8 + q
@@ -150,17 +150,27 @@ __device__ __forceinline__ Axis axis_weight_rt(bool poly, float x, float res) {
 // RCOLS all ones (so acc[:, RCOLS] = sum_k L[i][k]); lsum, if given, accumulates this lane's L operands.
 template <int RCOLS, bool ONES>
 __device__ __forceinline__ f32x16 wgrad_pass(const float* TL, const float* TR, int pt, int h, f32x16 acc, float* lsum) {
+  // MFMA t contracts over the two points k = 16 h + t (h = lane >> 5): any bijection onto the tile's 32 points will do,
+  // and this one makes a lane's 16 operands contiguous: four ds_read_b128 per operand instead of sixteen ds_read_b32.
+  const float4* pl = reinterpret_cast<const float4*>(TL + pt * TP + 16 * h);
+  const float4* pr = reinterpret_cast<const float4*>(TR + pt * TP + 16 * h);
+  float lv[16], bv[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 x = pl[j];
+    lv[4 * j] = x.x, lv[4 * j + 1] = x.y, lv[4 * j + 2] = x.z, lv[4 * j + 3] = x.w;
+    if (RCOLS == 32 || pt < RCOLS) {
+      const float4 y = pr[j];
+      bv[4 * j] = y.x, bv[4 * j + 1] = y.y, bv[4 * j + 2] = y.z, bv[4 * j + 3] = y.w;
+    } else {
+      const float c = (ONES && pt == RCOLS) ? 1.f : 0.f;
+      bv[4 * j] = bv[4 * j + 1] = bv[4 * j + 2] = bv[4 * j + 3] = c;
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
-    const int k = 2 * t + h;
-    const float l = TL[pt * TP + k];
-    if (lsum) *lsum += l;
-    float b;
-    if (RCOLS == 32)
-      b = TR[pt * TP + k];
-    else
-      b = pt < RCOLS ? TR[pt * TP + k] : ((ONES && pt == RCOLS) ? 1.f : 0.f);
-    acc = mfma32(l, b, acc);
+    if (lsum) *lsum += lv[t];
+    acc = mfma32(lv[t], bv[t], acc);
   }
   return acc;
 }
