@@ -405,6 +405,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
       for (int s = 0; s < L; ++s) {
         const V1Level& Lv = a.lv[s];
         const bool hit = slot[s] >= 0;
+        if (!EIK && gather_on) issue_row_gathers(Lv.feat, i0[s], i1[s], hit, h, rowbuf);  // the ALU below runs under them
         // node-run boundaries of the sorted stream (wave-uniform bit masks over the 32 points of the tile)
         int prev = __shfl_up(slot[s], 1, 64);
         if (pt == 0) prev = last_slot[s];
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) U_w[(s * 8 + 4 * h + c) * WP + pt] = h == 0 ? w[c] : w[4 + c];
         if (gather_on) {
-          issue_row_gathers(Lv.feat, i0[s], i1[s], hit, h, rowbuf);
+          if (EIK) issue_row_gathers(Lv.feat, i0[s], i1[s], hit, h, rowbuf);
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             const float wz = w[c];
