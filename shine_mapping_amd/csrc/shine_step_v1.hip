@@ -148,28 +148,35 @@ __device__ __forceinline__ Axis axis_weight_rt(bool poly, float x, float res) {
 // one transposed weight-grad pass: acc[i][j] += sum_k L[i][k] * R[j][k] over the tile's 32 points.
 // TL/TR hold the operands as [channel][point]; RCOLS < 32 zero-fills the unused B columns, ONES makes column
 // RCOLS all ones (so acc[:, RCOLS] = sum_k L[i][k]); lsum, if given, accumulates this lane's L operands.
-template <int RCOLS, bool ONES>
+// EXTRA: what MFMA column RCOLS carries — 0 nothing, 1 all ones (acc[:, RCOLS] = sum_k L[i][k]), 2 row RCOLS of TR
+// (acc[:, RCOLS] = sum_k L[i][k] TR[RCOLS][k]).  WSUM: *lsum accumulates sum_k L[i][k] * d[k] with d[0..31] read from
+// the pad columns of TL's first 8 rows (d[k] at TL[(k >> 2) * TP + 32 + (k & 3)]), else the plain sum of L.
+template <int RCOLS, int EXTRA, bool WSUM>
 __device__ __forceinline__ f32x16 wgrad_pass(const float* TL, const float* TR, int pt, int h, f32x16 acc, float* lsum) {
   // MFMA t contracts over the two points k = 16 h + t (h = lane >> 5): any bijection onto the tile's 32 points will do,
   // and this one makes a lane's 16 operands contiguous: four ds_read_b128 per operand instead of sixteen ds_read_b32.
   const float4* pl = reinterpret_cast<const float4*>(TL + pt * TP + 16 * h);
   const float4* pr = reinterpret_cast<const float4*>(TR + pt * TP + 16 * h);
-  float lv[16], bv[16];
+  float lv[16], bv[16], dv[WSUM ? 16 : 1];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float4 x = pl[j];
     lv[4 * j] = x.x, lv[4 * j + 1] = x.y, lv[4 * j + 2] = x.z, lv[4 * j + 3] = x.w;
-    if (RCOLS == 32 || pt < RCOLS) {
+    if (RCOLS == 32 || pt < RCOLS || (EXTRA == 2 && pt == RCOLS)) {
       const float4 y = pr[j];
       bv[4 * j] = y.x, bv[4 * j + 1] = y.y, bv[4 * j + 2] = y.z, bv[4 * j + 3] = y.w;
     } else {
-      const float c = (ONES && pt == RCOLS) ? 1.f : 0.f;
+      const float c = (EXTRA == 1 && pt == RCOLS) ? 1.f : 0.f;
       bv[4 * j] = bv[4 * j + 1] = bv[4 * j + 2] = bv[4 * j + 3] = c;
+    }
+    if (WSUM) {
+      const float4 d = *reinterpret_cast<const float4*>(TL + (4 * h + j) * TP + 32);
+      dv[4 * j] = d.x, dv[4 * j + 1] = d.y, dv[4 * j + 2] = d.z, dv[4 * j + 3] = d.w;
     }
   }
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
-    if (lsum) *lsum += lv[t];
+    if (lsum) *lsum = WSUM ? fmaf(lv[t], dv[t], *lsum) : *lsum + lv[t];
     acc = mfma32(lv[t], bv[t], acc);
   }
   return acc;
@@ -581,7 +588,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
         TR[rowidx(r, h) * TP + pt] = h1[r];
       }
       wave_lds_fence();
-      accW2 = wgrad_pass<32, false>(TL, TR, pt, h, accW2, &db2acc);  // dW2[out][in] += d2[out][k] h1[in][k]; db2 rides
+      accW2 = wgrad_pass<32, 0, false>(TL, TR, pt, h, accW2, &db2acc);  // dW2[out][in] += d2[out][k] h1[in][k]; db2 rides
       wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = d1[r];
@@ -589,7 +596,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
       for (int q = 0; q < 4; ++q) TR[(4 * h + q) * TP + pt] = f4[q];
       wave_lds_fence();
       // B columns 0..7 = f, column 8 = ones: accW1[:,8] accumulates db1 = sum_k d1[ch][k] in the spare MFMA lanes
-      accW1 = wgrad_pass<F, true>(TL, TR, pt, h, accW1, nullptr);    // dW1[ch][feat] += d1[ch][k] f[feat][k]
+      accW1 = wgrad_pass<F, 1, false>(TL, TR, pt, h, accW1, nullptr);    // dW1[ch][feat] += d1[ch][k] f[feat][k]
       wave_lds_fence();
       if (EIK) {
 #pragma unroll
@@ -598,14 +605,14 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
           TR[rowidx(r, h) * TP + pt] = a1[r];
         }
         wave_lds_fence();
-        accW2 = wgrad_pass<32, false>(TL, TR, pt, h, accW2, nullptr);  // dW2 += v2 (x) a1
+        accW2 = wgrad_pass<32, 0, false>(TL, TR, pt, h, accW2, nullptr);  // dW2 += v2 (x) a1
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = v1[r];
 #pragma unroll
         for (int q = 0; q < 4; ++q) TR[(4 * h + q) * TP + pt] = r4[q];
         wave_lds_fence();
-        accW1 = wgrad_pass<F, false>(TL, TR, pt, h, accW1, nullptr);   // dW1 += v1 (x) r   (no bias term)
+        accW1 = wgrad_pass<F, 0, false>(TL, TR, pt, h, accW1, nullptr);   // dW1 += v1 (x) r   (no bias term)
         wave_lds_fence();
       }
     }
@@ -663,48 +670,16 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
     if (h == 0) db3 += delta;
 
     // ================================================================ phase 4: backward through the decoder
-    {
-      float d2[16];
+    // The decoder has ONE output, so everything the loss sends back is the eikonal chain scaled by the point's delta:
+    //   d2 = delta * v2,  d1 = delta * v1,  d loss / d f = delta * J          (v2 = m2 .* w3, v1 = m1 .* W2^T v2, J = W1^T v1)
+    // -> no separate backward MFMA chain, and the weight grads of both terms contract in ONE pass per matrix:
+    //   dW2 += v2 (x) (delta * h1 + a1),   dW1 += v1 (x) (delta * f + r),   db2 += sum_k delta_k v2,  db1 += sum_k delta_k v1.
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        d2[r] = ((m2 >> r) & 1u) ? delta * s_bias[SB_W3 + rowidx(r, h)] : 0.f;
-        dw3c[r] = fmaf(delta, h2[r], dw3c[r]);
-      }
-      f32x16 e1 = zero16(), e0 = zero16();
-#pragma unroll
-      for (int t = 0; t < 16; ++t) e1 = mfma32(s_opA[OP_A2T + t * 64 + lane], d2[t], e1);
-      if (wg) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = d2[r];
-      }
-      float d1[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) d1[r] = ((m1 >> r) & 1u) ? e1[r] : 0.f;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) e0 = mfma32(s_opA[OP_A1T + t * 64 + lane], d1[t], e0);
-      // rows 0..7 of e0 = d loss / d f ; lane (pt,h) holds rows 4h..4h+3 in regs 0..3
-#pragma unroll
-      for (int q = 0; q < 4; ++q) df4[q] = e0[q];
-      SHINE_STAMP(3)  // loss + decoder backward
-
-      // ============================================================== phase 5: decoder weight grads (transposed MFMA)
-      if (wg) {
-        wave_lds_fence();
-        accW2 = wgrad_pass<32, false>(TL, TR, pt, h, accW2, &db2acc);  // dW2[out][in] += d2[out][k] h1[in][k]; db2 rides
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = d1[r];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) TR[(4 * h + q) * TP + pt] = f4[q];
-        wave_lds_fence();
-        // B columns 0..7 = f, column 8 = ones: accW1[:,8] accumulates db1 = sum_k d1[ch][k] in the spare MFMA lanes
-        accW1 = wgrad_pass<F, true>(TL, TR, pt, h, accW1, nullptr);    // dW1[ch][feat] += d1[ch][k] f[feat][k]
-        wave_lds_fence();
-      }
-    }
+    for (int r = 0; r < 16; ++r) dw3c[r] = fmaf(delta, h2[r], dw3c[r]);
+    SHINE_STAMP(3)  // loss + decoder backward
 
     // ---------------------------------------------------------------- eikonal term (closed form)
-    if (EIK) {
+    {
       float v1[16], a1[16], r4[4], g[3];
       {
         f32x16 ev = zero16(), ej = zero16();
@@ -716,7 +691,10 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) ej = mfma32(s_opA[OP_A1T + t * 64 + lane], v1[t], ej);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) J4[q] = ej[q];  // d y / d f_{4h+q}
+        for (int q = 0; q < 4; ++q) {
+          J4[q] = ej[q];             // d y / d f_{4h+q}
+          df4[q] = delta * ej[q];    // d loss_bce / d f_{4h+q}
+        }
       }
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
@@ -753,21 +731,26 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dw3c[r] += ((m2 >> r) & 1u) ? t2[r] : 0.f;  // a2 = (W2 a1) .* m2
       }
+      // ============================================================== phase 5: decoder weight grads (transposed MFMA)
       if (wg) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          TL[rowidx(r, h) * TP + pt] = ((m2 >> r) & 1u) ? s_bias[SB_W3 + rowidx(r, h)] : 0.f;  // v2
-          TR[rowidx(r, h) * TP + pt] = a1[r];
+          const int row = rowidx(r, h);
+          const float hv = TR[row * TP + pt];  // h1, parked here by this lane after layer 2
+          TR[row * TP + pt] = fmaf(delta, hv, a1[r]);
+          TL[row * TP + pt] = ((m2 >> r) & 1u) ? s_bias[SB_W3 + row] : 0.f;  // v2
         }
+        if (h == 0) TL[(pt >> 2) * TP + 32 + (pt & 3)] = delta;  // delta_k in the pad columns (wgrad_pass WSUM)
         wave_lds_fence();
-        accW2 = wgrad_pass<32, false>(TL, TR, pt, h, accW2, nullptr);  // dW2 += v2 (x) a1
+        accW2 = wgrad_pass<32, 0, true>(TL, TR, pt, h, accW2, &db2acc);  // dW2 += v2 (x) (delta h1 + a1); db2 rides
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = v1[r];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) TR[(4 * h + q) * TP + pt] = r4[q];
+        for (int q = 0; q < 4; ++q) TR[(4 * h + q) * TP + pt] = fmaf(delta, f4[q], r4[q]);
+        if (h == 0) TR[F * TP + pt] = delta;  // row 8: accW1[:, 8] = sum_k v1[ch][k] delta_k = db1
         wave_lds_fence();
-        accW1 = wgrad_pass<F, false>(TL, TR, pt, h, accW1, nullptr);   // dW1 += v1 (x) r   (no bias term)
+        accW1 = wgrad_pass<F, 2, false>(TL, TR, pt, h, accW1, nullptr);    // dW1 += v1 (x) (delta f + r)
         wave_lds_fence();
       }
     }
