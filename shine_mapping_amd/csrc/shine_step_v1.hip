@@ -496,33 +496,6 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
     const float y = yp + __shfl_xor(yp, 32, 64) + b3;
     if (valid && h == 0 && a.pred) __builtin_nontemporal_store(y, a.pred + po);
 
-    // ---------------------------------------------------------------- eikonal: d pred / d coord (closed form)
-    float v1[16], g[3] = {0.f, 0.f, 0.f};
-    if (EIK) {
-      f32x16 ev = zero16(), ej = zero16();
-#pragma unroll
-      for (int t = 0; t < 16; ++t)
-        ev = mfma32(s_opA[OP_A2T + t * 64 + lane], h2[t] > 0.f ? s_bias[SB_W3 + rowidx(t, h)] : 0.f, ev);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v1[r] = h1[r] > 0.f ? ev[r] : 0.f;  // m1 .* (W2^T (m2 .* w3))
-#pragma unroll
-      for (int t = 0; t < 16; ++t) ej = mfma32(s_opA[OP_A1T + t * 64 + lane], v1[t], ej);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) J4[q] = ej[q];  // d y / d f_{4h+q}
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s = fmaf(J4[q], A4[q][e], s);
-        s += __shfl_xor(s, 32, 64);
-        g[e] = sigma * s;
-      }
-      if (valid && h == 0 && a.grad_x) {
-        a.grad_x[3 * po] = g[0];
-        a.grad_x[3 * po + 1] = g[1];
-        a.grad_x[3 * po + 2] = g[2];
-      }
-    }
     SHINE_STAMP(2)  // decoder forward
 
     // ================================================================ phase 3: loss
@@ -534,32 +507,9 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
         cnt_acc += 1.0;
       }
       delta = (sigmoidf_acc(y) - zt) * a.inv_n;
-      if (EIK && wgt > 0.f) {
-        const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
-        const float e = 1.0f - gn;
-        if (h == 0) eik_acc += (double)(e * e);
-        const float coef = gn > 0.f ? (-2.0f * e / gn) * (a.weight_e * inv_nsurf) : 0.f;  // norm's sub-gradient 0 at 0
-        qv[0] = coef * g[0];
-        qv[1] = coef * g[1];
-        qv[2] = coef * g[2];
-      }
     }
 
     // ================================================================ phase 4: backward through the decoder
-    float r4[4], a1[16];
-    if (EIK) {
-      f32x16 t1 = zero16(), t2 = zero16();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) r4[q] = sigma * (A4[q][0] * qv[0] + A4[q][1] * qv[1] + A4[q][2] * qv[2]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) t1 = mfma32(s_opA[OP_A1 + t * 64 + lane], r4[t], t1);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a1[r] = h1[r] > 0.f ? t1[r] : 0.f;  // (W1 r) .* m1
-#pragma unroll
-      for (int t = 0; t < 16; ++t) t2 = mfma32(s_opA[OP_A2 + t * 64 + lane], a1[t], t2);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dw3c[r] += h2[r] > 0.f ? t2[r] : 0.f;  // a2 = (W2 a1) .* m2
-    }
     float d2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -598,23 +548,6 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
       // B columns 0..7 = f, column 8 = ones: accW1[:,8] accumulates db1 = sum_k d1[ch][k] in the spare MFMA lanes
       accW1 = wgrad_pass<F, 1, false>(TL, TR, pt, h, accW1, nullptr);    // dW1[ch][feat] += d1[ch][k] f[feat][k]
       wave_lds_fence();
-      if (EIK) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          TL[rowidx(r, h) * TP + pt] = h2[r] > 0.f ? s_bias[SB_W3 + rowidx(r, h)] : 0.f;  // v2
-          TR[rowidx(r, h) * TP + pt] = a1[r];
-        }
-        wave_lds_fence();
-        accW2 = wgrad_pass<32, 0, false>(TL, TR, pt, h, accW2, nullptr);  // dW2 += v2 (x) a1
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) TL[rowidx(r, h) * TP + pt] = v1[r];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) TR[(4 * h + q) * TP + pt] = r4[q];
-        wave_lds_fence();
-        accW1 = wgrad_pass<F, 0, false>(TL, TR, pt, h, accW1, nullptr);   // dW1 += v1 (x) r   (no bias term)
-        wave_lds_fence();
-      }
     }
     } else {
     // ---- eikonal build: same maths, activations retired early (register budget: v1/a1 need the room)
