@@ -5,29 +5,32 @@
 //   loss     sdf_bce_loss, eikonal term    utils/loss.py:17-24, shine_batch.py:141-142,182-185 (get_gradient: utils/tools.py:175-185)
 //   backward cur_loss.backward()           shine_batch.py:208-209 (closed form, SURVEY.md §8a math contract)
 //
-// One wave owns a contiguous run of the Morton-sorted batch and walks it in tiles of 32 points.
+// One wave owns a contiguous run of the node-ordered batch and walks it in tiles of 32 points.
 //   lane = (pt = lane & 31, h = lane >> 5): the two half-waves hold features 4h..4h+3 of the same 32 points,
 //   which is exactly the B-operand / C-accumulator shape of v_mfma_f32_32x32x2_f32 (exact fp32):
 //     D[32 channels x 32 points] += A[32 x 2] . B[2 x 32],   lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
 //     acc reg r of lane l = D[row (r&3) + 8(r>>2) + 4(l>>5)][col l&31].
-//   * query: leaf Morton key once (parents are key >> 3), first-slot key loads of every level issued together,
-//     then ids and 16-B row gathers two levels at a time; a miss reads row 0 with weight 0 (no branches);
-//   * decoder forward/backward (and the eikonal chain v1, J, a1, a2) are chained MFMAs that never leave
-//     registers: the k-order of each product is permuted to the accumulator row order of the previous one
-//     (k(t,h) = rowidx(t,h)), so the ReLU'd accumulator register t IS the next B operand; the matching A
-//     operands are pre-permuted once per workgroup into LDS (s_opA);
-//   * decoder weight grads contract over POINTS, so their operands are the transposes: d2/h1, d1/f (and v2/a1,
-//     v1/r for the eikonal term) go through a padded [32][33] LDS tile pair per wave and accumulate in MFMA
-//     accumulators that live in registers for the whole kernel; db1 rides in a spare MFMA column, db2 is the
-//     sum of the transposed operands that are loaded anyway;
-//   * feature grads: lane = (corner c = lane>>3, feature q = lane&7); node-run boundaries / hits of the sorted
+//   * query: the point's hash slots come with the batch (plan / pool) or are probed here (leaf Morton key once,
+//     parents are key >> 3); the corner ids of all levels are loaded together, then per level the 8 16-B row gathers
+//     are issued as a batch; a miss reads row 0 with weight 0 (no branches).  The next tile's point data is
+//     prefetched one tile ahead (its index two tiles ahead) — AFTER this tile's gathers in the BCE build, because
+//     vmcnt counts in issue order and those loads are HBM misses;
+//   * decoder forward/backward are chained MFMAs that never leave registers: the k-order of each product is permuted
+//     to the accumulator row order of the previous one (k(t,h) = rowidx(t,h)), so the ReLU'd accumulator register t
+//     IS the next B operand; the matching A operands are pre-permuted once per workgroup into LDS (s_opA).  In the
+//     eikonal build the loss's backward IS the eikonal chain (v1, J) scaled by the point's delta (one decoder output);
+//   * decoder weight grads contract over POINTS, so their operands are the transposes: they go through a padded
+//     [32][36] LDS tile pair per wave (operands read back as ds_read_b128) and accumulate in MFMA accumulators that
+//     live in registers for the whole kernel; BCE build: d2/h1 and d1/f, db1 in a spare MFMA column, db2 as the sum of
+//     the transposed operands; eikonal build: v2/(delta h1 + a1) and v1/(delta f + r), one pass per matrix for both terms;
+//   * feature grads: lane = (corner c = lane>>3, feature q = lane&7); node-run boundaries / hits of the ordered
 //     stream are wave-uniform bit masks, the wave keeps a running sum while the node stays the same and issues
-//     ONE 64-lane global_atomic_add_f32 (8 rows x 32 B) per node run; misses (index -1, the trash row :205,231)
-//     are summed in registers for the whole kernel;
+//     ONE 64-lane global_atomic_add_f32 (8 rows x 32 B) per node run; the trash row (index -1, :205,231) gets the plain
+//     sum of df over the points that miss a level (its 8 corner weights sum to 1), kept in registers for the whole kernel;
 //   * decoder / trash-row / loss sums leave the workgroup as one partial vector in the caller's workspace and a
 //     second tiny kernel adds them up (deterministic, no hot-spot atomics), re-zeroes the trash rows
 //     (set_zero, :78-81) and finalises the loss.
-// Workgroup = 512 threads (8 waves, 2 per SIMD), one per CU: ~151 KB of LDS, ~17 KB of it private to each wave.
+// Workgroup = 512 threads (8 waves, 2 per SIMD), one per CU: 157 KB of LDS, 18 KB of it private to each wave.
 #include "shine_internal.hpp"
 
 namespace shine {
