@@ -130,6 +130,20 @@ int shine_interp_backward_backward(const shine_tables* t, const shine_step_confi
                                    const float* gg_coord, float* grad_gfeat_out, float* const* grad_feats,
                                    void* stream);
 
+/* ---- Tier A (strict drop-in): Decoder.sdf (model/decoder.py:49-63) as a twice-differentiable op — forward, the
+ *      backward autograd derives for cur_loss.backward() (shine_batch.py:208-209), and the backward of that backward,
+ *      needed when get_gradient(create_graph=True) (utils/tools.py:175-185) feeds the eikonal term
+ *      (shine_batch.py:141-142,182-185).  feat [N,8]; mlp = 6 device pointers W1,b1,W2,b2,w3,b3 (host array).
+ *      _backward: grad_pred [N] = d loss / d pred;  grad_feat_out [N,8] (overwritten) or NULL;  grad_mlp: NULL or 6
+ *      device pointers ACCUMULATED INTO (shapes of mlp).
+ *      _backward_backward: gg_feat [N,8] = d loss / d(grad_feat);  grad_gpred_out [N] (overwritten) or NULL;
+ *      grad_mlp: NULL or 6 pointers, W1/W2/w3 accumulated into (the biases receive nothing). ----------------------- */
+int shine_mlp_forward(const float* feat, int64_t n, const float* const* mlp, float* pred_out, void* stream);
+int shine_mlp_backward(const float* feat, const float* grad_pred, int64_t n, const float* const* mlp,
+                       float* grad_feat_out, float* const* grad_mlp, void* stream);
+int shine_mlp_backward_backward(const float* feat, const float* grad_pred, const float* gg_feat, int64_t n,
+                                const float* const* mlp, float* grad_gpred_out, float* const* grad_mlp, void* stream);
+
 /* ---- fused training step: query + decode + sdf_bce_loss (utils/loss.py:17-24) [+ eikonal
  *      (shine_batch.py:182-185)] + the whole backward (shine_batch.py:208-209) in one pass.
  *      Inputs : coord [N,3], sdf_label [N], weight [N] (sign = surface/free, data_sampler.py:102-103),

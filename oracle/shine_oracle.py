@@ -153,6 +153,8 @@ class OracleOctree:
     def interp_weights(self, x: torch.Tensor, level: int) -> torch.Tensor:
         u = (2 ** level) * (x * 0.5 + 0.5)
         d = torch.frac(u)
+        if getattr(self, "acc_dtype", torch.float32) != torch.float32:
+            d = d.to(self.acc_dtype)  # wide-accumulation mode (to_wide): fp32 coordinate arithmetic, wide sums
         if self.poly:
             tx = 3 * (d[:, 0] ** 2) - 2 * (d[:, 0] ** 3)
             ty = 3 * (d[:, 1] ** 2) - 2 * (d[:, 1] ** 3)
@@ -174,7 +176,7 @@ class OracleOctree:
 
     # model/feature_octree.py:222-234
     def query_feature_with_indices(self, coord: torch.Tensor, hidx: Sequence[torch.Tensor]) -> torch.Tensor:
-        acc = torch.zeros(coord.shape[0], self.feature_dim)
+        acc = torch.zeros(coord.shape[0], self.feature_dim, dtype=getattr(self, "acc_dtype", torch.float32))
         for i in range(self.featured_level_num):
             lvl = self.max_level - i
             fl = self.featured_level_num - i - 1
@@ -249,9 +251,24 @@ class OracleDecoder:
 # --------------------------------------------------------------------------- losses / glue
 
 
+def to_wide(octree: "OracleOctree", mlp: "OracleDecoder", dtype=torch.float64) -> None:
+    """Wide-accumulation mode of the oracle, for error attribution at BASELINE sizes (tests/test_gpu_scale_parity.py):
+    voxel ids and the fractional coordinates d = frac(2^l (x/2 + 1/2)) are still computed in fp32 exactly as the
+    reference does (so every point lands in the same voxel with the same d), everything downstream — corner weights,
+    feature sums, decoder, loss, and above all the index_put_(accumulate) / GEMM reductions of the backward pass over
+    10^5..10^6 points — runs in `dtype`.  It answers "what is the exact value of the reference's function on these fp32
+    inputs"; the fp32 oracle (= the reference bit for bit) and the HIP path are both compared with it."""
+    octree.acc_dtype = dtype
+    octree.hier_features = [t.detach().to(dtype).requires_grad_(True) for t in octree.hier_features]
+    octree.importance_weight = [t.to(dtype) for t in octree.importance_weight]
+    octree.features_last_frame = [t.to(dtype) for t in octree.features_last_frame]
+    for n in ("W1", "b1", "W2", "b2", "w3", "b3"):
+        setattr(mlp, n, getattr(mlp, n).detach().to(dtype).requires_grad_(True))
+
+
 def sdf_bce_loss(pred, label, sigma, reduction="mean"):
     """utils/loss.py:17-24 with weighted=False (loss_weight_on is False in all 15 shipped yamls)."""
-    target = torch.sigmoid(label / sigma)
+    target = torch.sigmoid(label / sigma).to(pred.dtype)
     return torch.nn.functional.binary_cross_entropy_with_logits(pred, target, reduction=reduction)
 
 

@@ -89,6 +89,9 @@ _SIGNATURES = {
     "shine_tables_set_ranks": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, C.c_int64, _P]),
     "shine_plan_batch": (C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, _P, _P, _P, C.c_size_t, _P,
                                    C.POINTER(C.c_size_t), _P]),
+    "shine_mlp_forward": (C.c_int, [_P, C.c_int64, C.POINTER(_P), _P, _P]),
+    "shine_mlp_backward": (C.c_int, [_P, _P, C.c_int64, C.POINTER(_P), _P, C.POINTER(_P), _P]),
+    "shine_mlp_backward_backward": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(_P), _P, C.POINTER(_P), _P]),
     "shine_interp_backward": (
         C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P,
                   C.POINTER(_P), _P]),

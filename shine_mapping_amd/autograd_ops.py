@@ -108,3 +108,152 @@ class OctreeInterpBackward(torch.autograd.Function):
             grad_g = extra if grad_g is None else grad_g + extra
         # inputs: g, coord, octree, want_coord, *feats   (no second derivative wrt coord: it is a leaf nobody reads)
         return (grad_g, None, None, None) + tuple(grad_feats)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Tier A: Decoder.sdf (model/decoder.py:49-63) as a twice-differentiable HIP op
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def _f32c(t):
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+class FusedMLP(torch.autograd.Function):
+    """pred[N] = w3 . relu(W2 relu(W1 feat + b1) + b2) + b3   (shine_mlp_forward).  Inputs: feat [N,8], then the six
+    decoder tensors W1 [32,8], b1, W2 [32,32], b2, w3 [1,32], b3 [1].  Backward is FusedMLPBackward (itself
+    differentiable), so get_gradient(create_graph=True) (utils/tools.py:175-185) works through it."""
+
+    @staticmethod
+    def forward(ctx, feat, *mlp):
+        f = _f32c(feat)
+        n = f.shape[0]
+        pred = torch.empty(n, dtype=torch.float32, device=f.device)
+        _lib.check(
+            _lib.lib().shine_mlp_forward(f.data_ptr(), n, _lib.ptr_array([_f32c(p).data_ptr() for p in mlp]),
+                                         pred.data_ptr(), _stream()),
+            "shine_mlp_forward",
+        )
+        ctx.save_for_backward(feat, *mlp)
+        return pred
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, *mlp = ctx.saved_tensors
+        need_w = any(ctx.needs_input_grad[1:])
+        outs = FusedMLPBackward.apply(g, feat, ctx.needs_input_grad[0], need_w, *mlp)
+        grad_feat = outs[0] if ctx.needs_input_grad[0] else None
+        grads = tuple(o if need else None for o, need in zip(outs[1:], ctx.needs_input_grad[1:]))
+        return (grad_feat,) + grads
+
+
+class FusedMLPBackward(torch.autograd.Function):
+    """(grad_feat [N,8], gW1, gb1, gW2, gb2, gw3, gb3) = backward of FusedMLP for g = d loss / d pred
+    (shine_mlp_backward).  Differentiable wrt g and the weights through grad_feat (shine_mlp_backward_backward): the
+    eikonal term's path.  Second derivatives THROUGH the weight-grad outputs are not implemented (nothing in the
+    reference differentiates them) and raise."""
+
+    @staticmethod
+    def forward(ctx, g, feat, want_feat, want_w, *mlp):
+        f, gc = _f32c(feat), _f32c(g)
+        n = f.shape[0]
+        dev = f.device
+        grad_feat = torch.empty((n, 8), dtype=torch.float32, device=dev) if want_feat else None
+        gw = [torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in mlp] \
+            if want_w else None
+        _lib.check(
+            _lib.lib().shine_mlp_backward(
+                f.data_ptr(), gc.data_ptr(), n, _lib.ptr_array([_f32c(p).data_ptr() for p in mlp]),
+                grad_feat.data_ptr() if want_feat else None,
+                _lib.ptr_array([t.data_ptr() for t in gw]) if want_w else None, _stream(),
+            ),
+            "shine_mlp_backward",
+        )
+        ctx.save_for_backward(g, feat, *mlp)
+        ctx.set_materialize_grads(False)
+        if grad_feat is None:
+            grad_feat = torch.zeros((0, 8), dtype=torch.float32, device=dev)
+        if gw is None:
+            gw = [torch.zeros(0, dtype=torch.float32, device=dev) for _ in mlp]
+        return (grad_feat,) + tuple(gw)
+
+    @staticmethod
+    def backward(ctx, gg_feat, *gg_w):
+        if any(x is not None for x in gg_w):
+            raise NotImplementedError("second derivatives through the decoder's weight gradients are not implemented")
+        g, feat, *mlp = ctx.saved_tensors
+        none = (None,) * (4 + len(mlp))
+        if gg_feat is None:
+            return none
+        need_g = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[4:])
+        if not (need_g or need_w):
+            return none
+        f, gc, r = _f32c(feat), _f32c(g), _f32c(gg_feat)
+        n = f.shape[0]
+        grad_g = torch.empty(n, dtype=torch.float32, device=f.device) if need_g else None
+        gw = [torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in mlp] \
+            if need_w else None
+        _lib.check(
+            _lib.lib().shine_mlp_backward_backward(
+                f.data_ptr(), gc.data_ptr(), r.data_ptr(), n, _lib.ptr_array([_f32c(p).data_ptr() for p in mlp]),
+                grad_g.data_ptr() if need_g else None,
+                _lib.ptr_array([t.data_ptr() for t in gw]) if need_w else None, _stream(),
+            ),
+            "shine_mlp_backward_backward",
+        )
+        grads = tuple(t if need else None for t, need in zip(gw, ctx.needs_input_grad[4:])) if need_w \
+            else (None,) * len(mlp)
+        # inputs: g, feat, want_feat, want_w, *mlp   (relu masks are piecewise constant: nothing flows to feat)
+        return (grad_g, None, None, None) + grads
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Tier B: the fused step as ONE autograd node (SURVEY.md §8b)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class ShineTrainStep(torch.autograd.Function):
+    """loss, pred, g = ShineTrainStep.apply(octree, decoder, opts, coord, sdf_label, weight, extras, *F_levels, *mlp6)
+
+    query_feature + Decoder.sdf + sdf_bce_loss (+ get_gradient and the eikonal term) of shine_batch.py:123-185 as one
+    node of the autograd graph.  forward launches the fused HIP kernel, which computes the loss AND every gradient in
+    the same pass into private dense buffers; backward multiplies them by d(total)/d(loss) and hands them to autograd,
+    which accumulates into `.grad` exactly as for the reference's composite (so `opt.zero_grad(); loss.backward();
+    opt.step()` of shine_batch.py:208-210 is unchanged).  `pred` and `g` are returned for logging / other loss terms
+    but carry no gradient (the fused node already accounts for the BCE and eikonal terms)."""
+
+    @staticmethod
+    def forward(ctx, octree, decoder, opts, coord, sdf_label, weight, extras, *params):
+        from .ops import _fused_launch
+
+        L = octree.featured_level_num
+        feats, mlp = params[:L], params[L:]
+        need_f = [bool(x) for x in ctx.needs_input_grad[7:7 + L]]
+        need_m = any(ctx.needs_input_grad[7 + L:])
+        dev = feats[0].device
+        # one private flat buffer for every gradient of this node: a single fill, a single scale in backward
+        sizes = [p.numel() if nf else 0 for p, nf in zip(feats, need_f)] + [p.numel() if need_m else 0 for p in mlp]
+        flat = torch.zeros((sum(sizes) + 3) // 4 * 4, dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for p, sz in zip(params, sizes):
+            views.append(flat[off:off + sz].view_as(p) if sz else None)
+            off += sz
+        loss, pred, g = _fused_launch(octree, decoder, coord, sdf_label, weight, opts, gfeat=views[:L],
+                                      gmlp=views[L:] if need_m else [None] * 6, dec_grad=need_m, **extras)
+        ctx.flat, ctx.views = flat, views
+        ctx.mark_non_differentiable(pred)
+        if g is None:
+            g = torch.zeros((0, 3), dtype=torch.float32, device=dev)
+        ctx.mark_non_differentiable(g)
+        return loss.to(torch.float32), pred, g
+
+    @staticmethod
+    def backward(ctx, grad_loss, _gp, _gg):
+        flat, views = ctx.flat, ctx.views
+        ctx.flat = ctx.views = None  # single use, like autograd's own buffers
+        if flat is None:
+            raise RuntimeError("ShineTrainStep: backward through the fused node a second time (its buffers are freed)")
+        flat.mul_(grad_loss.to(torch.float32))
+        return (None,) * 7 + tuple(views)

@@ -141,6 +141,23 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // hardware fp32 atomic add (global_atomic_add_f32), no CAS loop
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
+// ---- lane-per-point kernels (shine_step_v0.hip, shine_mlp.hip): decoder weight grads contract over POINTS; the
+//      per-point vectors of one wave are staged in LDS as [64 points][ST] and every lane owns a few output entries.
+constexpr int ST = 75;  // staging row stride in floats (odd -> conflict-free column writes)
+
+// contraction over the 64 staged points: acc[q] += left[p][j] * right[p][rb+q]
+template <int NQ>
+__device__ __forceinline__ void contract64(const float* st, int j, int rb, float (&acc)[NQ], float& acc_left,
+                                           bool with_bias) {
+  for (int p = 0; p < 64; ++p) {
+    const float* row = st + p * ST;
+    float l = row[j];
+    if (with_bias) acc_left += l;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = fmaf(l, row[rb + q], acc[q]);
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 }  // namespace shine

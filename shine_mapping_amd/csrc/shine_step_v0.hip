@@ -17,7 +17,6 @@
 
 namespace shine {
 
-constexpr int ST = 75;  // staging row stride in floats (odd -> conflict-free column writes)
 
 struct StepArgs {
   LevelSet ls;
@@ -49,19 +48,6 @@ __device__ __forceinline__ void load_mlp_to_lds(const StepArgs& a, float* s_mlp,
   for (int i = tid; i < H; i += nthreads) s_mlp[MLP_B2 + i] = a.mlp[3][i];
   for (int i = tid; i < H; i += nthreads) s_mlp[MLP_W3 + i] = a.mlp[4][i];
   if (tid == 0) s_mlp[MLP_B3] = a.mlp[5][0];
-}
-
-// contraction over the 64 staged points: acc[q] += left[p][j] * right[p][rb+q]
-template <int NQ>
-__device__ __forceinline__ void contract64(const float* st, int j, int rb, float (&acc)[NQ], float& acc_left,
-                                           bool with_bias) {
-  for (int p = 0; p < 64; ++p) {
-    const float* row = st + p * ST;
-    float l = row[j];
-    if (with_bias) acc_left += l;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = fmaf(l, row[rb + q], acc[q]);
-  }
 }
 
 template <bool POLY, bool EIK, bool TRAIN>

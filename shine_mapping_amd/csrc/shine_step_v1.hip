@@ -908,8 +908,10 @@ __global__ __launch_bounds__(256) void k_mark_touched(V1Args a) {
   if (i >= a.n) return;
   const int L = a.n_levels;
   float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+  const long long p = a.perm ? (long long)a.perm[i] : i;
+  // slots are in VISITING order for a planned batch, but indexed by pool sample id in pool mode (like the main kernel)
+  const long long si = a.pool_mode ? p : i;
   if (!a.slots) {
-    const long long p = a.perm ? (long long)a.perm[i] : i;
     x0 = a.coord[3 * p];
     x1 = a.coord[3 * p + 1];
     x2 = a.coord[3 * p + 2];
@@ -918,7 +920,7 @@ __global__ __launch_bounds__(256) void k_mark_touched(V1Args a) {
     if (!a.touched[s]) continue;
     int sl;
     if (a.slots) {
-      sl = a.slots[i * L + s];
+      sl = a.slots[si * L + s];
     } else {
       LevelDev Lv = {};
       Lv.keys = a.lv[s].keys;

@@ -2,10 +2,12 @@
 
 Same constructor signature, same sub-module names (so ``pretrained/geo_decoder_8dim.pth`` and the
 reference's checkpoints load with ``load_state_dict``): ``layers.{0,1}``, ``lout``, ``nclass_out``.
-`sdf` stays a differentiable torch composite for the strict drop-in tier (it is three tiny GEMMs and
-must be twice differentiable for get_gradient, utils/tools.py:175-185); the benchmarked tier never
-calls it — the fused HIP step reads the six parameter tensors directly (ops.fused_train_step).
-The out-of-scope heads (time-conditioned, semantic; flags off in every shipped yaml) are plain torch.
+`sdf` is a twice-differentiable HIP op (autograd_ops.FusedMLP: forward, backward and backward-of-backward are
+one launch each — get_gradient(create_graph=True), utils/tools.py:175-185, differentiates it twice) for the
+decoder shape every shipped config uses (8 -> 32 -> 32 -> 1 with bias) on CUDA float32 input; the benchmarked
+tier never calls it — the fused HIP step reads the six parameter tensors directly (ops.train_step).
+The out-of-scope heads (time-conditioned, semantic; flags off in every shipped yaml) and other decoder shapes
+are plain torch composites, as in the reference.
 """
 import torch
 import torch.nn as nn
@@ -38,7 +40,11 @@ class Decoder(nn.Module):
 
     # model/decoder.py:49-63
     def sdf(self, sum_features):
-        h = sum_features
+        if self.fusable and sum_features.is_cuda and sum_features.dtype == torch.float32 and sum_features.dim() == 2:
+            from .autograd_ops import FusedMLP
+
+            return FusedMLP.apply(sum_features, *self.fused_params())
+        h = sum_features  # other shapes / devices: the reference's composite
         for l in self.layers:
             h = F.relu(l(h))
         return self.lout(h).squeeze(1)

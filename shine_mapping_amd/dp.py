@@ -82,9 +82,10 @@ def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
     lib = _lib.lib()
     stream = _lib.current_stream_handle()
     wide = sum(cfg.sort_bits) > 32 or min(cfg.sort_bits) <= 0
-    key = (str(coord.device), n, wide)
+    # rocPRIM's scratch depends on the number of key bits (onesweep passes), which grows with the map's bounding box
+    key = (str(coord.device), n, wide, tuple(cfg.sort_bits))
     ent = _WS.get(key)
-    if ent is None:  # size query once per (device, batch size, key width); the buffer is reused every iteration
+    if ent is None:  # size query once per (device, batch size, key bits); the buffer is reused every iteration
         need = C.c_size_t(0)
         _lib.check(lib.shine_morton_sort(C.byref(cfg), None, n, None, None, C.byref(need), stream),
                    "shine_morton_sort")

@@ -541,8 +541,45 @@ class FeatureOctree(nn.Module):
         return state
 
     def __setstate__(self, state):
+        if "_node_keys" not in state and "nodes_lookup_tables" in state:
+            return self._adopt_reference_state(state)
         self.__dict__.update(state)
         self.rebuild_device_tables()
+
+    def _adopt_reference_state(self, state):
+        """Unpickling a checkpoint the REFERENCE wrote (utils/tools.py:200-213 pickles its whole FeatureOctree module;
+        with shine_mapping_amd.dropin installed the class path resolves here).  Its __dict__ carries the plain python
+        dict tables (model/feature_octree.py:47-52); they go through load_tables().  One-way: a pickle written by this
+        class names shine_mapping_amd.feature_octree.FeatureOctree and needs this package to load."""
+        state = dict(state)
+        nodes = state.pop("nodes_lookup_tables")
+        state.pop("corners_lookup_tables", None)  # re-derived from the node tables (same ids)
+        self.__dict__.update(state)
+        L = self.featured_level_num
+        if self.feature_dim != _lib.FEATURE_DIM:
+            raise NotImplementedError("libshine_hip is built for feature_dim == 8 (every shipped config)")
+        self._node_keys = [np.zeros(0, np.int64) for _ in range(L)]
+        self._node_ids = [np.zeros((0, 8), np.int32) for _ in range(L)]
+        self._node_sorted = [np.zeros(0, np.int64) for _ in range(L)]
+        self._corner_lex = [np.zeros(0, np.int64) for _ in range(L)]
+        self._corner_id_of_lex = [np.zeros(0, np.int64) for _ in range(L)]
+        self._corner_count = [0] * L
+        self._dict_cache = self._sort_box_cache = self._tables = self._box = None
+        self._ranks_uploaded = False
+        self._n_buckets = 0
+        self._tables_epoch = 0
+        self._pending = [[] for _ in range(L)]
+        self._dev_log = [[] for _ in range(L)]
+        self._corners_on_device = False
+        # features_last_frame as pickled are plain tensors: the attached-clone quirk (:160) does not survive a pickle
+        self._reg_grad_on = [True] * L
+        tables = []
+        for s in range(L):
+            tab = nodes[self.free_level_num + s]
+            keys = torch.tensor(list(tab.keys()), dtype=torch.int64)
+            ids = torch.tensor(list(tab.values()), dtype=torch.int32).reshape(-1, 8)
+            tables.append((keys, ids))
+        self.load_tables(tables)
 
     def rebuild_device_tables(self):
         """Drop the library handle; it is re-created from the host copies at the next query / device update

@@ -90,13 +90,42 @@ def forward_sdf(octree, decoder, coord, want_feat=False, want_indices=False, wan
 def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
                      n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None,
                      pool=None, idx: Optional[torch.Tensor] = None):
-    """One training iteration's forward+backward (no optimiser): the fused Tier-B step.
+    """One training iteration's forward+backward (no optimiser): the fused Tier-B step, raw form.
 
     coord [N,3], sdf_label [N], weight [N] (sign: + surface / - free space, utils/data_sampler.py:102-103).
     Accumulates into ``.grad`` of octree.hier_features[*] and the six decoder tensors (dense, trash row
     included — what ``cur_loss.backward()`` produces, shine_batch.py:209).  Returns (loss, pred, g) where
-    loss is a 0-dim float64 device tensor (no host sync) and g = get_gradient(coord,pred)*sigma or None.
+    loss is a 0-dim float64 device tensor (no host sync, NO grad_fn — the gradients are already in place) and
+    g = get_gradient(coord,pred)*sigma or None.  `train_step` is the same launch as an autograd node.
     """
+    return _fused_launch(octree, decoder, coord, sdf_label, weight, opts, want_grad_x=want_grad_x, perm=perm,
+                         n_surf=n_surf, slots=slots, touched=touched, pool=pool, idx=idx)
+
+
+def train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
+               n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None,
+               pool=None, idx: Optional[torch.Tensor] = None):
+    """The fused step as ONE node of the autograd graph (autograd_ops.ShineTrainStep; SURVEY.md §8b Tier B):
+
+        loss, pred, g = train_step(octree, geo_mlp, coord, sdf_label, weight, opts)
+        opt.zero_grad(set_to_none=True); loss.backward(); opt.step()          # shine_batch.py:208-210, unchanged
+
+    `loss` (0-dim float32, requires grad) = sdf_bce_loss [+ weight_e * eikonal]; other terms (e.g. lambda *
+    cal_regularization, shine_incre.py:156-158) can be added to it before backward().  Same keyword arguments as
+    fused_train_step.  When nothing requires grad (or under torch.no_grad) it degenerates to a forward pass."""
+    from .autograd_ops import ShineTrainStep
+
+    params = list(octree.feature_list()) + list(decoder.fused_params())
+    extras = dict(want_grad_x=want_grad_x, perm=perm, n_surf=n_surf, slots=slots, touched=touched, pool=pool, idx=idx)
+    loss, pred, g = ShineTrainStep.apply(octree, decoder, opts, coord, sdf_label, weight, extras, *params)
+    return loss, pred, (g if g.numel() else None)
+
+
+def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
+                  n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None,
+                  pool=None, idx: Optional[torch.Tensor] = None, gfeat=None, gmlp=None, dec_grad=None):
+    """shine_train_step on explicit gradient buffers (gfeat: L tensors or None entries, gmlp: 6 tensors; default: the
+    parameters' own dense `.grad`)."""
     t = octree._require_tables()
     pool_mode = pool is not None
     if pool_mode:  # batch = pool[idx] with idx sorted (sampler.SortedPool.draw): read straight out of the pool
@@ -118,7 +147,8 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
         raise ValueError("loss_reduction must be 'mean' or 'sum'")
     n_global = int(opts.n_global) if opts.n_global else n
     params = decoder.fused_params()
-    dec_grad = opts.decoder_grad_on
+    if dec_grad is None:
+        dec_grad = opts.decoder_grad_on
     if dec_grad is None:
         dec_grad = any(p.requires_grad for p in params)
     cfg = octree.step_config(
@@ -133,14 +163,16 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     pred = torch.empty(n, dtype=torch.float32, device=dev)
     gx = torch.empty((n, 3), dtype=torch.float32, device=dev) if (want_grad_x and eik) else None
     loss_parts = torch.empty(4, dtype=torch.float64, device=dev)  # overwritten by the step; set_zero is in-kernel
-    gfeat = [_dense_grad(p) if p.requires_grad else None for p in octree.feature_list()]
-    gmlp = [_dense_grad(p) for p in params] if dec_grad else [None] * 6
+    if gfeat is None:
+        gfeat = [_dense_grad(p) if p.requires_grad else None for p in octree.feature_list()]
+    if gmlp is None:
+        gmlp = [_dense_grad(p) for p in params] if dec_grad else [None] * 6
     if perm is not None and not (perm.is_cuda and perm.dtype == torch.int32 and perm.numel() == n):
         raise ValueError("perm must be a CUDA int32 tensor of N entries")
     if slots is not None and not pool_mode and not (perm is not None and slots.is_cuda and slots.dtype == torch.int32
                                                     and slots.numel() == n * octree.featured_level_num):
         raise ValueError("slots must come with perm from dp.plan_batch: CUDA int32 [N, L]")
-    ws = _workspace(dev, int(_lib.lib().shine_train_step_workspace_bytes(C.byref(cfg), n)))
+    ws = _workspace(dev, cfg)
     _lib.check(
         _lib.lib().shine_train_step(
             t.handle, C.byref(cfg), coord.data_ptr(), sdf_label.data_ptr(),
@@ -198,11 +230,16 @@ _DUMMY = {}
 _WORKSPACE = {}
 
 
-def _workspace(dev, nbytes):
-    """Scratch for the fused step, owned by torch's caching allocator and reused across iterations."""
+def _workspace(dev, cfg):
+    """Scratch for the fused step (per-workgroup partial sums), one buffer per device for the life of the process.
+
+    It is allocated ONCE at the size of the largest launch geometry (the workgroup count is capped at one per CU, so
+    the bound is ~1.5 MB) and never replaced: a captured HIP graph (loop.GraphedIteration, bench.py) bakes its address
+    in, so swapping it for a bigger one later would leave the graph writing into freed memory."""
     key = str(dev)
     ws = _WORKSPACE.get(key)
-    if ws is None or ws.numel() < nbytes:
+    if ws is None:
+        nbytes = int(_lib.lib().shine_train_step_workspace_bytes(C.byref(cfg), 1 << 40))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         _WORKSPACE[key] = ws
     return ws

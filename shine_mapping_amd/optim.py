@@ -26,6 +26,7 @@ class FusedAdam:
         self.eps = eps
         self.step_count = 0
         self.state = {}
+        self._age = {}  # per-tensor step count, like torch.optim.Adam's state[p]["step"] (bias correction is per tensor)
         self._dev = None  # (step_state int64[2], lr float[n]) for graph-replayable steps
 
     def _tensors(self):
@@ -71,7 +72,11 @@ class FusedAdam:
         if not ts:
             return
         n = len(ts)
+        ages = [self._age.get(t[0], 0) for t in ts]
         if graph_safe:
+            if len(set(ages)) != 1 or (self._dev is None and ages[0] != self.step_count):
+                raise NotImplementedError("graph-replayable FusedAdam steps need all tensors to have the same age "
+                                          "(a parameter that started receiving grads later: use eager steps)")
             dev = ts[0][0].device
             if self._dev is None or self._dev[1].numel() != n:
                 self._dev = (torch.tensor([self.step_count, 0], dtype=torch.int64, device=dev),
@@ -92,9 +97,23 @@ class FusedAdam:
             )
             return
         if self._dev is not None:  # continue the count a graph advanced on the device
-            self.step_count = self.steps_taken()
+            taken = self.steps_taken()
+            for t in ts:
+                self._age[t[0]] = self._age.get(t[0], 0) + (taken - self.step_count)
+            self.step_count = taken
             self._dev = None
+            ages = [self._age.get(t[0], 0) for t in ts]
         self.step_count += 1
+        if len(set(ages)) > 1:  # torch.optim.Adam semantics: one launch per distinct age (normally there is one)
+            for age in sorted(set(ages)):
+                self._launch([t for t, a in zip(ts, ages) if a == age], age + 1, zero_grad)
+        else:
+            self._launch(ts, ages[0] + 1, zero_grad)
+        for t in ts:
+            self._age[t[0]] = self._age.get(t[0], 0) + 1
+
+    def _launch(self, ts, step, zero_grad):
+        n = len(ts)
         if n > 16:
             raise NotImplementedError("FusedAdam handles up to 16 tensors (decoder 6 + feature levels)")
         for p, m, v, _, _ in ts:
@@ -107,7 +126,7 @@ class FusedAdam:
                 n, _lib.ptr_array([t[0].data_ptr() for t in ts]), _lib.ptr_array([t[0].grad.data_ptr() for t in ts]),
                 _lib.ptr_array([t[1].data_ptr() for t in ts]), _lib.ptr_array([t[2].data_ptr() for t in ts]),
                 _lib.i64_array([t[0].numel() for t in ts]), lr, wd, float(self.betas[0]), float(self.betas[1]),
-                float(self.eps), self.step_count, 1 if zero_grad else 0, _lib.current_stream_handle(),
+                float(self.eps), int(step), 1 if zero_grad else 0, _lib.current_stream_handle(),
             ),
             "shine_adam_step",
         )

@@ -20,7 +20,7 @@ class SortedPool:
         self.octree = octree
         self.seed = int(seed)
         self.draws = 0
-        self._ws = None
+        self._ws = {}  # per batch size, never replaced: captured HIP graphs bake the address in
         self._stream_state = None  # device uint64[2] for graph-replayable draws (loop.GraphedIteration)
         self.rebuild(coord, sdf_label, weight)
 
@@ -41,26 +41,28 @@ class SortedPool:
         dev = self.coord.device
         lib = _lib.lib()
         stream = _lib.current_stream_handle()
-        if self._ws is None or self._ws[1] != n:
+        ws = self._ws.get((n, self.size))
+        if ws is None:
             need = C.c_size_t(0)
             _lib.check(lib.shine_sample_sorted(self.size, n, self.seed, 0, None, None, 0, None, C.byref(need), stream),
                        "shine_sample_sorted")
-            self._ws = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev), n, int(need.value))
+            ws = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev), n, int(need.value))
+            self._ws[(n, self.size)] = ws
         idx = out if out is not None else torch.empty(n, dtype=torch.int32, device=dev)
-        need = C.c_size_t(self._ws[2])
+        need = C.c_size_t(ws[2])
         if graph_safe:
             if self._stream_state is None:
                 self._stream_state = torch.tensor([self.draws, 0], dtype=torch.int64, device=dev)
             _lib.check(lib.shine_sample_sorted_dev(self.size, n, self.seed, self._stream_state.data_ptr(), idx.data_ptr(),
                                                    zero.data_ptr() if zero is not None else None,
                                                    zero.numel() * zero.element_size() if zero is not None else 0,
-                                                   self._ws[0].data_ptr(), C.byref(need), stream),
+                                                   ws[0].data_ptr(), C.byref(need), stream),
                        "shine_sample_sorted_dev")
             return idx
         _lib.check(lib.shine_sample_sorted(self.size, n, self.seed, self.draws, idx.data_ptr(),
                                            zero.data_ptr() if zero is not None else None,
                                            zero.numel() * zero.element_size() if zero is not None else 0,
-                                           self._ws[0].data_ptr(), C.byref(need), stream), "shine_sample_sorted")
+                                           ws[0].data_ptr(), C.byref(need), stream), "shine_sample_sorted")
         self.draws += 1
         return idx
 

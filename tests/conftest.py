@@ -62,3 +62,24 @@ def product_from_golden(fx, device="cuda"):
     dec = Decoder(cfg)
     dec.load_state_dict(fx["decoder"], strict=False)
     return cfg, octree, dec
+
+
+def oracle_from_product(octree, dec, cfg):
+    """The CPU oracle loaded with a PRODUCT octree's tables / features and decoder weights (synthetic workloads built by
+    shine_mapping_amd.synth): lets the at-scale GPU tests compare with the oracle on workloads no fixture holds."""
+    from oracle import shine_oracle as so
+
+    ocfg = so.make_config(tree_level_world=cfg.tree_level_world, tree_level_feat=cfg.tree_level_feat,
+                          leaf_vox_size=cfg.leaf_vox_size, sigma_sigmoid_m=cfg.sigma_sigmoid_m,
+                          ekional_loss_on=cfg.ekional_loss_on, weight_e=cfg.weight_e, poly_int_on=cfg.poly_int_on,
+                          loss_reduction=cfg.loss_reduction, lambda_forget=getattr(cfg, "lambda_forget", 0.0))
+    oct_ = so.OracleOctree(ocfg)
+    for lvl, tab in enumerate(octree.nodes_lookup_tables):
+        oct_.node_table[lvl] = tab
+    oct_.hier_features = [p.detach().cpu().clone().requires_grad_(True) for p in octree.hier_features]
+    if len(octree.importance_weight):
+        oct_.importance_weight = [t.detach().cpu().clone() for t in octree.importance_weight]
+        oct_.features_last_frame = [t.detach().cpu().clone() for t in octree.features_last_frame]
+    mlp = so.OracleDecoder(ocfg)
+    mlp.load_state_dict({k: v.detach().cpu() for k, v in dec.state_dict().items()})
+    return ocfg, oct_, mlp

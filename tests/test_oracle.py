@@ -239,3 +239,49 @@ def test_oracle_mesher_query_matches_reference_fixture(name):
     assert np.array_equal(sdf.astype("float32"), fx["sdf_pred"].numpy())
     assert np.array_equal(mask.astype("uint8"), fx["mc_mask"].numpy())
     assert 0 < int(mask.sum()) < mask.size
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_import.available(), reason="needs /root/reference (authoring container)")
+def test_reference_pickled_octree_loads_through_the_dropin(tmp_path):
+    """utils/tools.py:200-213 pickles the reference's whole FeatureOctree; with shine_mapping_amd.dropin installed the
+    class path resolves to ours and __setstate__ adopts the reference's dict tables (ids and insertion order kept)."""
+    import subprocess, sys, os, json
+
+    R = ref_import.install()
+    fx = load_golden("maicity_bce_L3")
+    cfg = R.SHINEConfig()
+    for k, v in fx["cfg"].items():
+        setattr(cfg, k, v)
+    cfg.device = "cpu"
+    cfg.calculate_world_scale() if hasattr(cfg, "calculate_world_scale") else None
+    ref_oct = R.FeatureOctree(cfg)
+    for sp in fx["surface_points"]:
+        ref_oct.update(sp, True)
+    path = os.path.join(str(tmp_path), "ckpt.pth")
+    torch.save({"feature_octree": ref_oct}, path)
+    L = ref_oct.featured_level_num
+    want = {str(lvl): {str(k): v for k, v in ref_oct.nodes_lookup_tables[lvl].items()}
+            for lvl in range(ref_oct.free_level_num, ref_oct.max_level + 1)}
+    code = (
+        "import json, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import shine_mapping_amd.dropin\n"
+        "o = torch.load(%r, map_location='cpu', weights_only=False)['feature_octree']\n"
+        "assert type(o).__module__ == 'shine_mapping_amd.feature_octree', type(o)\n"
+        "t = o.nodes_lookup_tables\n"
+        "out = {str(l): {str(k): v for k, v in t[l].items()} for l in range(o.free_level_num, o.max_level + 1)}\n"
+        "rows = [int(p.shape[0]) for p in o.hier_features]\n"
+        "print(json.dumps(dict(tables=out, rows=rows, corners=o._corner_count, imp=len(o.importance_weight))))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
+    env = dict(os.environ)
+    env.pop("PYTHONPATH", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["tables"] == want
+    for lvl in want:  # insertion order survives too (dicts keep it)
+        assert list(got["tables"][lvl]) == list(want[lvl])
+    assert got["rows"] == [int(p.shape[0]) for p in ref_oct.hier_features]
+    assert got["corners"] == [r_ - 1 for r_ in got["rows"]]
+    assert got["imp"] == L
