@@ -243,10 +243,9 @@ class ShineTrainStep(torch.autograd.Function):
         loss, pred, g = _fused_launch(octree, decoder, coord, sdf_label, weight, opts, gfeat=views[:L],
                                       gmlp=views[L:] if need_m else [None] * 6, dec_grad=need_m, **extras)
         ctx.flat, ctx.views = flat, views
-        ctx.mark_non_differentiable(pred)
         if g is None:
             g = torch.zeros((0, 3), dtype=torch.float32, device=dev)
-        ctx.mark_non_differentiable(g)
+        ctx.mark_non_differentiable(pred, g)  # (one call: a second call would replace the first)
         return loss.to(torch.float32), pred, g
 
     @staticmethod
