@@ -170,6 +170,17 @@ int shine_train_step(const shine_tables* t, const shine_step_config* cfg, const 
  * workspace may be NULL (or too small): the step then falls back to fp32 atomics for those sums. */
 size_t shine_train_step_workspace_bytes(const shine_step_config* cfg, int64_t n);
 
+/* measurement aid: what one shine_train_step launch of n points looks like.  out: int64[8] = {workgroups, waves,
+ * points per tile, MFMA FLOP issued per tile (padding included), LDS bytes per workgroup, useful decoder FLOP per point
+ * (SURVEY.md §8d), 0, 0}.  bench.py derives its `roofline.mfma_*` figures from these instead of hard-coding them. */
+int shine_train_step_info(const shine_step_config* cfg, int64_t n, int64_t* out);
+/* the stand-alone form of the `touched` pass of shine_train_step: mark (set to 1) in touched[s][rows_s] every feature row
+ * that the n samples address (perm / slots / cfg->sorted_input as for shine_train_step; coord may be NULL when slots are
+ * given).  Data-parallel ranks mark the rows of the GLOBAL draw with it (every rank derives the same set without a
+ * collective), then exchange only those rows (shine_mapping_amd/dp.py). */
+int shine_mark_touched(const shine_tables* t, const shine_step_config* cfg, const float* coord, const int32_t* perm,
+                       const int32_t* slots, int64_t n, const int64_t* rows, unsigned char* const* touched, void* stream);
+
 /* ---- Morton ordering of a batch: the new step right after LiDARDataset.get_batch
  *      (dataset/lidar_dataset.py:430-450).  perm_out[N] int32 = argsort of the leaf-level node keys, to be
  *      passed as `perm` to shine_train_step.  Call with workspace == NULL to get the required bytes. --- */

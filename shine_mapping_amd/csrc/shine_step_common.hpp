@@ -1,0 +1,160 @@
+// shine_step_common.hpp — what the fused-step kernels (shine_step_v1.hip: 32-point tiles; shine_step_v2.hip: 16-point
+// tiles) share: the kernel argument block, the layout of the per-workgroup partial vector that k_reduce_partials adds
+// up, and a few wave-level device helpers.
+#pragma once
+#include "shine_internal.hpp"
+
+namespace shine {
+
+constexpr int LCAP = 4;        // featured levels handled by the MFMA kernels (tree_level_feat <= 4 in every yaml)
+
+constexpr int PART_TRASH = SHINE_MLP_PARAMS;                     // + s*8 + q
+constexpr int PART_FLOATS = PART_TRASH + SHINE_MAX_LEVELS * 8;   // 1441
+constexpr int PART_LOSS = 1444;   // float index of double[3] {bce sum, count, eikonal sum} (8-B aligned)
+constexpr int PART_STRIDE = 1456;
+// MFMAs issued per 32-point tile (v_mfma_f32_32x32x2_f32): forward 4 + 16, backward 16 + 16, weight grads 16 + 16;
+// the eikonal build replaces the backward pair by the closed-form chain 16 + 16 + 4 + 16 (checked against the ISA)
+constexpr int MFMA_PER_TILE_BCE = 84, MFMA_PER_TILE_EIK = 104;
+
+// what the hot loop needs per level, nothing else (SGPR budget)
+struct V1Level {
+  const unsigned long long* keys;
+  const int4* vals;
+  const float* feat;
+  float* grad;
+  unsigned int shift, mask;
+  float res;
+  int pad;
+};
+
+struct V1Args {
+  V1Level lv[LCAP];
+  long long rows[LCAP];
+  float* feat_rw[LCAP];  // same tables, writable: the trash row is re-zeroed in-kernel (set_zero, :78-81)
+  unsigned char* touched[LCAP];  // optional byte flag per row that received gradient (for shine_regularize)
+  const float* coord;
+  const float* label;
+  const float* weight;
+  const int* perm;
+  const int* slots;  // [n][L] hash slots per point IN VISITING ORDER (shine_plan_batch), or null: probe in-kernel
+  const long long* n_surf;
+  const float* mlp[6];
+  float* pred;
+  float* grad_x;
+  float* grad_mlp[6];
+  double* loss_parts;
+  float* partials;
+  long long* prof;  // debug: per-wave phase cycle counters [waves][8] (shine_debug_set_profile_buffer) or null
+  long long n;
+  long long chunk;
+  int n_levels;
+  int reduction_sum;
+  int decoder_grad_on;
+  int poly;
+  int pool_mode;  // 1: coord/label/weight/slots are a node-ordered POOL indexed by perm[i] (sorted sample indices,
+                  //    shine_sample_sorted); pred / grad_x are written at the batch position i.  0: a batch.
+  int ablate;  // debug only (kernel_variant >> 8): 1 no feature atomics, 2 no weight-grad phase, 4 no scatter phase,
+               // 8 no row gathers, 16 no probe (every point misses), 32 skip the partial-sum reduction launch
+  float sigma;
+  float inv_n;
+  float weight_e;
+};
+
+__device__ __forceinline__ long long clk() { return (long long)__builtin_readcyclecounter(); }
+
+// wave-local LDS hand-off: DS ops of one wave execute in order; this only stops the compiler reordering them
+// (a workgroup-scope __builtin_amdgcn_fence would also drain vmcnt, i.e. wait for every gather/atomic in flight)
+__device__ __forceinline__ void wave_lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row (4 VALU ops, no LDS traffic)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+// d w_c / d x for ONE corner (keeps the eikonal path's live set small; corner_weight_grads builds all 24 values)
+__device__ __forceinline__ void corner_dw(const Axis& X, const Axis& Y, const Axis& Z, int c, float out[3]) {
+  const int cx = (c >> 2) & 1, cy = (c >> 1) & 1, cz = c & 1;
+  const float px = cx ? X.t : 1.0f - X.t, py = cy ? Y.t : 1.0f - Y.t, pz = cz ? Z.t : 1.0f - Z.t;
+  const float gx = cx ? X.dt : -X.dt, gy = cy ? Y.dt : -Y.dt, gz = cz ? Z.dt : -Z.dt;
+  out[0] = gx * py * pz;
+  out[1] = px * gy * pz;
+  out[2] = px * py * gz;
+}
+
+__device__ __forceinline__ Axis axis_weight_rt(bool poly, float x, float res) {
+  return poly ? axis_weight<true>(x, res, res * 0.5f) : axis_weight<false>(x, res, res * 0.5f);
+}
+
+// second stage of a fused step (shine_step_v1.hip): add `nblocks` per-workgroup partial vectors [PART_STRIDE floats each]
+// into the gradient tensors / loss, re-zero the trash rows (set_zero, model/feature_octree.py:78-81)
+__global__ void k_reduce_partials(V1Args a, int nblocks);
+__global__ void k_mark_touched(V1Args a);
+
+// host: fill everything of V1Args that does not depend on the launch geometry (argument checks included)
+inline int fill_step_args(V1Args* a, const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                          const float* sdf_label, const float* weight, const int32_t* perm, const int32_t* slots,
+                          const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,
+                          const float* const* mlp, float* pred_out, float* grad_x_out, float* const* grad_feats,
+                          float* const* grad_mlp, double* loss_parts, unsigned char* const* touched) {
+  if (n < 0 || !feats || !rows || !mlp || !grad_feats || (n > 0 && (!coord || !sdf_label)))
+    return set_error(SHINE_E_INVALID, "shine_train_step: null argument");
+  if (cfg->n_levels > LCAP) return set_error(SHINE_E_INVALID, "shine_train_step: the MFMA kernels handle up to 4 featured levels");
+  if (cfg->eikonal_on && (!weight || !n_surf))
+    return set_error(SHINE_E_INVALID, "shine_train_step: eikonal needs weight and n_surf");
+  LevelSet ls = {};
+  int rc = make_level_set(t, cfg, feats, rows, grad_feats, &ls);
+  if (rc != SHINE_OK) return rc;
+  for (int s = 0; s < cfg->n_levels; ++s) {
+    if (!feats[s]) return set_error(SHINE_E_INVALID, "shine_train_step: null feature level");
+    // the kernel addresses feature/grad rows with 32-bit float offsets off an SGPR base (one VGPR per address)
+    if (ls.lv[s].rows >= (1ll << 29)) return set_error(SHINE_E_INVALID, "shine_train_step: level exceeds 2^29 rows");
+    a->lv[s].keys = ls.lv[s].keys;
+    a->lv[s].vals = ls.lv[s].vals;
+    a->lv[s].feat = ls.lv[s].feat;
+    a->lv[s].grad = ls.lv[s].grad;
+    a->lv[s].shift = ls.lv[s].shift;
+    a->lv[s].mask = ls.lv[s].mask;
+    a->lv[s].res = ls.lv[s].res;
+    a->rows[s] = ls.lv[s].rows;
+    a->feat_rw[s] = const_cast<float*>(feats[s]);
+    a->touched[s] = touched ? touched[s] : nullptr;
+  }
+  for (int k = 0; k < 6; ++k) {
+    if (!mlp[k]) return set_error(SHINE_E_INVALID, "shine_train_step: null decoder parameter");
+    a->mlp[k] = mlp[k];
+    if (cfg->decoder_grad_on) {
+      if (!grad_mlp || !grad_mlp[k]) return set_error(SHINE_E_INVALID, "shine_train_step: null decoder grad");
+      a->grad_mlp[k] = grad_mlp[k];
+    }
+  }
+  a->coord = coord;
+  a->label = sdf_label;
+  a->weight = weight;
+  a->perm = perm;
+  a->slots = slots;
+  a->n_surf = cfg->eikonal_on ? reinterpret_cast<const long long*>(n_surf) : nullptr;
+  a->pred = pred_out;
+  a->grad_x = grad_x_out;
+  a->loss_parts = loss_parts;
+  a->n = n;
+  a->n_levels = cfg->n_levels;
+  a->reduction_sum = cfg->reduction_sum;
+  a->decoder_grad_on = cfg->decoder_grad_on;
+  a->poly = cfg->poly_int_on;
+  a->pool_mode = cfg->sorted_input == 2 ? 1 : 0;
+  if (a->pool_mode && !perm) return set_error(SHINE_E_INVALID, "shine_train_step: pool mode needs the sample indices in perm");
+  a->ablate = cfg->kernel_variant >> 8;
+  a->sigma = cfg->sigma;
+  a->inv_n = (float)cfg->inv_n;
+  a->weight_e = cfg->weight_e;
+  return SHINE_OK;
+}
+
+}  // namespace shine

@@ -31,13 +31,12 @@
 //     second tiny kernel adds them up (deterministic, no hot-spot atomics), re-zeroes the trash rows
 //     (set_zero, :78-81) and finalises the loss.
 // Workgroup = 512 threads (8 waves, 2 per SIMD), one per CU: 157 KB of LDS, 18 KB of it private to each wave.
-#include "shine_internal.hpp"
+#include "shine_step_common.hpp"
 
 namespace shine {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int LCAP = 4;        // featured levels handled by this kernel (tree_level_feat <= 4 in every yaml)
 constexpr int WAVES = 8;       // waves per workgroup
 constexpr int NT = WAVES * 64;
 constexpr int TP = 36;         // transpose tile pitch (floats): 16-B aligned rows for the b128 operand reads
@@ -50,60 +49,9 @@ constexpr int R2_FLOATS = 2 * 32 * TP;           // 2304
 constexpr int WAVE_FLOATS = U_IDS + U_W + R2_FLOATS;  // 4608 floats = 18,432 B per wave
 constexpr int OP_A1 = 0, OP_A2 = 4 * 64, OP_A2T = 20 * 64, OP_A1T = 36 * 64, OP_TOTAL = 52 * 64;
 constexpr int SB_B1 = 0, SB_B2 = 32, SB_W3 = 64, SB_B3 = 96;
-constexpr int PART_TRASH = SHINE_MLP_PARAMS;                     // + s*8 + q
-constexpr int PART_FLOATS = PART_TRASH + SHINE_MAX_LEVELS * 8;   // 1441
-constexpr int PART_LOSS = 1444;   // float index of double[3] {bce sum, count, eikonal sum} (8-B aligned)
-constexpr int PART_STRIDE = 1456;
-
 static_assert(16 * WP + LCAP * 8 * WP <= R2_FLOATS, "df/J/cq must fit the transpose region");
 static_assert((PART_LOSS * 4) % 8 == 0 && PART_LOSS >= PART_FLOATS && PART_LOSS + 6 <= PART_STRIDE, "loss slot");
 static_assert(PART_STRIDE <= WAVE_FLOATS, "each wave's partial vector aliases its staging region at the end");
-
-// what the hot loop needs per level, nothing else (SGPR budget)
-struct V1Level {
-  const unsigned long long* keys;
-  const int4* vals;
-  const float* feat;
-  float* grad;
-  unsigned int shift, mask;
-  float res;
-  int pad;
-};
-
-struct V1Args {
-  V1Level lv[LCAP];
-  long long rows[LCAP];
-  float* feat_rw[LCAP];  // same tables, writable: the trash row is re-zeroed in-kernel (set_zero, :78-81)
-  unsigned char* touched[LCAP];  // optional byte flag per row that received gradient (for shine_regularize)
-  const float* coord;
-  const float* label;
-  const float* weight;
-  const int* perm;
-  const int* slots;  // [n][L] hash slots per point IN VISITING ORDER (shine_plan_batch), or null: probe in-kernel
-  const long long* n_surf;
-  const float* mlp[6];
-  float* pred;
-  float* grad_x;
-  float* grad_mlp[6];
-  double* loss_parts;
-  float* partials;
-  long long* prof;  // debug: per-wave phase cycle counters [waves][8] (shine_debug_set_profile_buffer) or null
-  long long n;
-  long long chunk;
-  int n_levels;
-  int reduction_sum;
-  int decoder_grad_on;
-  int poly;
-  int pool_mode;  // 1: coord/label/weight/slots are a node-ordered POOL indexed by perm[i] (sorted sample indices,
-                  //    shine_sample_sorted); pred / grad_x are written at the batch position i.  0: a batch.
-  int ablate;  // debug only (kernel_variant >> 8): 1 no feature atomics, 2 no weight-grad phase, 4 no scatter phase,
-               // 8 no row gathers, 16 no probe (every point misses), 32 skip the partial-sum reduction launch
-  float sigma;
-  float inv_n;
-  float weight_e;
-};
-
-__device__ __forceinline__ long long clk() { return (long long)__builtin_readcyclecounter(); }
 
 __device__ __forceinline__ int rowidx(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -116,36 +64,6 @@ __device__ __forceinline__ f32x16 zero16() {
 #pragma unroll
   for (int r = 0; r < 16; ++r) z[r] = 0.f;
   return z;
-}
-
-// wave-local LDS hand-off: DS ops of one wave execute in order; this only stops the compiler reordering them
-// (a workgroup-scope __builtin_amdgcn_fence would also drain vmcnt, i.e. wait for every gather/atomic in flight)
-__device__ __forceinline__ void wave_lds_fence() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// sum over the 16 lanes of a DPP row, result in every lane of the row (4 VALU ops, no LDS traffic)
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-  return v;
-}
-
-// d w_c / d x for ONE corner (keeps the eikonal path's live set small; corner_weight_grads builds all 24 values)
-__device__ __forceinline__ void corner_dw(const Axis& X, const Axis& Y, const Axis& Z, int c, float out[3]) {
-  const int cx = (c >> 2) & 1, cy = (c >> 1) & 1, cz = c & 1;
-  const float px = cx ? X.t : 1.0f - X.t, py = cy ? Y.t : 1.0f - Y.t, pz = cz ? Z.t : 1.0f - Z.t;
-  const float gx = cx ? X.dt : -X.dt, gy = cy ? Y.dt : -Y.dt, gz = cz ? Z.dt : -Z.dt;
-  out[0] = gx * py * pz;
-  out[1] = px * gy * pz;
-  out[2] = px * py * gz;
-}
-
-__device__ __forceinline__ Axis axis_weight_rt(bool poly, float x, float res) {
-  return poly ? axis_weight<true>(x, res, res * 0.5f) : axis_weight<false>(x, res, res * 0.5f);
 }
 
 // one transposed weight-grad pass: acc[i][j] += sum_k L[i][k] * R[j][k] over the tile's 32 points.
@@ -221,7 +139,9 @@ __device__ __forceinline__ void issue_row_gathers(const float* feat, const int4&
   }
 }
 
-template <int L, bool EIK, bool PROF>
+// ABL: the measurement build honours the `ablate` debug bits (tools/ablate.py); in the product instantiation
+// (ABL = false) they are compile-time zero and every test on them folds away.
+template <int L, bool EIK, bool PROF, bool ABL>
 __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   __shared__ float s_opA[OP_TOTAL];
   __shared__ float s_bias[100];
@@ -231,6 +151,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pt = lane & 31, h = lane >> 5;
   const bool poly = a.poly != 0;
+  const int ablate = ABL ? a.ablate : 0;
   long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tk = PROF ? clk() : 0;
 #define SHINE_STAMP(k)            \
@@ -362,7 +283,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
     int slot[LCAP];
     if (a.slots) {  // planned batch: the slots were found by shine_plan_batch (wave-uniform branch)
 #pragma unroll
-      for (int s = 0; s < L; ++s) slot[s] = (valid && !(a.ablate & 16)) ? pslot[s] : -1;
+      for (int s = 0; s < L; ++s) slot[s] = (valid && !(ablate & 16)) ? pslot[s] : -1;
     } else {
     unsigned long long key[LCAP];
     unsigned int slot0[LCAP];
@@ -395,7 +316,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
           q = (q + 1) & Lv.mask;
         }
       }
-      slot[s] = (valid && !(a.ablate & 16)) ? sl : -1;
+      slot[s] = (valid && !(ablate & 16)) ? sl : -1;
     }
     }
     int4 i0[LCAP], i1[LCAP];
@@ -410,7 +331,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
       // All 8 gathers of a level are issued before the first is consumed (issue_row_gathers).  Issuing level s+1's
       // as well before level s is consumed (a second row buffer) spills: +6 % time on the BCE build (A/B, tools/ab_build.py).
       float4 rowbuf[8];
-      const bool gather_on = !(a.ablate & 8);
+      const bool gather_on = !(ablate & 8);
 #pragma unroll
       for (int s = 0; s < L; ++s) {
         const V1Level& Lv = a.lv[s];
@@ -534,7 +455,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
     SHINE_STAMP(3)  // loss + decoder backward
 
     // ================================================================ phase 5: decoder weight grads (transposed MFMA)
-    if (a.decoder_grad_on && !(a.ablate & 2)) {
+    if (a.decoder_grad_on && !(ablate & 2)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         TL[rowidx(r, h) * TP + pt] = d2[r];
@@ -557,7 +478,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
     // ================================================================ phase 2: decoder forward (MFMA chain)
     // Activations are retired as early as possible (register budget): h1 goes to its transpose tile (TR) as soon as
     // layer 2 has consumed it, d2 to TL right after the loss; only the ReLU masks stay, as 16-bit lane masks.
-    const bool wg = a.decoder_grad_on && !(a.ablate & 2);
+    const bool wg = a.decoder_grad_on && !(ablate & 2);
     f32x16 c1, c2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -697,7 +618,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
     // stage df [feature][pt] (and, EIK, J and cq = sigma * (d w_c / d x . q)) in region 2, then
     // lane = (corner sc, feature sq): run boundaries / hits are wave-uniform bit masks (scalar branches only);
     // one 64-lane atomic (8 rows x 32 B) per node run, misses go to a register sum.
-    if (!(a.ablate & 4)) {
+    if (!(ablate & 4)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) R2[R2_DF + (4 * h + q) * WP + pt] = df4[q];
       if (EIK) {
@@ -784,7 +705,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
             float racc = run_acc[s];
             const unsigned int cm = (chgmask[s] & validmask) >> (CH * ch);
             // (debug bit 1, "no atomics", is folded into the hit mask: no test inside the loop)
-            const unsigned int hm = (a.ablate & 1) ? 0u : hitmask[s] >> (CH * ch);
+            const unsigned int hm = (ablate & 1) ? 0u : hitmask[s] >> (CH * ch);
 #pragma unroll
             for (int p2 = 0; p2 < CH; ++p2) {
               if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
@@ -1061,15 +982,19 @@ template <bool EIK>
 static void launch_v1(const V1Args& a0, int levels, dim3 grid, hipStream_t st) {
   V1Args a = a0;
   if (a.prof && levels == 4) {  // debug build of the same kernel with s_memtime stamps per phase
-    hipLaunchKernelGGL((k_step_v1<4, EIK, true>), grid, dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((k_step_v1<4, EIK, true, true>), grid, dim3(NT), 0, st, a);
     return;
   }
   a.prof = nullptr;
+  if ((a.ablate & 31) && levels == 4) {  // measurement build that honours the ablation bits (4 levels only)
+    hipLaunchKernelGGL((k_step_v1<4, EIK, false, true>), grid, dim3(NT), 0, st, a);
+    return;
+  }
   switch (levels) {  // the level count is a template parameter: straight-line query code, no guards
-    case 1: hipLaunchKernelGGL((k_step_v1<1, EIK, false>), grid, dim3(NT), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_step_v1<2, EIK, false>), grid, dim3(NT), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((k_step_v1<3, EIK, false>), grid, dim3(NT), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_step_v1<4, EIK, false>), grid, dim3(NT), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((k_step_v1<1, EIK, false, false>), grid, dim3(NT), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_step_v1<2, EIK, false, false>), grid, dim3(NT), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_step_v1<3, EIK, false, false>), grid, dim3(NT), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_step_v1<4, EIK, false, false>), grid, dim3(NT), 0, st, a); break;
   }
 }
 
@@ -1081,6 +1006,54 @@ extern "C" size_t shine_train_step_workspace_bytes(const shine_step_config* cfg,
   (void)cfg;
   if (n <= 0) return 0;
   return (size_t)v1_geometry(n).blocks * PART_STRIDE * sizeof(float);
+}
+
+// what one launch does, for measurement (bench.py's roofline object): out[0] workgroups, out[1] waves, out[2] points per
+// tile, out[3] MFMA FLOP issued per tile (padding included), out[4] LDS bytes per workgroup, out[5] useful decoder FLOP
+// per point (3 x 2624 BCE, 6 x 2624 with the eikonal term)
+extern "C" int shine_train_step_info(const shine_step_config* cfg, int64_t n, int64_t* out) {
+  if (!cfg || !out) return set_error(SHINE_E_INVALID, "shine_train_step_info: null argument");
+  const V1Geometry g = v1_geometry(n > 0 ? n : 1);
+  out[0] = g.blocks;
+  out[1] = g.waves;
+  out[2] = 32;
+  out[3] = (long long)(cfg->eikonal_on ? MFMA_PER_TILE_EIK : MFMA_PER_TILE_BCE) * 4096;  // 32x32x2 MFMA = 4096 FLOP
+  out[4] = (long long)(sizeof(float) * (OP_TOTAL + 100 + WAVES * WAVE_FLOATS) + 4 * sizeof(double));
+  out[5] = cfg->eikonal_on ? 6 * 2624 : 3 * 2624;
+  return SHINE_OK;
+}
+
+// rows a set of pool samples touches (the unique() of their hierarchical_indices without -1), marked in byte flags:
+// the stand-alone form of the pass shine_train_step runs when it is given `touched` — for data-parallel ranks that mark
+// the rows of the GLOBAL draw, not only of their own slice (shine_mapping_amd/dp.py TouchedRowReducer).
+extern "C" int shine_mark_touched(const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                                  const int32_t* perm, const int32_t* slots, int64_t n, const int64_t* rows,
+                                  unsigned char* const* touched, void* stream) {
+  if (!cfg || !touched || n < 0 || (!slots && !coord)) return set_error(SHINE_E_INVALID, "shine_mark_touched: null argument");
+  if (cfg->n_levels > LCAP) return set_error(SHINE_E_INVALID, "shine_mark_touched: more than 4 featured levels");
+  if (n == 0) return SHINE_OK;
+  V1Args a = {};
+  LevelSet ls = {};
+  int rc = make_level_set(t, cfg, nullptr, rows, nullptr, &ls);
+  if (rc != SHINE_OK) return rc;
+  for (int s = 0; s < cfg->n_levels; ++s) {
+    a.lv[s].keys = ls.lv[s].keys;
+    a.lv[s].vals = ls.lv[s].vals;
+    a.lv[s].shift = ls.lv[s].shift;
+    a.lv[s].mask = ls.lv[s].mask;
+    a.lv[s].res = ls.lv[s].res;
+    a.touched[s] = touched[s];
+  }
+  a.coord = coord;
+  a.perm = perm;
+  a.slots = slots;
+  a.n = n;
+  a.n_levels = cfg->n_levels;
+  a.pool_mode = cfg->sorted_input == 2 ? 1 : 0;
+  if (a.pool_mode && !perm) return set_error(SHINE_E_INVALID, "shine_mark_touched: pool mode needs the sample indices");
+  hipLaunchKernelGGL(k_mark_touched, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
 }
 
 static long long* g_prof_buffer = nullptr;
@@ -1101,62 +1074,14 @@ extern "C" int shine_train_step_v1(const shine_tables* t, const shine_step_confi
                                    float* const* grad_feats, float* const* grad_mlp, double* loss_parts,
                                    unsigned char* const* touched, void* workspace, size_t workspace_bytes,
                                    void* stream) {
-  if (n < 0 || !feats || !rows || !mlp || !grad_feats || (n > 0 && (!coord || !sdf_label)))
-    return set_error(SHINE_E_INVALID, "shine_train_step: null argument");
-  if (cfg->n_levels > LCAP) return set_error(SHINE_E_INVALID, "shine_train_step_v1: more than 4 featured levels");
-  if (cfg->eikonal_on && (!weight || !n_surf))
-    return set_error(SHINE_E_INVALID, "shine_train_step: eikonal needs weight and n_surf");
   V1Args a = {};
-  LevelSet ls = {};
-  int rc = make_level_set(t, cfg, feats, rows, grad_feats, &ls);
+  int rc = fill_step_args(&a, t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
+                          grad_x_out, grad_feats, grad_mlp, loss_parts, touched);
   if (rc != SHINE_OK) return rc;
-  for (int s = 0; s < cfg->n_levels; ++s) {
-    if (!feats[s]) return set_error(SHINE_E_INVALID, "shine_train_step: null feature level");
-    // the kernel addresses feature/grad rows with 32-bit float offsets off an SGPR base (one VGPR per address)
-    if (ls.lv[s].rows >= (1ll << 29)) return set_error(SHINE_E_INVALID, "shine_train_step: level exceeds 2^29 rows");
-    a.lv[s].keys = ls.lv[s].keys;
-    a.lv[s].vals = ls.lv[s].vals;
-    a.lv[s].feat = ls.lv[s].feat;
-    a.lv[s].grad = ls.lv[s].grad;
-    a.lv[s].shift = ls.lv[s].shift;
-    a.lv[s].mask = ls.lv[s].mask;
-    a.lv[s].res = ls.lv[s].res;
-    a.rows[s] = ls.lv[s].rows;
-    a.feat_rw[s] = const_cast<float*>(feats[s]);
-    a.touched[s] = touched ? touched[s] : nullptr;
-  }
-  for (int k = 0; k < 6; ++k) {
-    if (!mlp[k]) return set_error(SHINE_E_INVALID, "shine_train_step: null decoder parameter");
-    a.mlp[k] = mlp[k];
-    if (cfg->decoder_grad_on) {
-      if (!grad_mlp || !grad_mlp[k]) return set_error(SHINE_E_INVALID, "shine_train_step: null decoder grad");
-      a.grad_mlp[k] = grad_mlp[k];
-    }
-  }
   if (n == 0) return SHINE_OK;
   V1Geometry g = v1_geometry(n);
-  a.coord = coord;
-  a.label = sdf_label;
-  a.weight = weight;
-  a.perm = perm;
-  a.slots = slots;
-  a.n_surf = cfg->eikonal_on ? reinterpret_cast<const long long*>(n_surf) : nullptr;
-  a.pred = pred_out;
-  a.grad_x = grad_x_out;
-  a.loss_parts = loss_parts;
-  a.n = n;
   a.chunk = g.chunk;
-  a.n_levels = cfg->n_levels;
-  a.reduction_sum = cfg->reduction_sum;
-  a.decoder_grad_on = cfg->decoder_grad_on;
-  a.poly = cfg->poly_int_on;
-  a.pool_mode = cfg->sorted_input == 2 ? 1 : 0;
-  if (a.pool_mode && !perm) return set_error(SHINE_E_INVALID, "shine_train_step: pool mode needs the sample indices in perm");
-  a.ablate = cfg->kernel_variant >> 8;
   a.prof = g_prof_buffer;
-  a.sigma = cfg->sigma;
-  a.inv_n = (float)cfg->inv_n;
-  a.weight_e = cfg->weight_e;
   const size_t need = (size_t)g.blocks * PART_STRIDE * sizeof(float);
   a.partials = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
   hipStream_t st = (hipStream_t)stream;

@@ -137,3 +137,80 @@ def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None, _debug_va
         "shine_plan_batch",
     )
     return perm, slots
+
+
+def mark_touched(octree, pool, idx: torch.Tensor, flags=None):
+    """Byte flags (one uint8 tensor [rows_s + 1] per level, top-down) of the feature rows the pool samples `idx` address:
+    shine_mark_touched on the node-ordered pool's slot table.  Under data parallelism every rank calls this on the
+    GLOBAL draw (same seed everywhere), so all ranks hold the same row set without a collective."""
+    t = octree._require_tables()
+    if flags is None:
+        flags = [torch.zeros(p.shape[0], dtype=torch.uint8, device=p.device) for p in octree.hier_features]
+    cfg = octree.step_config(sorted_input=2)
+    _lib.check(
+        _lib.lib().shine_mark_touched(t.handle, C.byref(cfg), pool.coord.data_ptr(), idx.data_ptr(), pool.slots.data_ptr(),
+                                      idx.numel(), octree.row_counts(), _lib.ptr_array([f.data_ptr() for f in flags]),
+                                      _lib.current_stream_handle()),
+        "shine_mark_touched",
+    )
+    return flags
+
+
+class TouchedRowReducer(GradReducer):
+    """Gradient exchange of the rows a step touched ("shared-feature grads") instead of the dense tables.
+
+    The dense bucket is Σ_l rows_l·F·4 bytes whatever the batch (13 MB for a 100 m street, 0.4 GB for a 6 km map); a
+    step only writes the rows its points' corners address.  Given per-level byte flags of the rows the GLOBAL batch
+    touches — identical on every rank: each rank marks the global draw itself (mark_touched), or the flags were OR-reduced
+    — every rank packs those rows (+ the L trash rows + the 1377 decoder floats) in the same order into one contiguous
+    message, all-reduces it, and unpacks.  Rows outside the set hold zeros on every rank and stay untouched.  Packing is
+    index plumbing around the collective (torch index_select / index_copy_, one host read of the row count per step), so
+    the same code runs over gloo on CPU tensors in the tests.  `feature_params`: the L feature tables (top-down);
+    `other_params`: the decoder tensors."""
+
+    def __init__(self, feature_params, other_params, dist=None, group=None):
+        super().__init__(list(feature_params) + list(other_params), dist, group)
+        self.n_feat = len(list(feature_params))
+        self.last_rows = 0      # rows exchanged by the last sparse reduce (all levels)
+        self.last_bytes = 0     # message size of the last reduce
+
+    def dense_bytes(self):
+        return sum(p.numel() for p in self.params) * 4
+
+    def or_reduce_flags(self, flags):
+        """For callers whose ranks drew independent batches: make the per-rank flags the global union (MAX of bytes)."""
+        if self.dist is not None:
+            for f in flags:
+                self.dist.all_reduce(f, op=self.dist.ReduceOp.MAX, group=self.group)
+        return flags
+
+    def all_reduce_touched(self, flags):
+        """flags: per level uint8 [rows_l + 1] (or [rows_l]); identical on all ranks.  Clears them for the next step."""
+        self._ensure_flat()
+        feats = self.params[:self.n_feat]
+        idx = []
+        for p, f in zip(feats, flags):
+            f = f[: p.shape[0] - 1]
+            idx.append(torch.nonzero(f, as_tuple=False).flatten())  # (host read of the count: the message size)
+        pieces = [p.grad.index_select(0, i).reshape(-1) for p, i in zip(feats, idx)]
+        pieces += [p.grad[-1].reshape(-1) for p in feats]                      # trash rows: every miss lands there
+        pieces += [p.grad.reshape(-1) for p in self.params[self.n_feat:]]      # decoder
+        msg = torch.cat(pieces)
+        self.last_rows = int(sum(i.numel() for i in idx))
+        self.last_bytes = msg.numel() * 4
+        if self.dist is not None:
+            self.dist.all_reduce(msg, op=self.dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        F = feats[0].shape[1]
+        for p, i in zip(feats, idx):
+            k = i.numel() * F
+            p.grad.index_copy_(0, i, msg[off:off + k].view(-1, F))
+            off += k
+        for p in feats:
+            p.grad[-1].copy_(msg[off:off + F])
+            off += F
+        for p in self.params[self.n_feat:]:
+            p.grad.copy_(msg[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        for f in flags:
+            f.zero_()

@@ -8,7 +8,10 @@ device-agnostic, so bench.py generates the pool on the GPU in a second or two.
 
 Workload presets follow the shipped yamls:
   maicity : config/maicity/maicity_batch.yaml  leaf 0.2 m, L=3 (or 4), sigma 0.05, BCE only
-  kitti   : config/kitti/kitti_batch.yaml      leaf 0.3 m, L=3, sigma 0.1, eikonal on (w_e 0.1)
+  kitti   : config/kitti/kitti_batch.yaml      leaf 0.3 m, L=3, sigma 0.1, eikonal on (w_e 0.1); 600 m polyline with
+            two turns
+  kitti_large : the same sensor/config on an 8 x 1 km serpentine (8.4 km of trajectory): a map whose feature tables
+            (> 256 MiB) do not fit the Infinity Cache — the regime dataset/lidar_dataset.py:93-97 anticipates
   ncd     : config/ncd/ncd_incre_reg.yaml      leaf 0.2 m, L=3, sigma 0.1, sum reduction + regulariser
 """
 from __future__ import annotations
@@ -26,7 +29,11 @@ PRESETS = {
     "kitti": dict(tree_level_world=12, tree_level_feat=3, leaf_vox_size=0.3, sigma_sigmoid_m=0.1,
                   surface_sample_range_m=0.3, surface_sample_n=3, free_sample_n=3, free_sample_begin_ratio=0.3,
                   free_sample_end_dist_m=0.8, ekional_loss_on=True, weight_e=0.1, loss_reduction="mean",
-                  pc_radius_m=50.0, min_range_m=3.0, street_len=300.0, turns=0, lr=0.01),
+                  pc_radius_m=50.0, min_range_m=3.0, street_len=600.0, turns=2, lr=0.01),
+    "kitti_large": dict(tree_level_world=12, tree_level_feat=3, leaf_vox_size=0.3, sigma_sigmoid_m=0.1,
+                        surface_sample_range_m=0.3, surface_sample_n=3, free_sample_n=3, free_sample_begin_ratio=0.3,
+                        free_sample_end_dist_m=0.8, ekional_loss_on=True, weight_e=0.1, loss_reduction="mean",
+                        pc_radius_m=50.0, min_range_m=3.0, street_len=8420.0, turns=-8, lr=0.01),
     "ncd": dict(tree_level_world=12, tree_level_feat=3, leaf_vox_size=0.2, sigma_sigmoid_m=0.1,
                 surface_sample_range_m=0.3, surface_sample_n=3, free_sample_n=3, free_sample_begin_ratio=0.3,
                 free_sample_end_dist_m=1.0, ekional_loss_on=False, weight_e=0.1, loss_reduction="sum",
@@ -118,20 +125,77 @@ def sample_rays(points, origin, cfg, gen=None):
     return xyz.contiguous(), label.contiguous(), w.contiguous()
 
 
+def trajectory(street_len: float, turns: int):
+    """The sensor path as axis-aligned segments [(x0, y0, heading_deg, length)].
+    turns == 0: one straight street; turns > 0: a polyline with that many 90-degree turns (alternating left/right, equal
+    legs — SURVEY.md §8d's KITTI-like "600 m polyline with two turns"); turns < 0: a serpentine of |turns| long rows
+    joined by 60 m connectors (a large map that still fits the [-1,1] cube)."""
+    if turns == 0:
+        return [(0.0, 0.0, 0.0, float(street_len))]
+    segs, x, y = [], 0.0, 0.0
+    if turns > 0:
+        leg = street_len / (turns + 1)
+        for k in range(turns + 1):
+            h = 0.0 if k % 2 == 0 else 90.0
+            segs.append((x, y, h, leg))
+            x, y = (x + leg, y) if h == 0.0 else (x, y + leg)
+        return segs
+    rows, gap = -turns, 60.0
+    row_len = (street_len - gap * (rows - 1)) / rows
+    for k in range(rows):
+        h = 0.0 if k % 2 == 0 else 180.0
+        segs.append((x, y, h, row_len))
+        x = x + row_len if h == 0.0 else x - row_len
+        if k + 1 < rows:
+            segs.append((x, y, 90.0, gap))
+            y += gap
+    return segs
+
+
+def _rot(heading_deg: float, device):
+    c, s_ = round(math.cos(math.radians(heading_deg))), round(math.sin(math.radians(heading_deg)))
+    return torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]], device=device)
+
+
 def make_frames(cfg, frames=100, beams=64, azimuths=450, seed=42, device="cuda"):
-    """Yield per-frame (coord, sdf_label, weight) in the scaled space, like LiDARDataset.process_frame (:115-233)."""
+    """Yield per-frame (coord, sdf_label, weight) in the scaled space, like LiDARDataset.process_frame (:115-233).
+    Each segment of the trajectory is a street canyon in its own frame (ground, two facades, boxes); a scan is ray-cast
+    against the canyon of the segment the sensor is in."""
     g = torch.Generator().manual_seed(seed)
-    lo, hi = _boxes(cfg.street_len, g)
-    lo, hi = lo.to(device), hi.to(device)
+    segs = trajectory(cfg.street_len, getattr(cfg, "turns", 0))
+    boxes = []
+    for (_, _, _, length) in segs:
+        lo, hi = _boxes(length, g, n=max(4, int(20 * length / 100.0)) if len(segs) > 1 else 20)
+        boxes.append((lo.to(device), hi.to(device)))
     dirs = sensor_dirs(beams, azimuths, device=device)
     gen = torch.Generator(device=device).manual_seed(seed + 1) if str(device) != "cpu" else \
         torch.Generator().manual_seed(seed + 1)
-    step = cfg.street_len / max(frames, 1)
+    total = sum(sg[3] for sg in segs)
+    step = total / max(frames, 1)
     # centre the map on the origin so it fits the [-1,1] cube (the reference shifts by the first pose, first_frame_ref)
-    shift = torch.tensor([cfg.street_len / 2, 0.0, 0.0], device=device)
+    ends = [(x0 + math.cos(math.radians(h)) * ln, y0 + math.sin(math.radians(h)) * ln) for (x0, y0, h, ln) in segs]
+    xs = [sg[0] for sg in segs] + [e[0] for e in ends]
+    ys = [sg[1] for sg in segs] + [e[1] for e in ends]
+    shift = torch.tensor([(min(xs) + max(xs)) / 2, (min(ys) + max(ys)) / 2, 0.0], device=device)
+    k, acc = 0, 0.0
+    rots = [(_rot(sg[2], device), _rot(-sg[2], device)) for sg in segs]
     for f in range(frames):
-        origin = torch.tensor([f * step, 0.3 * math.sin(0.2 * f), 1.8], device=device)
-        hits = cast_scan(origin, dirs, lo, hi, max_range=cfg.pc_radius_m, min_range=cfg.min_range_m)
+        s_ = f * step
+        while k + 1 < len(segs) and s_ >= acc + segs[k][3]:
+            acc += segs[k][3]
+            k += 1
+        x0, y0, _, _ = segs[k]
+        R, Rinv = rots[k]
+        lo, hi = boxes[k]
+        local_origin = torch.tensor([s_ - acc, 0.3 * math.sin(0.2 * f), 1.8], device=device)
+        hits = cast_scan(local_origin, dirs @ Rinv.T if len(segs) > 1 else dirs, lo, hi, max_range=cfg.pc_radius_m,
+                         min_range=cfg.min_range_m)
+        base = torch.tensor([x0, y0, 0.0], device=device)
+        if len(segs) > 1:
+            hits = hits @ R.T + base
+            origin = local_origin @ R.T + base
+        else:
+            origin = local_origin
         yield sample_rays((hits - shift) * cfg.scale, (origin - shift) * cfg.scale, cfg, gen)
 
 

@@ -86,3 +86,59 @@ def test_two_rank_gloo_matches_single_process(name, tmp_path):
     assert abs(float(got["loss"]) - float(ref["loss"])) <= 1e-5 * max(1.0, abs(float(ref["loss"])))
     for g, r in zip(got["grads"], refs):
         assert float((g - r).abs().max()) <= 1e-5 * max(float(r.abs().max()), 1e-30)
+
+
+def _worker_touched(rank, world, port, name, out_dir):
+    """§8(e)'s partition: ONE global batch in node order, rank r takes the r-th contiguous slice; every rank marks the
+    rows of the global batch itself (no collective) and only those rows travel."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from shine_mapping_amd.dp import TouchedRowReducer
+
+    fx = load_golden(name)
+    cfg, oct_, mlp = oracle_from_golden(fx)
+    n = fx["coord"].shape[0]
+    # the global batch, ordered by leaf-level node (what the sorted pool draw produces), known to every rank
+    hidx = oct_.get_indices(fx["coord"])
+    order = torch.argsort(hidx[0][:, 0], stable=True)
+    gc, gl, gw = fx["coord"][order], fx["sdf_label"][order], fx["weight"][order]
+    L = len(oct_.hier_features)
+    flags = []
+    for s in range(L):
+        f = torch.zeros(oct_.hier_features[s].shape[0], dtype=torch.uint8)
+        u = hidx[L - 1 - s].flatten().unique()
+        f[u[u >= 0]] = 1
+        flags.append(f)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    reducer = TouchedRowReducer(list(oct_.hier_features), mlp.params(), dist)
+    n_surf = int((gw > 0).sum())  # from the common draw: no scalar all-reduce
+    loss = _sharded_step(oct_, mlp, gc[lo:hi], gl[lo:hi], gw[lo:hi], cfg, n, n_surf)
+    local = [p.grad.clone() for p in reducer.params]
+    reducer.all_reduce_touched([f.clone() for f in flags])
+    sparse = [p.grad.clone() for p in reducer.params]
+    for p, g in zip(reducer.params, local):  # same local grads through the dense bucket
+        p.grad.copy_(g)
+    reducer.all_reduce_grads()
+    dist.all_reduce(loss)
+    if rank == 0:
+        torch.save(dict(loss=loss, sparse=sparse, dense=[p.grad.clone() for p in reducer.params],
+                        rows=reducer.last_rows, bytes=reducer.last_bytes, dense_bytes=reducer.dense_bytes()),
+                   os.path.join(out_dir, "dp_touched.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["maicity_bce_L3", "kitti_eik_L3"])
+def test_touched_row_exchange_equals_dense_all_reduce(name, tmp_path):
+    world = 2
+    mp.spawn(_worker_touched, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "dp_touched.pt"), weights_only=False)
+    fx = load_golden(name)
+    ref = fx["out"]
+    refs = list(ref["feat_grads"]) + list(ref["mlp_grads"])
+    assert abs(float(got["loss"]) - float(ref["loss"])) <= 1e-5 * max(1.0, abs(float(ref["loss"])))
+    for s, d, r in zip(got["sparse"], got["dense"], refs):
+        assert torch.equal(s, d), "touched-row exchange differs from the dense all-reduce"
+        assert float((s - r).abs().max()) <= 1e-5 * max(float(r.abs().max()), 1e-30)
+    assert 0 < got["bytes"] < got["dense_bytes"]  # 4096 points touch a fraction of the fixture's rows

@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Per-launch PMC figures of one kernel from several rocprofv3 --pmc runs (one db directory per counter group) -> the
+JSON record bench.py reads (profiles/r02_pmc_<workload>_<points>_L<levels>.json).
+
+    python tools/pmc_to_json.py --kernel k_step_v1 --out profiles/r02_pmc_maicity_262144_L4.json \
+        --meta workload=maicity points=262144 levels=4 -- /tmp/p_FETCH /tmp/p_WRITE /tmp/p_sq /tmp/p_mfma
+
+Every counter is summed over its instances (XCDs / SEs) per dispatch, then averaged over the dispatches of the kernel
+whose grid matches the most frequent grid size (the bench's own launches).  Corrections (MI355X_MICROARCH.md §HBM):
+FETCH_SIZE and WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled.
+"""
+import argparse
+import glob
+import json
+import os
+import sqlite3
+from collections import Counter, defaultdict
+
+
+def read_db(root, pat):
+    dbs = glob.glob(os.path.join(root, "**", "*_results.db"), recursive=True)
+    if not dbs:
+        raise SystemExit("no *_results.db under %s" % root)
+    con = sqlite3.connect(dbs[0])
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    pmc = [t for t in tabs if t.startswith("rocpd_pmc_event")][0]
+    info = [t for t in tabs if t.startswith("rocpd_info_pmc")][0]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    q = ("select s.kernel_name, d.event_id, d.grid_size_x, i.name, sum(e.value), d.end - d.start from %s e "
+         "join %s i on e.pmc_id = i.id join %s d on e.event_id = d.event_id join %s s on d.kernel_id = s.id "
+         "group by d.event_id, i.name" % (pmc, info, kd, ks))
+    per = defaultdict(dict)
+    grids, durs, name = {}, {}, None
+    for kname, ev, grid, cname, val, dur in cur.execute(q):
+        if pat not in kname:
+            continue
+        name = kname.replace(".kd", "")
+        per[ev][cname] = val
+        grids[ev] = grid
+        durs[ev] = dur
+    if not per:
+        raise SystemExit("kernel %s not found in %s" % (pat, dbs[0]))
+    top = Counter(grids.values()).most_common(1)[0][0]
+    keep = [ev for ev in per if grids[ev] == top]
+    out = {}
+    for c in sorted({c for ev in keep for c in per[ev]}):
+        vals = [per[ev][c] for ev in keep if c in per[ev]]
+        out[c] = sum(vals) / len(vals)
+    return name, out, len(keep), sum(durs[ev] for ev in keep) / len(keep) / 1e3, top
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kernel", default="k_step_v1")
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--meta", nargs="*", default=[])
+    ap.add_argument("--command", default="")
+    ap.add_argument("dirs", nargs="+")
+    a = ap.parse_args()
+    counters, launches, name, dur_us, grid = {}, {}, None, {}, None
+    for d in a.dirs:
+        name, c, n, us, grid = read_db(d, a.kernel)
+        for k, v in c.items():
+            counters[k] = v
+            launches[k] = n
+            dur_us[k] = us
+    rec = {"kernel": name, "grid_size_x": grid, "launches_averaged": launches, "counters_per_launch": counters,
+           "kernel_us_under_profiler": dur_us, "command": a.command,
+           "source": "rocprofv3 --kernel-trace --pmc <group> (one run per group), tools/collect_profiles.sh + "
+                     "tools/pmc_to_json.py"}
+    for kv in a.meta:
+        k, v = kv.split("=", 1)
+        rec[k] = int(v) if v.isdigit() else v
+    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        rec["FETCH_SIZE_KB_per_launch"] = counters["FETCH_SIZE"]
+        rec["WRITE_SIZE_KB_per_launch"] = counters["WRITE_SIZE"]
+        rec["hbm_bytes_per_launch"] = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+        rec["correction"] = ("MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced "
+                             "reads -> doubled; WRITE_SIZE as reported; both in KB (x1024)")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in counters:
+        busy = counters["SQ_VALU_MFMA_BUSY_CYCLES"]
+        rec["mfma_busy_cycles_per_launch"] = busy
+        if "GRBM_GUI_ACTIVE" in counters and counters["GRBM_GUI_ACTIVE"] > 0:
+            # gfx94x MfmaUtil formula: busy cycles summed over the chip / (GPU-active cycles x CUs x 4 SIMDs)
+            rec["mfma_util"] = busy / (counters["GRBM_GUI_ACTIVE"] * 256.0 * 4.0)
+            rec["mfma_util_formula"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)"
+        if "SQ_BUSY_CYCLES" in counters and counters["SQ_BUSY_CYCLES"] > 0:
+            rec["mfma_busy_over_sq_busy"] = busy / counters["SQ_BUSY_CYCLES"]
+    json.dump(rec, open(a.out, "w"), indent=1)
+    print(json.dumps(rec, indent=1))
+
+
+if __name__ == "__main__":
+    main()
