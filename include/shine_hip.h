@@ -56,7 +56,8 @@ typedef struct shine_step_config {
   int32_t sorted_input;    /* 0: visit the batch as given; 1: through perm[] (shine_plan_batch / shine_morton_sort);
                               2: POOL mode — coord/label/weight/slots are a node-ordered sample pool, perm[] holds the
                               batch's sorted sample indices (shine_sample_sorted), outputs are written at batch position */
-  int32_t kernel_variant;  /* 0: auto (fastest kernel that supports the config), 1: force the simple v0 kernel */
+  int32_t kernel_variant;  /* low byte — 0: auto (fastest kernel that supports the config), 1: the simple v0 kernel
+                              (lane = point), 2: the 32-point-tile MFMA kernel, 3: the 16-point-tile MFMA kernel */
   float sigma;             /* sigma_sigmoid = ratio*sigma_m*scale      (shine_batch.py:87) */
   float weight_e;          /* eikonal weight                           (config weight_e) */
   double inv_n;            /* 1/N_global for "mean", 1 for "sum"       */
@@ -262,6 +263,8 @@ void shine_debug_set_profile_buffer(int64_t* buffer);
 /* ---- device self-test: D[32,32] = A[32,2] . B[2,32] through ONE v_mfma_f32_32x32x2_f32, written back with the
  *      accumulator lane map the fused kernel relies on (pins the MFMA operand layouts on the hardware). --- */
 int shine_selftest_mfma(const float* a, const float* b, float* d, void* stream);
+/* the same for v_mfma_f32_16x16x4_f32 (the 16-point-tile kernel): D[16,16] = A[16,4] . B[4,16] */
+int shine_selftest_mfma16(const float* a, const float* b, float* d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "shine_internal.hpp"
+#include "shine_step_common.hpp"
 
 namespace shine {
 
@@ -35,7 +35,28 @@ extern "C" int shine_train_step_v1(const shine_tables*, const shine_step_config*
                                    const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
                                    double*, unsigned char* const*, void*, size_t, void*);
 
-extern "C" int shine_version(void) { return 100; }
+extern "C" int shine_train_step_v2(const shine_tables*, const shine_step_config*, const float*, const float*,
+                                   const float*, const int32_t*, const int32_t*, const int64_t*, int64_t,
+                                   const float* const*,
+                                   const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
+                                   double*, unsigned char* const*, void*, size_t, void*);
+
+namespace shine {
+// which configurations the 16-point-tile kernel serves when the caller leaves the choice to the library
+// (kernel_variant 0): BCE steps (the eikonal build stays on the 32-point kernel).  SHINE_KERNEL=v1 forces the 32-point one.
+bool v2_serves(const shine_step_config* cfg) {
+  static const int force_v1 = []() {
+    const char* e = getenv("SHINE_KERNEL");
+    return (e && strcmp(e, "v1") == 0) ? 1 : 0;
+  }();
+  const int variant = cfg->kernel_variant & 0xff;
+  if (variant == 3) return !cfg->eikonal_on && cfg->n_levels <= LCAP;
+  if (variant != 0 || force_v1) return false;
+  return !cfg->eikonal_on && cfg->n_levels <= LCAP;
+}
+}  // namespace shine
+
+extern "C" int shine_version(void) { return 200; }
 
 extern "C" const char* shine_error_string(int code) {
   if (code == SHINE_OK) return "ok";
@@ -65,9 +86,18 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
     const char* e = getenv("SHINE_KERNEL");
     return (e && strcmp(e, "v0") == 0) ? 1 : 0;
   }();
-  // v1 (MFMA decoder, run-length scatter) handles up to 4 featured levels (every shipped yaml); v0 is the
-  // simple cross-check kernel and the fallback for deeper trees
-  if (!force_v0 && (cfg->kernel_variant & 0xff) != 1 && cfg->n_levels <= 4)
+  // kernel_variant (low byte): 0 auto, 1 the simple v0 kernel, 2 the 32-point-tile MFMA kernel (shine_step_v1.hip),
+  // 3 the 16-point-tile MFMA kernel (shine_step_v2.hip).  The MFMA kernels handle up to 4 featured levels (every shipped
+  // yaml); v0 is the cross-check kernel and the fallback for deeper trees.
+  const int variant = cfg->kernel_variant & 0xff;
+  const size_t v2_need = shine_train_step_workspace_bytes(cfg, n);
+  if (variant == 3 && !shine::v2_serves(cfg))
+    return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 3 (16-point tiles) serves BCE steps only");
+  if (!force_v0 && workspace && workspace_bytes >= v2_need && shine::v2_serves(cfg))
+    return shine_train_step_v2(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
+                               grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,
+                               stream);
+  if (!force_v0 && variant != 1 && cfg->n_levels <= 4)
     return shine_train_step_v1(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
                                grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,
                                stream);

@@ -92,6 +92,19 @@ __device__ __forceinline__ Axis axis_weight_rt(bool poly, float x, float res) {
   return poly ? axis_weight<true>(x, res, res * 0.5f) : axis_weight<false>(x, res, res * 0.5f);
 }
 
+// launch geometry of the 16-point-tile kernel (shine_step_v2.hip)
+struct V2Geometry {
+  long long waves, chunk, blocks;
+  int wg_waves;  // waves per workgroup: 16 (one workgroup per CU) or 4 (small batches)
+};
+V2Geometry v2_geometry(long long n);
+long long v2_lds_bytes(int wg_waves);
+// true when the 16-point-tile kernel serves this configuration (and is the faster one): see shine_api.hip
+bool v2_serves(const shine_step_config* cfg);
+
+// measurement aid (shine_debug_set_profile_buffer): per-wave phase cycle counters or null
+extern long long* g_prof_buffer;
+
 // second stage of a fused step (shine_step_v1.hip): add `nblocks` per-workgroup partial vectors [PART_STRIDE floats each]
 // into the gradient tensors / loss, re-zero the trash rows (set_zero, model/feature_octree.py:78-81)
 __global__ void k_reduce_partials(V1Args a, int nblocks);

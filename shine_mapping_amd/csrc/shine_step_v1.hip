@@ -139,9 +139,12 @@ __device__ __forceinline__ void issue_row_gathers(const float* feat, const int4&
   }
 }
 
-// ABL: the measurement build honours the `ablate` debug bits (tools/ablate.py); in the product instantiation
-// (ABL = false) they are compile-time zero and every test on them folds away.
-template <int L, bool EIK, bool PROF, bool ABL>
+// The `ablate` measurement bits (tools/ablate.py) are read at run time, also by the product instantiation, where the host
+// passes 0.  Making them a template parameter was tried in round 2 and REVERTED: with the tests folded away the
+// register allocator of ROCm 7.2 lands the same source at 256 VGPRs + 152 B/lane of scratch instead of 238 VGPRs and no
+// scratch (BCE, 4 levels: 83 -> 115 us; the eikonal builds went from 20-72 B to 440-716 B of scratch) — the wave-uniform
+// branches happen to pin a better schedule.  They cost a handful of scalar compares per tile.
+template <int L, bool EIK, bool PROF>
 __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   __shared__ float s_opA[OP_TOTAL];
   __shared__ float s_bias[100];
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(NT, 2) void k_step_v1(V1Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pt = lane & 31, h = lane >> 5;
   const bool poly = a.poly != 0;
-  const int ablate = ABL ? a.ablate : 0;
+  const int ablate = a.ablate;
   long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tk = PROF ? clk() : 0;
 #define SHINE_STAMP(k)            \
@@ -982,19 +985,15 @@ template <bool EIK>
 static void launch_v1(const V1Args& a0, int levels, dim3 grid, hipStream_t st) {
   V1Args a = a0;
   if (a.prof && levels == 4) {  // debug build of the same kernel with s_memtime stamps per phase
-    hipLaunchKernelGGL((k_step_v1<4, EIK, true, true>), grid, dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((k_step_v1<4, EIK, true>), grid, dim3(NT), 0, st, a);
     return;
   }
   a.prof = nullptr;
-  if ((a.ablate & 31) && levels == 4) {  // measurement build that honours the ablation bits (4 levels only)
-    hipLaunchKernelGGL((k_step_v1<4, EIK, false, true>), grid, dim3(NT), 0, st, a);
-    return;
-  }
   switch (levels) {  // the level count is a template parameter: straight-line query code, no guards
-    case 1: hipLaunchKernelGGL((k_step_v1<1, EIK, false, false>), grid, dim3(NT), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_step_v1<2, EIK, false, false>), grid, dim3(NT), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((k_step_v1<3, EIK, false, false>), grid, dim3(NT), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_step_v1<4, EIK, false, false>), grid, dim3(NT), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((k_step_v1<1, EIK, false>), grid, dim3(NT), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_step_v1<2, EIK, false>), grid, dim3(NT), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_step_v1<3, EIK, false>), grid, dim3(NT), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_step_v1<4, EIK, false>), grid, dim3(NT), 0, st, a); break;
   }
 }
 
@@ -1004,8 +1003,12 @@ using namespace shine;
 
 extern "C" size_t shine_train_step_workspace_bytes(const shine_step_config* cfg, int64_t n) {
   (void)cfg;
-  if (n <= 0) return 0;
-  return (size_t)v1_geometry(n).blocks * PART_STRIDE * sizeof(float);
+  if (n == 0) return 0;
+  // n < 0: an upper bound for ANY batch size (callers that keep one buffer for the life of the process): the 32-point
+  // kernel launches at most 256 workgroups, the 16-point kernel at most 512 (its 4-wave form below 2048 tiles)
+  if (n < 0) return (size_t)512 * PART_STRIDE * sizeof(float);
+  const long long b1 = v1_geometry(n).blocks, b2 = v2_geometry(n).blocks;
+  return (size_t)(b1 > b2 ? b1 : b2) * PART_STRIDE * sizeof(float);
 }
 
 // what one launch does, for measurement (bench.py's roofline object): out[0] workgroups, out[1] waves, out[2] points per
@@ -1013,13 +1016,25 @@ extern "C" size_t shine_train_step_workspace_bytes(const shine_step_config* cfg,
 // per point (3 x 2624 BCE, 6 x 2624 with the eikonal term)
 extern "C" int shine_train_step_info(const shine_step_config* cfg, int64_t n, int64_t* out) {
   if (!cfg || !out) return set_error(SHINE_E_INVALID, "shine_train_step_info: null argument");
+  out[5] = cfg->eikonal_on ? 6 * 2624 : 3 * 2624;
+  out[6] = out[7] = 0;
+  if (v2_serves(cfg)) {  // 16-point tiles, v_mfma_f32_16x16x4_f32 = 2048 FLOP each
+    const V2Geometry g2 = v2_geometry(n > 0 ? n : 1);
+    out[0] = g2.blocks;
+    out[1] = g2.waves;
+    out[2] = 16;
+    out[3] = 68ll * 2048;
+    out[4] = v2_lds_bytes(g2.wg_waves);
+    out[6] = 2;
+    return SHINE_OK;
+  }
   const V1Geometry g = v1_geometry(n > 0 ? n : 1);
   out[0] = g.blocks;
   out[1] = g.waves;
   out[2] = 32;
   out[3] = (long long)(cfg->eikonal_on ? MFMA_PER_TILE_EIK : MFMA_PER_TILE_BCE) * 4096;  // 32x32x2 MFMA = 4096 FLOP
   out[4] = (long long)(sizeof(float) * (OP_TOTAL + 100 + WAVES * WAVE_FLOATS) + 4 * sizeof(double));
-  out[5] = cfg->eikonal_on ? 6 * 2624 : 3 * 2624;
+  out[6] = 1;
   return SHINE_OK;
 }
 
@@ -1056,7 +1071,9 @@ extern "C" int shine_mark_touched(const shine_tables* t, const shine_step_config
   return SHINE_OK;
 }
 
-static long long* g_prof_buffer = nullptr;
+namespace shine {
+long long* g_prof_buffer = nullptr;
+}
 // measurement aid (include/shine_hip.h): per-wave phase cycle counters, [waves][8] int64, or NULL to disable
 extern "C" void shine_debug_set_profile_buffer(int64_t* p) { g_prof_buffer = reinterpret_cast<long long*>(p); }
 

@@ -30,7 +30,8 @@ class StepOptions:
     weight_e: float = 0.1
     n_global: Optional[int] = None    # global batch size under data parallelism (defaults to local N)
     decoder_grad_on: Optional[bool] = None  # default: any decoder parameter requires grad (freeze_model, tools.py:188)
-    kernel_variant: int = 0           # 0 auto; 1 forces the simple v0 kernel (kept as an on-device cross-check)
+    kernel_variant: int = 0           # 0 auto; 1 the simple v0 kernel (on-device cross-check); 2 / 3 force the 32- /
+                                      # 16-point-tile MFMA kernel
 
 
 def eik_needs_count(opts) -> bool:
@@ -239,7 +240,7 @@ def _workspace(dev, cfg):
     key = str(dev)
     ws = _WORKSPACE.get(key)
     if ws is None:
-        nbytes = int(_lib.lib().shine_train_step_workspace_bytes(C.byref(cfg), 1 << 40))
+        nbytes = int(_lib.lib().shine_train_step_workspace_bytes(C.byref(cfg), -1))  # bound for any batch size
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         _WORKSPACE[key] = ws
     return ws

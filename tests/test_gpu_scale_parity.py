@@ -25,8 +25,9 @@ def _workload(kind, levels, frames=8, seed=21, **over):
 
 # BASELINE.json config 2 (2^18 points, 4-level octree, BCE) and config 3 (2^20 points, L=3, eikonal), each with a ragged
 # tail (+37 / +1) so that the last tile is partial.  Reference: shine_batch.py:115-209.
-@pytest.mark.parametrize("kind,levels,n", [("maicity", 4, (1 << 18) + 37), ("kitti", 3, (1 << 20) + 1)])
-def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n):
+@pytest.mark.parametrize("kind,levels,n,variant", [("maicity", 4, (1 << 18) + 37, 0), ("maicity", 4, (1 << 18) + 37, 2),
+                                                   ("maicity", 3, (1 << 16) + 5, 3), ("kitti", 3, (1 << 20) + 1, 0)])
+def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n, variant):
     from oracle import shine_oracle as so
     from shine_mapping_amd import StepOptions, fused_train_step
     from shine_mapping_amd.sampler import SortedPool
@@ -37,7 +38,8 @@ def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n):
     sp = SortedPool(octree, wl.pool.coord, wl.pool.sdf_label, wl.pool.weight, seed=2)
     idx = sp.draw(n)
     params = list(octree.hier_features) + dec.fused_params()
-    opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=cfg.ekional_loss_on, weight_e=cfg.weight_e)
+    opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=cfg.ekional_loss_on, weight_e=cfg.weight_e,
+                       kernel_variant=variant)
     loss, pred, g = fused_train_step(octree, dec, None, None, None, opts, want_grad_x=True, pool=sp, idx=idx)
     torch.cuda.synchronize()
     c, l, w = (t.cpu() for t in sp.get_batch(idx))
@@ -88,16 +90,18 @@ def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n):
     assert all(float(p[-1].abs().max()) == 0.0 for p in octree.hier_features)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
-def test_both_kernels_are_pinned_to_the_goldens(golden, variant):
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_every_kernel_is_pinned_to_the_goldens(golden, variant):
     """kernel_variant 1 (v0, lane = point) is the on-device cross-check of other tests: it must itself match the
-    reference's recorded outputs, like the MFMA kernel (variant 0)."""
+    reference's recorded outputs, like the MFMA kernels (2: 32-point tiles, 3: 16-point tiles, 0: the library's pick)."""
     from shine_mapping_amd import fused_train_step
 
     cfg, octree, dec = product_from_golden(golden)
     ref = golden["out"]
     opts = step_options(golden)
     opts.kernel_variant = variant
+    if variant == 3 and opts.ekional_loss_on:
+        pytest.skip("the 16-point-tile kernel serves BCE steps")
     loss, pred, g = fused_train_step(octree, dec, golden["coord"].cuda(), golden["sdf_label"].cuda(),
                                      golden["weight"].cuda(), opts, want_grad_x=True)
     torch.cuda.synchronize()
@@ -338,3 +342,47 @@ def test_tier_a_loop_runs_no_torch_gemm():
     assert any("k_mlp<0>" in n or "k_mlp" in n for n in kernels), kernels
     bad = [n for n in names if "Cijk" in n or "gemm" in n.lower() or "addmm" in n.lower() or n.startswith("aten::mm")]
     assert not bad, bad
+
+
+def test_mfma16_lane_maps_on_hardware():
+    """v_mfma_f32_16x16x4_f32 operand / accumulator lane maps, as the 16-point-tile kernel relies on them."""
+    from shine_mapping_amd import _lib
+
+    torch.manual_seed(0)
+    a = torch.randn(16, 4, device="cuda")
+    b = torch.randn(4, 16, device="cuda")
+    d = torch.zeros(16, 16, device="cuda")
+    _lib.check(_lib.lib().shine_selftest_mfma16(a.data_ptr(), b.data_ptr(), d.data_ptr(), _lib.current_stream_handle()))
+    torch.cuda.synchronize()
+    assert abs_err(d, a.double() @ b.double()) <= 1e-5
+
+
+@pytest.mark.parametrize("n", [1, 15, 17, 257, 4096, 40000])
+@pytest.mark.parametrize("variant", [2, 3])
+def test_ragged_batches_on_both_mfma_kernels(n, variant):
+    """Unplanned batches (the kernel hashes and probes itself) of awkward sizes: partial tiles, one-tile waves, the
+    4-wave and the full-chip workgroup shapes of the 16-point kernel."""
+    from oracle import shine_oracle as so
+    from shine_mapping_amd import fused_train_step
+
+    fx = load_golden("maicity_bce_L4")
+    cfg, octree, dec = product_from_golden(fx)
+    ocfg, oct_, mlp = oracle_from_golden(fx)
+    reps = (n + fx["coord"].shape[0] - 1) // fx["coord"].shape[0]
+    c = fx["coord"].repeat(reps, 1)[:n].contiguous()
+    l = fx["sdf_label"].repeat(reps)[:n].contiguous()
+    w = fx["weight"].repeat(reps)[:n].contiguous()
+    if n > 4096:  # not all the same points: jitter inside the voxels
+        torch.manual_seed(n)
+        c = (c + 1e-5 * torch.randn_like(c)).contiguous()
+    ref = so.train_step(oct_, mlp, c, l, w, ocfg)
+    opts = step_options(fx)
+    opts.kernel_variant = variant
+    loss, pred, _ = fused_train_step(octree, dec, c.cuda(), l.cuda(), w.cuda(), opts)
+    torch.cuda.synchronize()
+    assert abs_err(pred, ref["pred"]) <= TOL
+    assert abs(float(loss) - float(ref["loss"])) <= TOL * max(1.0, abs(float(ref["loss"])))
+    for k, r in enumerate(ref["feat_grads"]):
+        assert rel_err(octree.hier_features[k].grad, r) <= TOL
+    for p, r in zip(dec.fused_params(), ref["mlp_grads"]):
+        assert rel_err(p.grad, r) <= TOL
