@@ -53,7 +53,7 @@ def read_db(root, pat):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="k_step_v1")
+    ap.add_argument("--kernel", default="k_step_v")
     ap.add_argument("--out", required=True)
     ap.add_argument("--meta", nargs="*", default=[])
     ap.add_argument("--command", default="")
