@@ -57,7 +57,8 @@ typedef struct shine_step_config {
                               2: POOL mode — coord/label/weight/slots are a node-ordered sample pool, perm[] holds the
                               batch's sorted sample indices (shine_sample_sorted), outputs are written at batch position */
   int32_t kernel_variant;  /* low byte — 0: auto (fastest kernel that supports the config), 1: the simple v0 kernel
-                              (lane = point), 2: the 32-point-tile MFMA kernel, 3: the 16-point-tile MFMA kernel */
+                              (lane = point), 2: the 32-point-tile MFMA kernel, 3: the 16-point-tile MFMA kernel that hashes
+                              and probes itself, 4: the 16-point-tile kernel for planned / pool batches (lane = point x level) */
   float sigma;             /* sigma_sigmoid = ratio*sigma_m*scale      (shine_batch.py:87) */
   float weight_e;          /* eikonal weight                           (config weight_e) */
   double inv_n;            /* 1/N_global for "mean", 1 for "sum"       */
@@ -265,6 +266,10 @@ void shine_debug_set_profile_buffer(int64_t* buffer);
 int shine_selftest_mfma(const float* a, const float* b, float* d, void* stream);
 /* the same for v_mfma_f32_16x16x4_f32 (the 16-point-tile kernel): D[16,16] = A[16,4] . B[4,16] */
 int shine_selftest_mfma16(const float* a, const float* b, float* d, void* stream);
+/* cross-lane exchanges of the lane = (point, level) kernel (shine_step_v3.hip), 64 lanes each: through
+ *  v_permlane32_swap  o32[l] = l < 32 ? x[l] + x[l + 32] : y[l] + y[l - 32];
+ *  v_permlane16_swap  o16[l] = (l & 16) ? y[l] + y[l - 16] : x[l] + x[l + 16]                                  */
+int shine_selftest_permlane(const float* x, const float* y, float* o32, float* o16, void* stream);
 
 #ifdef __cplusplus
 }

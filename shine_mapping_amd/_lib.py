@@ -87,6 +87,7 @@ _SIGNATURES = {
     "shine_morton_sort": (C.c_int, [C.POINTER(StepConfig), _P, C.c_int64, _P, _P, C.POINTER(C.c_size_t), _P]),
     "shine_selftest_mfma": (C.c_int, [_P, _P, _P, _P]),
     "shine_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
+    "shine_selftest_permlane": (C.c_int, [_P, _P, _P, _P, _P]),
     "shine_debug_set_profile_buffer": (None, [_P]),
     "shine_sample_sorted": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, C.c_size_t, _P,
                                       C.POINTER(C.c_size_t), _P]),

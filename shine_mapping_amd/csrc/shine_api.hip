@@ -41,6 +41,12 @@ extern "C" int shine_train_step_v2(const shine_tables*, const shine_step_config*
                                    const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
                                    double*, unsigned char* const*, void*, size_t, void*);
 
+extern "C" int shine_train_step_v3(const shine_tables*, const shine_step_config*, const float*, const float*,
+                                   const float*, const int32_t*, const int32_t*, const int64_t*, int64_t,
+                                   const float* const*,
+                                   const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
+                                   double*, unsigned char* const*, void*, size_t, void*);
+
 namespace shine {
 // which configurations the 16-point-tile kernel serves when the caller leaves the choice to the library
 // (kernel_variant 0): BCE steps (the eikonal build stays on the 32-point kernel).  SHINE_KERNEL=v1 forces the 32-point one.
@@ -50,7 +56,7 @@ bool v2_serves(const shine_step_config* cfg) {
     return (e && strcmp(e, "v1") == 0) ? 1 : 0;
   }();
   const int variant = cfg->kernel_variant & 0xff;
-  if (variant == 3) return !cfg->eikonal_on && cfg->n_levels <= LCAP;
+  if (variant == 3 || variant == 4) return !cfg->eikonal_on && cfg->n_levels <= LCAP;
   if (variant != 0 || force_v1) return false;
   return !cfg->eikonal_on && cfg->n_levels <= LCAP;
 }
@@ -91,8 +97,16 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
   // yaml); v0 is the cross-check kernel and the fallback for deeper trees.
   const int variant = cfg->kernel_variant & 0xff;
   const size_t v2_need = shine_train_step_workspace_bytes(cfg, n);
-  if (variant == 3 && !shine::v2_serves(cfg))
-    return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 3 (16-point tiles) serves BCE steps only");
+  if ((variant == 3 || variant == 4) && !shine::v2_serves(cfg))
+    return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 3 / 4 (16-point tiles) serve BCE steps only");
+  if (variant == 4 && !slots)
+    return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 4 needs a planned batch (slots)");
+  // 16-point tiles: planned / pool batches run on the lane = (point, level) kernel (shine_step_v3.hip), batches without
+  // a plan (in-kernel probing) on shine_step_v2.hip; kernel_variant 3 forces the latter
+  if (!force_v0 && workspace && workspace_bytes >= v2_need && shine::v2_serves(cfg) && slots && variant != 3)
+    return shine_train_step_v3(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
+                               grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,
+                               stream);
   if (!force_v0 && workspace && workspace_bytes >= v2_need && shine::v2_serves(cfg))
     return shine_train_step_v2(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
                                grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,

@@ -47,6 +47,8 @@ struct V1Args {
   long long* prof;  // debug: per-wave phase cycle counters [waves][8] (shine_debug_set_profile_buffer) or null
   long long n;
   long long chunk;
+  long long tiles;        // v2: tiles of the launch (16 points each) ...
+  long long waves_total;  // ... dealt evenly to this many waves: wave w owns tiles [w T / W, (w + 1) T / W)
   int n_levels;
   int reduction_sum;
   int decoder_grad_on;
@@ -94,11 +96,13 @@ __device__ __forceinline__ Axis axis_weight_rt(bool poly, float x, float res) {
 
 // launch geometry of the 16-point-tile kernel (shine_step_v2.hip)
 struct V2Geometry {
-  long long waves, chunk, blocks;
+  long long waves, chunk, blocks, tiles;
   int wg_waves;  // waves per workgroup: 16 (one workgroup per CU) or 4 (small batches)
 };
 V2Geometry v2_geometry(long long n);
 long long v2_lds_bytes(int wg_waves);
+V2Geometry v3_geometry(long long n);  // shine_step_v3.hip: tiles dealt evenly to every resident wave slot
+long long v3_lds_bytes(int wg_waves);
 // true when the 16-point-tile kernel serves this configuration (and is the faster one): see shine_api.hip
 bool v2_serves(const shine_step_config* cfg);
 

@@ -1007,8 +1007,9 @@ extern "C" size_t shine_train_step_workspace_bytes(const shine_step_config* cfg,
   // n < 0: an upper bound for ANY batch size (callers that keep one buffer for the life of the process): the 32-point
   // kernel launches at most 256 workgroups, the 16-point kernel at most 512 (its 4-wave form below 2048 tiles)
   if (n < 0) return (size_t)512 * PART_STRIDE * sizeof(float);
-  const long long b1 = v1_geometry(n).blocks, b2 = v2_geometry(n).blocks;
-  return (size_t)(b1 > b2 ? b1 : b2) * PART_STRIDE * sizeof(float);
+  const long long b1 = v1_geometry(n).blocks, b2 = v2_geometry(n).blocks, b3 = v3_geometry(n).blocks;
+  const long long b = b1 > b2 ? (b1 > b3 ? b1 : b3) : (b2 > b3 ? b2 : b3);
+  return (size_t)b * PART_STRIDE * sizeof(float);
 }
 
 // what one launch does, for measurement (bench.py's roofline object): out[0] workgroups, out[1] waves, out[2] points per
@@ -1019,13 +1020,14 @@ extern "C" int shine_train_step_info(const shine_step_config* cfg, int64_t n, in
   out[5] = cfg->eikonal_on ? 6 * 2624 : 3 * 2624;
   out[6] = out[7] = 0;
   if (v2_serves(cfg)) {  // 16-point tiles, v_mfma_f32_16x16x4_f32 = 2048 FLOP each
-    const V2Geometry g2 = v2_geometry(n > 0 ? n : 1);
+    // (bench.py's steps are pool batches: the lane = (point, level) kernel, shine_step_v3.hip)
+    const V2Geometry g2 = v3_geometry(n > 0 ? n : 1);
     out[0] = g2.blocks;
     out[1] = g2.waves;
     out[2] = 16;
     out[3] = 68ll * 2048;
-    out[4] = v2_lds_bytes(g2.wg_waves);
-    out[6] = 2;
+    out[4] = v3_lds_bytes(g2.wg_waves);
+    out[6] = 3;
     return SHINE_OK;
   }
   const V1Geometry g = v1_geometry(n > 0 ? n : 1);

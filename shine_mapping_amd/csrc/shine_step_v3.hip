@@ -1,0 +1,773 @@
+// shine_step_v3.hip — the fused SHINE training step, 16-point tiles, query lane = (point, LEVEL).
+//
+//   query    FeatureOctree.query_feature   model/feature_octree.py:199-244
+//   decode   Decoder.sdf                   model/decoder.py:49-63
+//   loss     sdf_bce_loss                  utils/loss.py:17-24
+//   backward cur_loss.backward()           shine_batch.py:208-209 (closed form, SURVEY.md §8a math contract)
+//
+// Same algorithm, staging layout and outputs as shine_step_v2.hip.  What the round-2 measurements said about v2
+// (profiles/r02_*): a wave spends ~19-24 k cycles on a 16-point tile, about half of it ISSUING instructions one at a
+// time (~1100 VALU + ~600 SALU per tile; 68 MFMAs are only 2.2 k cycles), the rest waiting on three dependent memory
+// round trips; with three waves per SIMD nothing else is left to run.  So this kernel removes instructions:
+//   * query: lane (pt, g) owns LEVEL g of point pt (v2: a corner pair of every level).  The per-level work — hash slot,
+//     node-run masks, smooth-step weights, offsets — is done ONCE per wave instruction instead of once per level:
+//     ~190 VALU per tile instead of ~640; one slot / eight ids per lane; the node-run masks of all four levels come
+//     out of ONE 64-bit ballot; the run carry is a DPP row broadcast.  Each lane gathers the eight 32-B corner rows of
+//     its level (sixteen 16-B loads, all in flight together: ONE round trip after the ids) and sums them with its
+//     eight weights; a reduce-scatter over g (v_permlane32_swap / v_permlane16_swap, gfx950) leaves features
+//     (2g, 2g+1) of the point in lane g — the B operand of layer 1, exactly as in v2;
+//   * loss: hardware transcendentals (v_exp_f32 / v_rcp_f32 / v_log_f32) instead of libm forms: ~25 VALU, not ~190;
+//   * decoder / weight grads / scatter / flush: as in v2.
+// Planned or pool batches only (the hash slots come with the batch); a batch without a plan runs on k_step_v2.
+#include "shine_step_common.hpp"
+
+namespace shine {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int V3_TP = 16;                      // points per tile
+constexpr int V3_WP = 16;                      // pitch of the [corner][point] staging rows
+constexpr int V3_TT = 20;                      // transpose tile pitch (floats, 16-B aligned rows)
+constexpr int V3_DFP = 20;                     // pitch of the [feature][point] rows
+constexpr int V3_IDS = LCAP * 8 * V3_WP;       // ids [LCAP][8][16] int32
+constexpr int V3_W = LCAP * 8 * V3_WP;         // w   [LCAP][8][16]
+constexpr int V3_R2 = 2 * 32 * V3_TT;          // two transpose tiles [32][20]; second life: df
+constexpr int V3_DF = 0;
+constexpr int V3_WAVE_FLOATS = V3_IDS + V3_W + V3_R2;  // 2304 floats = 9216 B per wave
+constexpr int V3_SLOT = 68;                    // pitch of one node's 8 x 8 corner rows in LDS (floats): conflict-free b128 reads
+constexpr int V3_OPA1 = 0, V3_OPA2 = 4 * 64, V3_OPA2T = 20 * 64, V3_OPA1T = 36 * 64, V3_OPTOTAL = 44 * 64;
+#ifndef SHINE_V3_BIG
+#define SHINE_V3_BIG 8
+#endif
+constexpr int V3_BIG = SHINE_V3_BIG;           // waves per workgroup of the full-chip launch (V3_BIG / 4 per SIMD)
+#ifndef SHINE_V3_GB
+#define SHINE_V3_GB 4
+#endif
+constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch (register budget: 8 floats each)
+#ifndef SHINE_V3_BAR  // bit 0: scheduling barriers at the phase boundaries, bit 1: per level inside the scatter
+#define SHINE_V3_BAR 3
+#endif
+#if SHINE_V3_BAR & 1
+#define SHINE_V3_PHASE_BARRIER __builtin_amdgcn_sched_barrier(0);
+#else
+#define SHINE_V3_PHASE_BARRIER
+#endif
+#if SHINE_V3_BAR & 2
+#define SHINE_V3_LEVEL_BARRIER __builtin_amdgcn_sched_barrier(0);
+#else
+#define SHINE_V3_LEVEL_BARRIER
+#endif
+#ifndef SHINE_V3_DEDUP
+#define SHINE_V3_DEDUP 0
+#endif
+#ifndef SHINE_V3_ABL  // measurement builds only (tools/mk_variant.py): 1 no atomics, 2 no weight-grad phase, 4 no scatter
+#define SHINE_V3_ABL 0  // phase, 8 no row gathers; the product build compiles none of it
+#endif
+
+static_assert(V3_DFP == V3_TT, "f_wr addresses both the transpose rows and the df rows");
+static_assert(PART_STRIDE <= V3_WAVE_FLOATS, "each wave's partial vector aliases its staging region at the end");
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 zero4() {
+  f32x4 z;
+  z[0] = z[1] = z[2] = z[3] = 0.f;
+  return z;
+}
+
+// sigmoid on the hardware transcendental units: 1 / (1 + 2^(-x log2 e)); exp2 overflow -> rcp(inf) = 0, as it should
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
+}
+
+// x + (the value lane ^ 32 holds in y)  for lanes < 32,   y + (the value lane ^ 32 holds in x)  for lanes >= 32:
+// v_permlane32_swap exchanges x[32..63] with y[0..31], after which both registers hold one own and one partner value.
+__device__ __forceinline__ float xsum32(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// the same across lane ^ 16 (v_permlane16_swap: x rows 1, 3 <-> y rows 0, 2)
+__device__ __forceinline__ float xsum16(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// lane 15 of each 16-lane row to every lane of the row (DPP row_newbcast:15), lane i-1 of the row to lane i (row_shr:1)
+__device__ __forceinline__ int row_last(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xF, 0xF, false); }
+__device__ __forceinline__ int row_prev(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false); }
+
+template <int L, int WAVES, bool PROF>
+__global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_v3(V1Args a) {
+  constexpr int NT = WAVES * 64;
+  __shared__ float s_opA[V3_OPTOTAL];
+  __shared__ float s_bias[100];
+  __shared__ double s_loss[4];
+  __shared__ float s_wave[WAVES][V3_WAVE_FLOATS];
+#if SHINE_V3_DEDUP
+  constexpr int ROWCAP = WAVES <= 8 ? 32 : 12;  // node slots per wave (what the 160 KB of LDS leave room for)
+  __shared__ float s_rows[WAVES][ROWCAP * V3_SLOT];
+#endif
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int pt = lane & 15, g = lane >> 4;
+  const bool poly = a.poly != 0;
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tk = PROF ? clk() : 0;
+#define SHINE_STAMP(k)            \
+  if (PROF) {                     \
+    long long now__ = clk();      \
+    pc[k] += now__ - tk;          \
+    tk = now__;                   \
+  }
+
+  // ---- per-workgroup setup: A operands in 16x16x4 lane order (lane l: row i = l & 15, k = l >> 4), biases
+  for (int idx = tid; idx < V3_OPTOTAL; idx += NT) {
+    const int t = idx >> 6, l = idx & 63, i = l & 15, kg = l >> 4;
+    float v;
+    if (t < 4) {  // W1: M-block mb = t >> 1, k-step tt = t & 1 contracts over features 2 kg + tt
+      v = a.mlp[0][(16 * (t >> 1) + i) * F + 2 * kg + (t & 1)];
+    } else if (t < 20) {  // W2: mb, k-step (m', r) contracts over channels 16 m' + 4 kg + r
+      const int u = t - 4, mb = u >> 3, ks = u & 7;
+      v = a.mlp[2][(16 * mb + i) * H + 16 * (ks >> 2) + 4 * kg + (ks & 3)];
+    } else if (t < 36) {  // W2^T
+      const int u = t - 20, mb = u >> 3, ks = u & 7;
+      v = a.mlp[2][(16 * (ks >> 2) + 4 * kg + (ks & 3)) * H + 16 * mb + i];
+    } else {  // W1^T, output rows permuted: row 4 g' + r' = feature 2 g' + r' for r' < 2, zero otherwise
+      const int ks = t - 36, gp = i >> 2, rp = i & 3;
+      const float w = a.mlp[0][(16 * (ks >> 2) + 4 * kg + (ks & 3)) * F + 2 * gp + (rp & 1)];
+      v = rp < 2 ? w : 0.f;
+    }
+    s_opA[idx] = v;
+  }
+  if (tid < 32) {
+    s_bias[tid] = a.mlp[1][tid];
+    s_bias[32 + tid] = a.mlp[3][tid];
+    s_bias[64 + tid] = a.mlp[4][tid];
+  }
+  if (tid == 0) {
+    s_bias[96] = a.mlp[5][0];
+    s_loss[0] = s_loss[1] = s_loss[2] = s_loss[3] = 0.0;
+  }
+  __syncthreads();
+
+  float* U = s_wave[wv];
+  int* U_ids = reinterpret_cast<int*>(U);  // [LCAP][8][16]
+  float* U_w = U + V3_IDS;                 // [LCAP][8][16]
+  float* R2 = U + V3_IDS + V3_W;
+#if SHINE_V3_DEDUP
+  float* const U_rows = s_rows[wv];
+#endif
+
+  // Per-lane LDS base addresses: every staging access below is one of these + a compile-time offset (DS instructions
+  // carry a 16-bit immediate).  They are re-derived from an opaque lane value at the top of every tile, which keeps
+  // LLVM's loop-invariant code motion from parking pre-added address variants in VGPRs across the whole loop.
+  int lane_o = lane;
+  const float b3 = s_bias[96];
+  const float inv_sigma = 1.0f / a.sigma;
+  const float4* sb4 = reinterpret_cast<const float4*>(s_bias);
+
+  // this lane's level (query role): table pointers and resolution of level g (lanes of a level the tree does not have
+  // borrow the leaf level's pointers and never hit)
+  const bool lvl_on = g < L;
+  const int gs = lvl_on ? g : L - 1;
+  const float* lv_feat = a.lv[0].feat;
+  const int4* lv_vals = a.lv[0].vals;
+  float lv_res = a.lv[0].res;
+#pragma unroll
+  for (int s = 1; s < L; ++s)
+    if (gs == s) {
+      lv_feat = a.lv[s].feat;
+      lv_vals = a.lv[s].vals;
+      lv_res = a.lv[s].res;
+    }
+
+  f32x4 accW2[2][2], accW1[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    accW1[m] = zero4();
+#pragma unroll
+    for (int n = 0; n < 2; ++n) accW2[m][n] = zero4();
+  }
+  float dw3c[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) dw3c[r] = 0.f;
+  float db2acc[2] = {0.f, 0.f};
+  float db3 = 0.f;
+  float loss_acc = 0.f;  // per-lane sum over this wave's <= a few dozen tiles; widened to double at the flush
+  int cnt_acc = 0;
+  int run_id[LCAP], run_hit[LCAP];
+  float run_acc[LCAP];
+  float trash_sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < LCAP; ++s) {
+    run_id[s] = -1;
+    run_acc[s] = 0.f;
+    run_hit[s] = 0;
+  }
+  int last_slot = -2;  // this lane's level: the node of the previous tile's last point (carries runs across tiles)
+  const int sc = lane >> 3, sq = lane & 7;  // scatter role: corner, feature
+
+  // Tiles are dealt evenly to all resident wave slots: wave w owns tiles [w T / W, (w + 1) T / W) of the ordered stream
+  const long long wave_g = (long long)blockIdx.x * WAVES + wv;
+  const long long begin = V3_TP * ((wave_g * a.tiles) / a.waves_total);
+  const long long end_t = V3_TP * (((wave_g + 1) * a.tiles) / a.waves_total);
+  const long long end = end_t < a.n ? end_t : a.n;
+
+  // software prefetch of the {perm -> coord, label, slot} chain, index two tiles ahead (as in v1 / v2)
+  long long np = 0;
+  float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, nlabel = 0.f;
+  int nslot = -1;
+  bool nvalid = begin + pt < end;
+  int np2 = 0;
+  if (a.perm && begin + V3_TP + pt < end) np2 = a.perm[begin + V3_TP + pt];
+  if (nvalid) {
+    np = a.perm ? (long long)a.perm[begin + pt] : begin + pt;
+    const long long si = a.pool_mode ? np : begin + pt;
+    if (lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
+    nx0 = a.coord[3 * np];
+    nx1 = a.coord[3 * np + 1];
+    nx2 = a.coord[3 * np + 2];
+    nlabel = a.label[np];
+  }
+  SHINE_STAMP(0)  // setup
+
+  for (long long base = begin; base < end; base += V3_TP) {
+    asm volatile("" : "+v"(lane_o));  // opaque per tile (see above)
+    const int o_pt = lane_o & 15, o_g = lane_o >> 4;
+    int* const st_ids = U_ids + (8 * o_g) * V3_WP + o_pt;   // staging writes (level o_g): + c * V3_WP
+    float* const st_w = U_w + (8 * o_g) * V3_WP + o_pt;
+    const int* const sc_ids = U_ids + (lane_o >> 3) * V3_WP;  // scatter reads: + s * 8 * V3_WP + point
+    const float* const sc_w = U_w + (lane_o >> 3) * V3_WP;
+    const float* const sc_df = R2 + V3_DF + (lane_o & 7) * V3_DFP;
+    float* const t_wr = R2 + (4 * o_g) * V3_TT + o_pt;       // transpose writes: + (16 m + r) * V3_TT [+ 32 * V3_TT]
+    const float* const t_rd = R2 + o_pt * V3_TT + 4 * o_g;   // operand reads (i16 = lane & 15, kk = lane >> 4)
+    float* const f_wr = R2 + (2 * o_g) * V3_TT + o_pt;       // [feature 2g (+1)][pt] rows (V3_DFP == V3_TT)
+    const float* const opa = s_opA + lane_o;
+    const bool valid = nvalid;
+    const long long p = np;
+    const long long po = a.pool_mode ? base + pt : p;  // where this point's outputs go
+    const float x0 = nx0, x1 = nx1, x2 = nx2, label = nlabel;
+    // ================================================================ phase 1: query (this lane: level g of point pt)
+    const int slot = valid ? nslot : -1;
+    const bool hit = slot >= 0;
+    const unsigned int validmask = (unsigned int)__ballot(valid) & 0xFFFFu;
+    // node-run boundaries of the ordered stream, all levels at once: bit 16 g + pt of one 64-bit ballot
+    const int prev = row_prev(slot, last_slot);
+    const bool chg = valid && lvl_on && slot != prev;
+    const unsigned long long chg64 = __ballot(chg);
+    const unsigned long long hit64 = __ballot(hit);
+    last_slot = row_last(slot);
+    // smooth-step weights of this level, in the reference's association (model/feature_octree.py:186-193)
+    float w[8];
+    {
+      const Axis X = axis_weight_rt(poly, x0, lv_res), Y = axis_weight_rt(poly, x1, lv_res),
+                 Z = axis_weight_rt(poly, x2, lv_res);
+      corner_weights(X.t, Y.t, Z.t, w);
+      if (!hit) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[c] = 0.f;  // padding lanes and misses contribute nothing to f or to the scatter
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) st_w[c * V3_WP] = w[c];  // staging for the scatter: [level][corner][point]
+    float pf[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pf[q] = 0.f;
+#if SHINE_V3_DEDUP
+    // ---- node-run reuse: the points of a tile sit in a handful of nodes per level (the stream is node-ordered), so only
+    // the FIRST lane of each node run ("leader": its slot differs from its left neighbour's, or it opens the tile) loads
+    // the node's 8 corner ids and 8 x 32-B rows — into an LDS slot — and every lane of the run reads them back from
+    // there (conflict-free: slot pitch 68 floats).  The vector L1 is what this kernel saturates (TCP busy ~94 % of the
+    // time at one access per lane and 16 B, profiles/r02_pmc2_*): ~8 runs instead of 64 (point, level) pairs per tile
+    // cut its accesses for the gathers ~5x.  Slot index = rank of the leader in lane order (level-major); tiles with
+    // more runs than slots take another round.
+    {
+      const bool leader = hit && (slot != prev || pt == 0);
+      const unsigned long long lead64 = __ballot(leader);
+      const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(lead64 >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((unsigned int)lead64, 0u));
+      const int ridx = below + (leader ? 1 : 0) - 1;  // hit lanes: the slot of this lane's node
+      const int n_runs = __popcll(lead64);
+      for (int r0 = 0; r0 < n_runs; r0 += ROWCAP) {
+        const int rl = ridx - r0;
+        const bool mine = hit && rl >= 0 && rl < ROWCAP;
+        float* const slotp = U_rows + (mine ? rl : 0) * V3_SLOT;
+        if (leader && mine) {
+          const unsigned int sl = (unsigned int)slot;
+          const int4 ia = lv_vals[2u * sl], ib = lv_vals[2u * sl + 1u];  // the eight corner ids: two 16-B loads
+          const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+          // ids staged for the scatter, which reads them at run starts only (lanes that are not leaders never stage)
+#pragma unroll
+          for (int c = 0; c < 8; ++c) st_ids[c * V3_WP] = ids[c];
+#pragma unroll
+          for (int cb = 0; cb < 8; cb += V3_GB) {
+            float4 r0v[V3_GB], r1v[V3_GB];
+#pragma unroll
+            for (int c = 0; c < V3_GB; ++c) {
+              const float* row = lv_feat + (size_t)(unsigned int)ids[cb + c] * F;
+#if SHINE_V3_ABL & 8
+              r0v[c] = make_float4((float)ids[cb + c], 1.f, 2.f, 3.f);
+              r1v[c] = r0v[c];
+              (void)row;
+#else
+              r0v[c] = *reinterpret_cast<const float4*>(row);
+              r1v[c] = *reinterpret_cast<const float4*>(row + 4);
+#endif
+            }
+#pragma unroll
+            for (int c = 0; c < V3_GB; ++c) {
+              *reinterpret_cast<float4*>(slotp + (cb + c) * F) = r0v[c];
+              *reinterpret_cast<float4*>(slotp + (cb + c) * F + 4) = r1v[c];
+            }
+          }
+        }
+        wave_lds_fence();
+        if (mine) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float4 ra = *reinterpret_cast<const float4*>(slotp + c * F);
+            const float4 rb = *reinterpret_cast<const float4*>(slotp + c * F + 4);
+            const float wc = w[c];
+            pf[0] = fmaf(wc, ra.x, pf[0]);
+            pf[1] = fmaf(wc, ra.y, pf[1]);
+            pf[2] = fmaf(wc, ra.z, pf[2]);
+            pf[3] = fmaf(wc, ra.w, pf[3]);
+            pf[4] = fmaf(wc, rb.x, pf[4]);
+            pf[5] = fmaf(wc, rb.y, pf[5]);
+            pf[6] = fmaf(wc, rb.z, pf[6]);
+            pf[7] = fmaf(wc, rb.w, pf[7]);
+          }
+        }
+        wave_lds_fence();
+      }
+    }
+#else
+    {  // every lane gathers the 8 ids and the 8 x 32-B rows of its own (point, level)
+      const unsigned int sl = hit ? (unsigned int)slot : 0u;
+      const int4 ia = lv_vals[2u * sl], ib = lv_vals[2u * sl + 1u];  // the eight corner ids: two 16-B loads
+      const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+      // staging for the scatter: a miss stages -1 (trash row), never the speculative ids
+      const int mneg = hit ? 0 : -1;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) st_ids[c * V3_WP] = ids[c] | mneg;
+      // V3_GB corners (2 V3_GB 16-B loads) in flight at a time
+#pragma unroll
+      for (int cb = 0; cb < 8; cb += V3_GB) {
+        float4 r0[V3_GB], r1[V3_GB];
+#pragma unroll
+        for (int c = 0; c < V3_GB; ++c) {  // a miss reads row 0 with weight 0 (no branches)
+          const float* row = lv_feat + (size_t)(hit ? (unsigned int)ids[cb + c] : 0u) * F;
+#if SHINE_V3_ABL & 8
+          r0[c] = make_float4((float)ids[cb + c], 1.f, 2.f, 3.f);
+          r1[c] = r0[c];
+          (void)row;
+#else
+          r0[c] = *reinterpret_cast<const float4*>(row);
+          r1[c] = *reinterpret_cast<const float4*>(row + 4);
+#endif
+        }
+#pragma unroll
+        for (int c = 0; c < V3_GB; ++c) {
+          const float wc = w[cb + c];
+          pf[0] = fmaf(wc, r0[c].x, pf[0]);
+          pf[1] = fmaf(wc, r0[c].y, pf[1]);
+          pf[2] = fmaf(wc, r0[c].z, pf[2]);
+          pf[3] = fmaf(wc, r0[c].w, pf[3]);
+          pf[4] = fmaf(wc, r1[c].x, pf[4]);
+          pf[5] = fmaf(wc, r1[c].y, pf[5]);
+          pf[6] = fmaf(wc, r1[c].z, pf[6]);
+          pf[7] = fmaf(wc, r1[c].w, pf[7]);
+        }
+        if (V3_GB < 8) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#endif
+    // prefetch of tile t+1's point data, issued after every gather of this tile (vmcnt counts in order)
+    {
+      const long long ni = base + V3_TP + pt;
+      nvalid = ni < end;
+      np = 0;
+      nx0 = nx1 = nx2 = nlabel = 0.f;
+      nslot = -1;
+      if (nvalid) {
+        np = a.perm ? (long long)np2 : ni;
+        const long long si = a.pool_mode ? np : ni;
+        if (lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
+        nx0 = __builtin_nontemporal_load(a.coord + 3 * np);
+        nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
+        nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
+        nlabel = __builtin_nontemporal_load(a.label + np);
+      }
+      if (a.perm && ni + V3_TP < end) np2 = __builtin_nontemporal_load(a.perm + ni + V3_TP);
+    }
+    // reduce-scatter of the per-level sums over the point's four lanes: lane g ends with features (2g, 2g+1)
+    float f2[2];
+    {
+      float h4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h4[q] = xsum32(pf[q], pf[4 + q]);  // g < 2: features q, g >= 2: features 4 + q
+#pragma unroll
+      for (int t = 0; t < 2; ++t) f2[t] = xsum16(h4[t], h4[2 + t]);  // even g: t, odd g: 2 + t
+    }
+    SHINE_V3_PHASE_BARRIER  // phase boundary: no operand of the next phase is fetched early
+    SHINE_STAMP(1)  // query
+
+    // ================================================================ phase 2: decoder forward (MFMA chain)
+    f32x4 c1[2], c2[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float4 v1b = sb4[4 * m + g], v2b = sb4[8 + 4 * m + g];
+      c1[m][0] = v1b.x, c1[m][1] = v1b.y, c1[m][2] = v1b.z, c1[m][3] = v1b.w;
+      c2[m][0] = v2b.x, c2[m][1] = v2b.y, c2[m][2] = v2b.z, c2[m][3] = v2b.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) c1[m] = mfma16(opa[V3_OPA1 + (2 * m + t) * 64], f2[t], c1[m]);
+    float h1[8], h2[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) h1[r] = fmaxf(c1[r >> 2][r & 3], 0.f);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) c2[m] = mfma16(opa[V3_OPA2 + (8 * m + ks) * 64], h1[ks], c2[m]);
+    float yp = 0.f;
+    float w3r[8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float4 v = sb4[16 + 4 * m + g];
+      w3r[4 * m] = v.x, w3r[4 * m + 1] = v.y, w3r[4 * m + 2] = v.z, w3r[4 * m + 3] = v.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      h2[r] = fmaxf(c2[r >> 2][r & 3], 0.f);
+      yp = fmaf(w3r[r], h2[r], yp);
+    }
+    yp += __shfl_xor(yp, 16, 64);
+    const float y = yp + __shfl_xor(yp, 32, 64) + b3;
+    if (valid && g == 0 && a.pred) __builtin_nontemporal_store(y, a.pred + po);
+    SHINE_V3_PHASE_BARRIER  // phase boundary: no operand of the next phase is fetched early
+    SHINE_STAMP(2)  // decoder forward
+
+    // ================================================================ phase 3: loss
+    // BCEWithLogits(y, z) = max(y, 0) - y z + log1p(e), e = exp(-|y|); sigmoid(y) = 1 / (1 + e) or e / (1 + e) shares e.
+    // Hardware transcendentals (v_exp_f32, v_rcp_f32, v_log_f32: ~1 ulp) — errors ~1e-7, the contract is 1e-4.
+    float delta = 0.f;
+    {
+      const float zt = fast_sigmoid(label * inv_sigma);
+      const float e = __builtin_amdgcn_exp2f(-1.44269504088896f * fabsf(y));
+      const float r = __builtin_amdgcn_rcpf(1.0f + e);
+      const float sg = y >= 0.f ? r : e * r;
+      if (valid) {
+        if (g == 0) {
+          loss_acc += fmaxf(y, 0.f) - y * zt + 0.693147180559945f * __builtin_amdgcn_logf(1.0f + e);
+          cnt_acc += 1;
+        }
+        delta = (sg - zt) * a.inv_n;
+      }
+    }
+    // ================================================================ phase 4: backward through the decoder
+    float d2[8], d1[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      d2[r] = h2[r] > 0.f ? delta * w3r[r] : 0.f;
+      dw3c[r] = fmaf(delta, h2[r], dw3c[r]);
+    }
+    if (g == 0) db3 += delta;
+    f32x4 e1[2] = {zero4(), zero4()}, e0 = zero4();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) e1[m] = mfma16(opa[V3_OPA2T + (8 * m + ks) * 64], d2[ks], e1[m]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d1[r] = h1[r] > 0.f ? e1[r >> 2][r & 3] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) e0 = mfma16(opa[V3_OPA1T + ks * 64], d1[ks], e0);
+    const float df2[2] = {e0[0], e0[1]};  // d loss / d f for features 2g, 2g+1 of this lane's point
+    SHINE_V3_PHASE_BARRIER  // phase boundary: no operand of the next phase is fetched early
+    SHINE_STAMP(3)  // loss + decoder backward
+
+    // ================================================================ phase 5: decoder weight grads (transposed MFMA)
+    if (a.decoder_grad_on && !(SHINE_V3_ABL & 2)) {
+      const int i16 = lane & 15;  // operand role: row / column i16 = lane & 15, points 4 kk .. 4 kk + 3 (kk = lane >> 4)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {  // channel 16 (r >> 2) + 4 g + (r & 3)
+        t_wr[(16 * (r >> 2) + (r & 3)) * V3_TT] = d2[r];
+        t_wr[(32 + 16 * (r >> 2) + (r & 3)) * V3_TT] = h1[r];
+      }
+      wave_lds_fence();
+      {
+        float4 la[2], lb[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          la[m] = *reinterpret_cast<const float4*>(t_rd + (16 * m) * V3_TT);
+          lb[m] = *reinterpret_cast<const float4*>(t_rd + (32 + 16 * m) * V3_TT);
+          db2acc[m] += (la[m].x + la[m].y) + (la[m].z + la[m].w);  // db2 rides on the transposed operands
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {  // dW2[out][in] += d2[out][k] h1[in][k]
+            accW2[m][n] = mfma16(la[m].x, lb[n].x, accW2[m][n]);
+            accW2[m][n] = mfma16(la[m].y, lb[n].y, accW2[m][n]);
+            accW2[m][n] = mfma16(la[m].z, lb[n].z, accW2[m][n]);
+            accW2[m][n] = mfma16(la[m].w, lb[n].w, accW2[m][n]);
+          }
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t_wr[(16 * (r >> 2) + (r & 3)) * V3_TT] = d1[r];
+      f_wr[32 * V3_TT] = f2[0];
+      f_wr[33 * V3_TT] = f2[1];
+      wave_lds_fence();
+      {
+        float4 la[2];
+        // B columns 0..7 = f, column 8 = ones: accW1[:, 8] accumulates db1 = sum_k d1[ch][k] in the spare MFMA lanes
+        float4 lb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i16 < F) lb = *reinterpret_cast<const float4*>(t_rd + 32 * V3_TT);
+        if (i16 == F) lb = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) la[m] = *reinterpret_cast<const float4*>(t_rd + (16 * m) * V3_TT);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {  // dW1[ch][feat] += d1[ch][k] f[feat][k]
+          accW1[m] = mfma16(la[m].x, lb.x, accW1[m]);
+          accW1[m] = mfma16(la[m].y, lb.y, accW1[m]);
+          accW1[m] = mfma16(la[m].z, lb.z, accW1[m]);
+          accW1[m] = mfma16(la[m].w, lb.w, accW1[m]);
+        }
+      }
+      wave_lds_fence();
+    }
+    SHINE_V3_PHASE_BARRIER  // phase boundary: no operand of the next phase is fetched early
+    SHINE_STAMP(5)  // weight grads
+
+    // ================================================================ phase 6: feature-grad scatter (run-length)
+    f_wr[V3_DF] = df2[0];
+    f_wr[V3_DF + V3_DFP] = df2[1];
+    wave_lds_fence();
+    if (!(SHINE_V3_ABL & 4)) {
+      constexpr int CH = 8;  // points per chunk (register budget)
+      // this lane's trash level: the points that miss level sc
+      const unsigned int mymiss = sc < L ? (~(unsigned int)(hit64 >> (16 * (sc & 3))) & validmask) : 0u;
+#pragma unroll
+      for (int ch = 0; ch < V3_TP / CH; ++ch) {
+        float dfr[CH];
+#pragma unroll
+        for (int j = 0; j < CH / 4; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(sc_df + CH * ch + 4 * j);
+          dfr[4 * j] = v.x;
+          dfr[4 * j + 1] = v.y;
+          dfr[4 * j + 2] = v.z;
+          dfr[4 * j + 3] = v.w;
+        }
+        {  // trash rows: the plain sum of df over the misses (the 8 corner weights of a missed node sum to 1)
+          const unsigned int mm = mymiss >> (CH * ch);
+#pragma unroll
+          for (int p2 = 0; p2 < CH; ++p2) {
+            const unsigned int keep = 0u - ((mm >> p2) & 1u);
+            trash_sum += __uint_as_float(__float_as_uint(dfr[p2]) & keep);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < L; ++s) {
+          float* gbase = a.lv[s].grad;
+          if (gbase) {
+            float wr[CH];
+            int idr[CH];
+#pragma unroll
+            for (int j = 0; j < CH / 4; ++j) {
+              const float4 v = *reinterpret_cast<const float4*>(sc_w + (s * 8) * V3_WP + CH * ch + 4 * j);
+              wr[4 * j] = v.x;
+              wr[4 * j + 1] = v.y;
+              wr[4 * j + 2] = v.z;
+              wr[4 * j + 3] = v.w;
+              const int4 u = *reinterpret_cast<const int4*>(sc_ids + (s * 8) * V3_WP + CH * ch + 4 * j);
+              idr[4 * j] = u.x;
+              idr[4 * j + 1] = u.y;
+              idr[4 * j + 2] = u.z;
+              idr[4 * j + 3] = u.w;
+            }
+            int rid = run_id[s], rhit = run_hit[s];
+            float racc = run_acc[s];
+            const unsigned int cm = ((unsigned int)(chg64 >> (16 * s)) & 0xFFFFu) >> (CH * ch);
+            const unsigned int hm = ((unsigned int)(hit64 >> (16 * s)) & 0xFFFFu) >> (CH * ch);
+#pragma unroll
+            for (int p2 = 0; p2 < CH; ++p2) {
+              if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
+                if (rhit && !(SHINE_V3_ABL & 1)) atomic_add_f32(gbase + (unsigned int)rid, racc);  // scalar branch
+                racc = 0.f;
+                rid = (idr[p2] << 3) | sq;  // float offset of this lane's (corner row, feature)
+                rhit = (int)((hm >> p2) & 1u);
+              }
+              racc = fmaf(wr[p2], dfr[p2], racc);  // misses and padding lanes staged w = 0
+            }
+            run_id[s] = rid;
+            run_hit[s] = rhit;
+            run_acc[s] = racc;
+          }
+          SHINE_V3_LEVEL_BARRIER  // one level's staged operands in registers at a time
+        }
+      }
+    }
+    wave_lds_fence();
+    SHINE_STAMP(4)  // scatter
+  }
+
+  // ---- end of the wave's run: flush the open node runs
+#pragma unroll
+  for (int s = 0; s < L; ++s) {
+    float* gbase = a.lv[s].grad;
+    if (gbase && run_hit[s]) atomic_add_f32(gbase + (unsigned int)run_id[s], run_acc[s]);
+  }
+  __syncthreads();  // every wave is done with its staging region: it now holds the wave's partial vector
+  float* wvec = s_wave[wv];
+  if (sc < L) wvec[PART_TRASH + sc * 8 + sq] = trash_sum;
+  if (a.decoder_grad_on) {
+    const int jc = lane & 15, rr = lane >> 4;  // accumulator role: column jc, rows 4 rr + r
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * m + 4 * rr + r;
+        wvec[MLP_W2 + row * H + jc] = accW2[m][0][r];
+        wvec[MLP_W2 + row * H + 16 + jc] = accW2[m][1][r];
+        if (jc <= F) wvec[jc < F ? MLP_W1 + row * F + jc : MLP_B1 + row] = accW1[m][r];  // column 8 of accW1 is db1
+        const float w3v = row16_sum(dw3c[4 * m + r]);  // channel 16 m + 4 g + r over the 16 points of the DPP row
+        if (pt == 0) wvec[MLP_W3 + 16 * m + 4 * g + r] = w3v;
+      }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {  // channel 16 m + (lane & 15), the four point groups kk
+      float v = db2acc[m];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) wvec[MLP_B2 + 16 * m + lane] = v;
+    }
+    const float b3v = wave_sum(db3);
+    if (lane == 0) wvec[MLP_B3] = b3v;
+  }
+  {
+    const double ls = wave_sum_d((double)loss_acc), cs = wave_sum_d((double)cnt_acc);
+    if (lane == 0) {
+      atomicAdd(&s_loss[0], ls);
+      atomicAdd(&s_loss[1], cs);
+    }
+  }
+  SHINE_STAMP(6)  // flush
+  __syncthreads();
+  SHINE_STAMP(7)  // wait for the workgroup
+  if (PROF && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a.prof[wave_g * 8 + k] = pc[k];
+  }
+  const int mlp_lo = a.decoder_grad_on ? 0 : SHINE_MLP_PARAMS;  // a frozen decoder has no sums to move
+  float* dst = a.partials + (long long)blockIdx.x * PART_STRIDE;
+  for (int idx = tid; idx < PART_TRASH + L * 8; idx += NT) {
+    float v = 0.f;
+    if (idx >= mlp_lo) {
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) v += s_wave[w][idx];
+    }
+    dst[idx] = v;
+  }
+  for (int idx = PART_TRASH + L * 8 + tid; idx < PART_FLOATS; idx += NT) dst[idx] = 0.f;
+  if (tid == 0) {
+    double* dl = reinterpret_cast<double*>(dst + PART_LOSS);
+    dl[0] = s_loss[0];
+    dl[1] = s_loss[1];
+    dl[2] = 0.0;
+  }
+#undef SHINE_STAMP
+}
+
+// x[l] + y[l ^ 32] style exchanges through v_permlane32_swap / v_permlane16_swap: pins the lane maps xsum32 / xsum16 assume
+__global__ void k_selftest_permlane(const float* x, const float* y, float* o32, float* o16) {
+  const int lane = threadIdx.x;
+  o32[lane] = xsum32(x[lane], y[lane]);
+  o16[lane] = xsum16(x[lane], y[lane]);
+}
+
+V2Geometry v3_geometry(long long n) {
+  V2Geometry g;
+  long long tiles = (n + V3_TP - 1) / V3_TP;
+  if (tiles < 1) tiles = 1;
+  g.tiles = tiles;
+  g.wg_waves = tiles < 2048 ? 4 : V3_BIG;  // small batches: 4-wave workgroups spread over more CUs
+  const long long max_waves = 256 * V3_BIG;  // resident waves of the full-chip launch
+  const long long waves = tiles < max_waves ? tiles : max_waves;
+  g.blocks = (waves + g.wg_waves - 1) / g.wg_waves;
+  g.waves = g.blocks * g.wg_waves;  // every launched wave takes its share (a wave beyond the tile count gets none)
+  g.chunk = 0;
+  return g;
+}
+
+long long v3_lds_bytes(int wg_waves) {
+  const int rowcap = SHINE_V3_DEDUP ? (wg_waves <= 8 ? 32 : 12) : 0;
+  return (long long)sizeof(float) * (V3_OPTOTAL + 100 + (long long)wg_waves * (V3_WAVE_FLOATS + rowcap * V3_SLOT)) +
+         4 * sizeof(double);
+}
+
+template <int L>
+static void launch_v3(const V1Args& a, const V2Geometry& g, hipStream_t st) {
+  const dim3 grid((unsigned)g.blocks);
+  if (a.prof) {
+    if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, true>), grid, dim3(V3_BIG * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_step_v3<L, 4, true>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, false>), grid, dim3(V3_BIG * 64), 0, st, a);
+  else hipLaunchKernelGGL((k_step_v3<L, 4, false>), grid, dim3(256), 0, st, a);
+}
+
+}  // namespace shine
+
+using namespace shine;
+
+extern "C" int shine_selftest_permlane(const float* x, const float* y, float* o32, float* o16, void* stream) {
+  if (!x || !y || !o32 || !o16) return set_error(SHINE_E_INVALID, "shine_selftest_permlane: null argument");
+  hipLaunchKernelGGL(k_selftest_permlane, dim3(1), dim3(64), 0, (hipStream_t)stream, x, y, o32, o16);
+  SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
+}
+
+// same contract as shine_train_step_v1 (shine_step_v1.hip); BCE only, planned / pool batches, needs the workspace
+extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                                   const float* sdf_label, const float* weight, const int32_t* perm,
+                                   const int32_t* slots, const int64_t* n_surf, int64_t n, const float* const* feats,
+                                   const int64_t* rows, const float* const* mlp, float* pred_out, float* grad_x_out,
+                                   float* const* grad_feats, float* const* grad_mlp, double* loss_parts,
+                                   unsigned char* const* touched, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  if (cfg->eikonal_on) return set_error(SHINE_E_INVALID, "shine_train_step_v3: BCE only");
+  if (!slots) return set_error(SHINE_E_INVALID, "shine_train_step_v3: needs a planned batch (slots)");
+  V1Args a = {};
+  int rc = fill_step_args(&a, t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
+                          grad_x_out, grad_feats, grad_mlp, loss_parts, touched);
+  if (rc != SHINE_OK) return rc;
+  if (n == 0) return SHINE_OK;
+  const V2Geometry g = v3_geometry(n);
+  a.tiles = g.tiles;
+  a.waves_total = g.waves;
+  a.prof = g_prof_buffer;
+  const size_t need = (size_t)g.blocks * PART_STRIDE * sizeof(float);
+  if (!workspace || workspace_bytes < need)
+    return set_error(SHINE_E_INVALID, "shine_train_step_v3: workspace too small (shine_train_step_workspace_bytes)");
+  a.partials = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  if (touched) {
+    hipLaunchKernelGGL(k_mark_touched, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    SHINE_HIP_CHECK(hipGetLastError());
+  }
+  switch (cfg->n_levels) {
+    case 1: launch_v3<1>(a, g, st); break;
+    case 2: launch_v3<2>(a, g, st); break;
+    case 3: launch_v3<3>(a, g, st); break;
+    default: launch_v3<4>(a, g, st); break;
+  }
+  SHINE_HIP_CHECK(hipGetLastError());
+  if (!(a.ablate & 32)) {  // (ablate bit 32: measurement only — time the dominant kernel by itself)
+    hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks);
+    SHINE_HIP_CHECK(hipGetLastError());
+  }
+  return SHINE_OK;
+}

@@ -357,6 +357,24 @@ def test_mfma16_lane_maps_on_hardware():
     assert abs_err(d, a.double() @ b.double()) <= 1e-5
 
 
+def test_permlane_swap_lane_maps_on_hardware():
+    """v_permlane32_swap / v_permlane16_swap as the lane = (point, level) kernel uses them for its reduce-scatter."""
+    from shine_mapping_amd import _lib
+
+    torch.manual_seed(0)
+    x = torch.randn(64, device="cuda")
+    y = torch.randn(64, device="cuda")
+    o32 = torch.zeros(64, device="cuda")
+    o16 = torch.zeros(64, device="cuda")
+    _lib.check(_lib.lib().shine_selftest_permlane(x.data_ptr(), y.data_ptr(), o32.data_ptr(), o16.data_ptr(),
+                                                  _lib.current_stream_handle()))
+    torch.cuda.synchronize()
+    l = torch.arange(64, device="cuda")
+    e32 = torch.where(l < 32, x + x[(l + 32) % 64], y + y[(l - 32) % 64])
+    e16 = torch.where((l & 16) != 0, y + y[(l - 16) % 64], x + x[(l + 16) % 64])
+    assert torch.equal(o32, e32) and torch.equal(o16, e16)
+
+
 @pytest.mark.parametrize("n", [1, 15, 17, 257, 4096, 40000])
 @pytest.mark.parametrize("variant", [2, 3])
 def test_ragged_batches_on_both_mfma_kernels(n, variant):

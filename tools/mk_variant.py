@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Build a VARIANT of libshine_hip.so for an in-process A/B on the GPU box (tools/ab_build.py):
+
+    python tools/mk_variant.py NAME [-DMACRO=1 ...] [--src shine_step_v2.hip ...]
+
+recompiles the named sources (default: the two fused-step kernels) with the extra flags, links them with the other
+objects of the current build (shine_mapping_amd/build/*.o) and writes tools/ab/lib_NAME.so (git-ignored; it travels
+with the gpurun snapshot)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from shine_mapping_amd import build as b  # noqa: E402
+
+name = sys.argv[1]
+flags = [a for a in sys.argv[2:] if a.startswith("-")]
+srcs = [a for a in sys.argv[2:] if a.endswith(".hip")] or ["shine_step_v2.hip", "shine_step_v1.hip"]
+b.build(verbose=False)
+out_dir = os.path.join(ROOT, "tools", "ab")
+os.makedirs(out_dir, exist_ok=True)
+objs = []
+for src in b.sources():
+    obj = os.path.join(b.OBJDIR, src.replace(".hip", ".o"))
+    if src in srcs:
+        obj = os.path.join(out_dir, "%s_%s.o" % (name, src.replace(".hip", "")))
+        subprocess.check_call([b.HIPCC] + b.FLAGS + flags + ["-c", os.path.join(b.CSRC, src), "-o", obj])
+    objs.append(obj)
+lib = os.path.join(out_dir, "lib_%s.so" % name)
+subprocess.check_call([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+print(lib)
