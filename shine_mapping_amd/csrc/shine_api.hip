@@ -60,6 +60,17 @@ bool v2_serves(const shine_step_config* cfg) {
   if (variant != 0 || force_v1) return false;
   return !cfg->eikonal_on && cfg->n_levels <= LCAP;
 }
+// the lane = (point, level) kernel: any planned / pool batch with <= 4 levels, unless another kernel is forced
+bool v3_serves(const shine_step_config* cfg, bool planned) {
+  static const int force_v1 = []() {
+    const char* e = getenv("SHINE_KERNEL");
+    return (e && strcmp(e, "v1") == 0) ? 1 : 0;
+  }();
+  const int variant = cfg->kernel_variant & 0xff;
+  if (!planned || cfg->n_levels > LCAP) return false;
+  if (variant == 4) return true;
+  return variant == 0 && !force_v1;
+}
 }  // namespace shine
 
 extern "C" int shine_version(void) { return 200; }
@@ -97,13 +108,14 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
   // yaml); v0 is the cross-check kernel and the fallback for deeper trees.
   const int variant = cfg->kernel_variant & 0xff;
   const size_t v2_need = shine_train_step_workspace_bytes(cfg, n);
-  if ((variant == 3 || variant == 4) && !shine::v2_serves(cfg))
-    return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 3 / 4 (16-point tiles) serve BCE steps only");
-  if (variant == 4 && !slots)
-    return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 4 needs a planned batch (slots)");
-  // 16-point tiles: planned / pool batches run on the lane = (point, level) kernel (shine_step_v3.hip), batches without
-  // a plan (in-kernel probing) on shine_step_v2.hip; kernel_variant 3 forces the latter
-  if (!force_v0 && workspace && workspace_bytes >= v2_need && shine::v2_serves(cfg) && slots && variant != 3)
+  if (variant == 3 && !shine::v2_serves(cfg))
+    return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 3 (16-point tiles, in-kernel probing) serves BCE steps only");
+  if (variant == 4 && (!slots || cfg->n_levels > 4))
+    return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 4 needs a planned batch (slots) and <= 4 levels");
+  // 16-point tiles: planned / pool batches (BCE or BCE + eikonal) run on the lane = (point, level) kernel
+  // (shine_step_v3.hip); BCE batches without a plan (in-kernel probing) on shine_step_v2.hip; everything else that has
+  // <= 4 levels on the 32-point kernel (shine_step_v1.hip).  kernel_variant 2 / 3 / 4 force v1 / v2 / v3.
+  if (!force_v0 && workspace && workspace_bytes >= v2_need && shine::v3_serves(cfg, slots != nullptr))
     return shine_train_step_v3(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
                                grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,
                                stream);

@@ -105,6 +105,7 @@ V2Geometry v3_geometry(long long n);  // shine_step_v3.hip: tiles dealt evenly t
 long long v3_lds_bytes(int wg_waves);
 // true when the 16-point-tile kernel serves this configuration (and is the faster one): see shine_api.hip
 bool v2_serves(const shine_step_config* cfg);
+bool v3_serves(const shine_step_config* cfg, bool planned);
 
 // measurement aid (shine_debug_set_profile_buffer): per-wave phase cycle counters or null
 extern long long* g_prof_buffer;

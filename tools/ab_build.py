@@ -96,6 +96,9 @@ for kind, pts, lv in CASES:
                 torch.save({"prof": prof, "slots": slots_b, "lib": name, "kind": kind, "levels": lv},
                            os.path.join(os.environ["AB_PROF_DUMP"], "prof_%s_%s_L%d.pt" % (os.path.basename(name), kind, lv)))
             used = prof[prof.sum(1) > 0]
+            if used.shape[0] == 0:
+                print('  prof %-16s (this kernel has no instrumented instantiation)' % os.path.basename(name))
+                continue
             tot = used.sum(1)
             print("  prof %-16s %d waves, cycles per wave mean (max): " % (os.path.basename(name), used.shape[0]) +
                   ", ".join("%s %.0f (%.0f)" % (nm, float(used[:, k].mean()), float(used[:, k].max())) for k, nm in enumerate(names)) +
