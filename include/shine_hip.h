@@ -65,6 +65,8 @@ typedef struct shine_step_config {
   int64_t n_global;        /* global batch size (data parallel)        */
   int32_t sort_origin[3];  /* leaf-level voxel coords of the map's bounding-box corner (shine_morton_sort) */
   int32_t sort_bits[3];    /* bits per axis that cover the box; 0 = whole cube (tree_level_world bits)     */
+  int32_t loss_weight_on;  /* 1: BCEWithLogitsLoss(weight=|weight|) (utils/loss.py:18-19, shine_batch.py:172-174):
+                              every sample's BCE term is multiplied by |weight[i]| (the reduction still divides by N) */
 } shine_step_config;
 
 /* ---- library ------------------------------------------------------------------------- */

@@ -48,6 +48,7 @@ def make_config(**kw) -> SimpleNamespace:
         loss_reduction="mean",
         ekional_loss_on=False,
         weight_e=0.1,
+        loss_weight_on=False,
         lambda_forget=1e5,
         surface_sample_range_m=0.5,
         surface_sample_n=5,
@@ -266,10 +267,12 @@ def to_wide(octree: "OracleOctree", mlp: "OracleDecoder", dtype=torch.float64) -
         setattr(mlp, n, getattr(mlp, n).detach().to(dtype).requires_grad_(True))
 
 
-def sdf_bce_loss(pred, label, sigma, reduction="mean"):
-    """utils/loss.py:17-24 with weighted=False (loss_weight_on is False in all 15 shipped yamls)."""
+def sdf_bce_loss(pred, label, sigma, reduction="mean", weight=None):
+    """utils/loss.py:17-24; `weight` is the `weighted=True` form (nn.BCEWithLogitsLoss(weight=weight): every element's
+    term is scaled, the mean still divides by N).  loss_weight_on is False in all 15 shipped yamls."""
     target = torch.sigmoid(label / sigma).to(pred.dtype)
-    return torch.nn.functional.binary_cross_entropy_with_logits(pred, target, reduction=reduction)
+    w = None if weight is None else weight.to(pred.dtype)
+    return torch.nn.functional.binary_cross_entropy_with_logits(pred, target, weight=w, reduction=reduction)
 
 
 def coord_gradient(coord, pred):
@@ -300,7 +303,8 @@ def train_step(octree: OracleOctree, mlp: OracleDecoder, coord, sdf_label, weigh
     g = None
     if eik:
         g = coord_gradient(coord, pred) * sig
-    loss = sdf_bce_loss(pred, sdf_label, sig, cfg.loss_reduction)
+    loss = sdf_bce_loss(pred, sdf_label, sig, cfg.loss_reduction,
+                        weight=torch.abs(weight) if getattr(cfg, "loss_weight_on", False) else None)  # shine_batch.py:172-174
     parts = {"bce": loss.detach().clone()}
     if regularize:
         reg = octree.cal_regularization()

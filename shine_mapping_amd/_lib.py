@@ -33,6 +33,7 @@ class StepConfig(C.Structure):
         ("n_global", C.c_int64),
         ("sort_origin", C.c_int32 * 3),
         ("sort_bits", C.c_int32 * 3),
+        ("loss_weight_on", C.c_int32),
     ]
 
 

@@ -119,11 +119,16 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
     return shine_train_step_v3(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
                                grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,
                                stream);
-  if (!force_v0 && workspace && workspace_bytes >= v2_need && shine::v2_serves(cfg))
+  // the |weight|-scaled BCE (loss_weight_on, off in every shipped yaml) is built into the planned-batch kernel above and
+  // into v0: a weighted batch WITHOUT a plan takes the simple kernel
+  const bool weighted_unplanned = cfg->loss_weight_on != 0;
+  if (weighted_unplanned && (variant == 2 || variant == 3))
+    return shine::set_error(SHINE_E_INVALID, "shine_train_step: loss_weight_on runs on kernel_variant 0 / 1 / 4");
+  if (!force_v0 && !weighted_unplanned && workspace && workspace_bytes >= v2_need && shine::v2_serves(cfg))
     return shine_train_step_v2(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
                                grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,
                                stream);
-  if (!force_v0 && variant != 1 && cfg->n_levels <= 4)
+  if (!force_v0 && !weighted_unplanned && variant != 1 && cfg->n_levels <= 4)
     return shine_train_step_v1(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
                                grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,
                                stream);

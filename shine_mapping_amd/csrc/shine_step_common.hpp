@@ -53,6 +53,7 @@ struct V1Args {
   int reduction_sum;
   int decoder_grad_on;
   int poly;
+  int weighted;   // 1: every sample's BCE term (and its gradient) is multiplied by |weight| (utils/loss.py:18-19)
   int pool_mode;  // 1: coord/label/weight/slots are a node-ordered POOL indexed by perm[i] (sorted sample indices,
                   //    shine_sample_sorted); pred / grad_x are written at the batch position i.  0: a batch.
   int ablate;  // debug only (kernel_variant >> 8): 1 no feature atomics, 2 no weight-grad phase, 4 no scatter phase,
@@ -126,6 +127,7 @@ inline int fill_step_args(V1Args* a, const shine_tables* t, const shine_step_con
   if (cfg->n_levels > LCAP) return set_error(SHINE_E_INVALID, "shine_train_step: the MFMA kernels handle up to 4 featured levels");
   if (cfg->eikonal_on && (!weight || !n_surf))
     return set_error(SHINE_E_INVALID, "shine_train_step: eikonal needs weight and n_surf");
+  if (cfg->loss_weight_on && !weight) return set_error(SHINE_E_INVALID, "shine_train_step: loss_weight_on needs weight");
   LevelSet ls = {};
   int rc = make_level_set(t, cfg, feats, rows, grad_feats, &ls);
   if (rc != SHINE_OK) return rc;
@@ -166,6 +168,7 @@ inline int fill_step_args(V1Args* a, const shine_tables* t, const shine_step_con
   a->reduction_sum = cfg->reduction_sum;
   a->decoder_grad_on = cfg->decoder_grad_on;
   a->poly = cfg->poly_int_on;
+  a->weighted = cfg->loss_weight_on ? 1 : 0;
   a->pool_mode = cfg->sorted_input == 2 ? 1 : 0;
   if (a->pool_mode && !perm) return set_error(SHINE_E_INVALID, "shine_train_step: pool mode needs the sample indices in perm");
   a->ablate = cfg->kernel_variant >> 8;

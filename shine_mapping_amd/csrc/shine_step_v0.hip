@@ -36,6 +36,7 @@ struct StepArgs {
   int n_levels;
   int reduction_sum;
   int decoder_grad_on;
+  int weighted;  // BCE terms scaled by |weight| (utils/loss.py:18-19)
   float sigma;
   float weight_e;
   float inv_n;
@@ -209,10 +210,11 @@ __global__ __launch_bounds__(256) void k_step_v0(StepArgs a) {
       float qv[3] = {0.f, 0.f, 0.f};
       if (valid) {
         float zt = sigmoidf_acc(a.label[p] / sigma);
-        float li = fmaxf(y, 0.f) - y * zt + log1pf(expf(-fabsf(y)));
+        const float lw = a.weighted ? fabsf(a.weight[p]) : 1.0f;  // BCEWithLogitsLoss(weight=|weight|), utils/loss.py:18-19
+        float li = lw * (fmaxf(y, 0.f) - y * zt + log1pf(expf(-fabsf(y))));
         loss_acc += (double)li;
         cnt_acc += 1.0;
-        delta = (sigmoidf_acc(y) - zt) * a.inv_n;
+        delta = lw * (sigmoidf_acc(y) - zt) * a.inv_n;
         if (EIK && a.weight[p] > 0.f) {
           float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
           float e = 1.0f - gn;
@@ -523,6 +525,7 @@ extern "C" int shine_train_step_v0(const shine_tables* t, const shine_step_confi
   a.n = n;
   a.n_levels = cfg->n_levels;
   a.reduction_sum = cfg->reduction_sum;
+  a.weighted = cfg->loss_weight_on ? 1 : 0;
   a.decoder_grad_on = cfg->decoder_grad_on;
   a.sigma = cfg->sigma;
   a.weight_e = cfg->weight_e;

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     nx1 = a.coord[3 * np + 1];
     nx2 = a.coord[3 * np + 2];
     nlabel = a.label[np];
-    if (EIK) nweight = a.weight[np];
+    if (EIK || a.weighted) nweight = a.weight[np];
   }
   SHINE_STAMP(0)  // setup
 
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
         nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
         nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
         nlabel = __builtin_nontemporal_load(a.label + np);
-        if (EIK) nweight = __builtin_nontemporal_load(a.weight + np);
+        if (EIK || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
       }
       if (a.perm && ni + V3_TP < end) np2 = __builtin_nontemporal_load(a.perm + ni + V3_TP);
     }
@@ -501,11 +501,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
       const float r = __builtin_amdgcn_rcpf(1.0f + e);
       const float sg = y >= 0.f ? r : e * r;
       if (valid) {
+        const float lw = a.weighted ? fabsf(wgt) : 1.0f;  // BCEWithLogitsLoss(weight=|weight|), utils/loss.py:18-19
         if (g == 0) {
-          loss_acc += fmaxf(y, 0.f) - y * zt + 0.693147180559945f * __builtin_amdgcn_logf(1.0f + e);
+          loss_acc += lw * (fmaxf(y, 0.f) - y * zt + 0.693147180559945f * __builtin_amdgcn_logf(1.0f + e));
           cnt_acc += 1;
         }
-        delta = (sg - zt) * a.inv_n;
+        delta = lw * (sg - zt) * a.inv_n;
       }
     }
     float sdf2[2];  // what the scatter multiplies the staged weights with: d loss / d f (BCE build), d y / d f (eikonal build)

@@ -16,8 +16,8 @@ from .ops import StepOptions, _dense_grad, fused_train_step
 
 def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduction="mean", loss_weight_on=False):
     """Same signature as the reference; `data` needs .coord_pool and .sdf_label_pool (utils/incre_learning.py:14-26)."""
-    if loss_weight_on:
-        raise NotImplementedError("loss_weight_on is False in every shipped config")
+    # loss_weight_on has no effect here, as in the reference: it passes weight=None (utils/incre_learning.py:32), and
+    # nn.BCEWithLogitsLoss(weight=None) is the unweighted loss
     sample_count = data.coord_pool.shape[0]
     batch_interval = bs * down_rate
     iter_n = math.ceil(sample_count / batch_interval)

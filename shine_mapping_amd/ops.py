@@ -28,6 +28,7 @@ class StepOptions:
     loss_reduction: str = "mean"      # "mean" | "sum" (shine_incre.py:77-78)
     ekional_loss_on: bool = False     # (sic) config key of the reference
     weight_e: float = 0.1
+    loss_weight_on: bool = False      # BCEWithLogitsLoss(weight=|weight|), utils/loss.py:18-19 (False in all shipped yamls)
     n_global: Optional[int] = None    # global batch size under data parallelism (defaults to local N)
     decoder_grad_on: Optional[bool] = None  # default: any decoder parameter requires grad (freeze_model, tools.py:188)
     kernel_variant: int = 0           # 0 auto; 1 the simple v0 kernel (on-device cross-check); 2 / 3 force the 32- /
@@ -142,6 +143,8 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
     dev = coord.device
     sdf_label = _f32(sdf_label, "sdf_label")
     eik = bool(opts.ekional_loss_on)
+    if bool(opts.loss_weight_on) and weight is None:
+        raise ValueError("loss_weight_on needs the sample weights")
     if eik or weight is not None:
         weight = _f32(weight, "weight")
     if opts.loss_reduction not in ("mean", "sum"):
@@ -156,7 +159,7 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         sigma=float(opts.sigma), weight_e=float(opts.weight_e), eikonal_on=1 if eik else 0,
         reduction_sum=1 if opts.loss_reduction == "sum" else 0, decoder_grad_on=1 if dec_grad else 0,
         sorted_input=2 if pool_mode else (0 if perm is None else 1), n_global=n_global,
-        kernel_variant=int(opts.kernel_variant),
+        kernel_variant=int(opts.kernel_variant), loss_weight_on=1 if opts.loss_weight_on else 0,
         inv_n=(1.0 if opts.loss_reduction == "sum" else 1.0 / max(n_global, 1)),
     )
     if eik and n_surf is None:

@@ -404,3 +404,91 @@ def test_ragged_batches_on_both_mfma_kernels(n, variant):
         assert rel_err(octree.hier_features[k].grad, r) <= TOL
     for p, r in zip(dec.fused_params(), ref["mlp_grads"]):
         assert rel_err(p.grad, r) <= TOL
+
+
+@pytest.mark.parametrize("mode", ["planned", "plain", "pool"])
+@pytest.mark.parametrize("name", ["maicity_bce_L4", "kitti_eik_L3"])
+def test_weighted_bce_matches_oracle(name, mode):
+    """loss_weight_on (utils/loss.py:18-19, shine_batch.py:172-174): BCEWithLogitsLoss(weight=|weight|).  Planned and pool
+    batches run the lane = (point, level) kernel, a batch without a plan the simple kernel."""
+    from oracle import shine_oracle as so
+    from shine_mapping_amd import dp, fused_train_step
+    from shine_mapping_amd.sampler import SortedPool
+
+    fx = load_golden(name)
+    cfg, octree, dec = product_from_golden(fx)
+    ocfg, oct_, mlp = oracle_from_golden(fx)
+    ocfg.loss_weight_on = True
+    torch.manual_seed(11)
+    c, l = fx["coord"], fx["sdf_label"]
+    w = fx["weight"] * (0.25 + 1.5 * torch.rand_like(fx["weight"]))  # keeps the sign (surface / free space), varies |w|
+    opts = step_options(fx)
+    opts.loss_weight_on = True
+    if mode == "pool":
+        octree._require_tables(with_ranks=True)
+        sp = SortedPool(octree, c.cuda(), l.cuda(), w.cuda(), seed=4)
+        idx = sp.draw(3000)
+        loss, pred, _ = fused_train_step(octree, dec, None, None, None, opts, pool=sp, idx=idx)
+        c, l, w = (t.cpu() for t in sp.get_batch(idx))
+    elif mode == "planned":
+        perm, slots = dp.plan_batch(octree, c.cuda())
+        loss, pred, _ = fused_train_step(octree, dec, c.cuda(), l.cuda(), w.cuda(), opts, perm=perm, slots=slots)
+    else:
+        loss, pred, _ = fused_train_step(octree, dec, c.cuda(), l.cuda(), w.cuda(), opts)
+    torch.cuda.synchronize()
+    ref = so.train_step(oct_, mlp, c, l, w, ocfg)
+    assert abs_err(pred, ref["pred"]) <= TOL
+    assert abs(float(loss) - float(ref["loss"])) <= TOL * max(1.0, abs(float(ref["loss"])))
+    for k, r in enumerate(ref["feat_grads"]):
+        assert rel_err(octree.hier_features[k].grad, r) <= TOL
+    for p, r in zip(dec.fused_params(), ref["mlp_grads"]):
+        assert rel_err(p.grad, r) <= TOL
+
+
+@pytest.mark.parametrize("levels", [1, 2, 3, 4])
+@pytest.mark.parametrize("eik", [False, True])
+@pytest.mark.parametrize("n", [1, 17, 300, 4099, 40000])
+def test_planned_ragged_batches_on_the_point_level_kernel(n, eik, levels):
+    """kernel_variant 4 (shine_step_v3.hip) on planned batches of awkward sizes and every level count: partial tiles,
+    waves without tiles, the 4-wave and the full-chip workgroup shapes, lanes of levels the tree does not have."""
+    from oracle import shine_oracle as so
+    from shine_mapping_amd import Decoder, FeatureOctree, StepOptions, dp, fused_train_step, synth
+
+    cfg = synth.make_config("kitti" if eik else "maicity", device="cuda", tree_level_feat=levels)
+    torch.manual_seed(3)
+    octree, dec = FeatureOctree(cfg), Decoder(cfg).cuda()
+    frames = list(synth.make_frames(cfg, frames=2, beams=16, azimuths=120, seed=9, device="cuda"))
+    for c, l, w in frames:
+        octree.update(c[w > 0])
+    with torch.no_grad():
+        for p in octree.hier_features:
+            p[:-1] *= 8.0
+    pc, pl, pw = (torch.cat([f[k] for f in frames]) for k in range(3))
+    g = torch.Generator(device="cuda").manual_seed(n)
+    sel = torch.randint(0, pc.shape[0], (n,), generator=g, device="cuda")
+    c, l, w = pc[sel].contiguous(), pl[sel].contiguous(), pw[sel].contiguous()
+    w[0] = w[0].abs().clamp_min(1e-3)  # at least one surface sample: the reference's eikonal mean of an empty set is NaN
+    perm, slots = dp.plan_batch(octree, c)
+    opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=eik, weight_e=cfg.weight_e, kernel_variant=4)
+    loss, pred, gx = fused_train_step(octree, dec, c, l, w, opts, want_grad_x=True, perm=perm, slots=slots)
+    torch.cuda.synchronize()
+    ocfg, oct_, mlp = oracle_from_product(octree, dec, cfg)
+    ocfg.ekional_loss_on = eik
+    ref = so.train_step(oct_, mlp, c.cpu(), l.cpu(), w.cpu(), ocfg)
+    assert abs_err(pred, ref["pred"]) <= TOL
+    assert abs(float(loss) - float(ref["loss"])) <= TOL * max(1.0, abs(float(ref["loss"])))
+    if eik:
+        err = (gx.double().cpu() - ref["g"].double()).abs().max(dim=1).values / max(float(ref["g"].abs().max()), 1e-30)
+        assert int((err > TOL).sum()) <= max(2, n // 20000)  # ReLU-kink points, see test_pool_mode_step_at_baseline_size...
+    # gradients: long signed fp32 sums — within TOL of the EXACT value (wide oracle: same fp32 voxel ids / fractions, sums in
+    # fp64) and of the fp32 oracle up to the fp32 oracle's own distance from the exact value (see the BASELINE-size test)
+    _, oct64, mlp64 = oracle_from_product(octree, dec, cfg)
+    so.to_wide(oct64, mlp64)
+    wide = so.train_step(oct64, mlp64, c.cpu(), l.cpu(), w.cpu(), ocfg)
+    for k, (r, r64) in enumerate(zip(ref["feat_grads"], wide["feat_grads"])):
+        gk = octree.hier_features[k].grad
+        assert rel_err(gk, r64) <= TOL, "level %d (wide oracle)" % k
+        assert rel_err(gk, r) <= TOL + rel_err(r, r64), "level %d (fp32 oracle)" % k
+    for k, (p, r, r64) in enumerate(zip(dec.fused_params(), ref["mlp_grads"], wide["mlp_grads"])):
+        assert rel_err(p.grad, r64) <= TOL, "decoder grad %d (wide oracle)" % k
+        assert rel_err(p.grad, r) <= TOL + rel_err(r, r64), "decoder grad %d (fp32 oracle)" % k
