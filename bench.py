@@ -321,7 +321,13 @@ def kernel_roofline(workload, octree, decoder, cfg, spool, points, n_surf_fn, la
     hbm_meas = None if traffic is None else traffic / t / 1e9 / HBM_PEAK_GBS
     l2_frac = achieved / L2_PEAK_GBS
     mfma_util = pmc.get("mfma_util") if pmc else None
-    fracs = {"hbm": hbm_meas if hbm_meas is not None else 0.0, "mfma": issued_tf / MFMA_F32_PEAK_TF}
+    # Exact-fp32 MFMA executes on the SIMD's fp32 FMA lanes and does NOT overlap VALU work of another wave
+    # (tools/ubench/mfma_valu_overlap.hip, profiles/r02_ubench_mfma_valu_overlap.txt: 0.473 ms MFMA-only, 0.307 ms
+    # VALU-only, 0.759 ms together), so the decoder's matrix work and the vector instructions share ONE datapath: its
+    # occupancy (PMC) is the compute roof of this kernel, not the MFMA rate alone.
+    dp_util = pmc.get("fp32_datapath_util") if pmc else None
+    fracs = {"hbm": hbm_meas if hbm_meas is not None else 0.0,
+             "mfma": dp_util if dp_util is not None else issued_tf / MFMA_F32_PEAK_TF}
     bound = max(fracs, key=fracs.get)
     return {
         # SURVEY.md §8(d) figure: algorithmic (no-reuse) bytes / kernel time against the HBM peak
@@ -330,13 +336,17 @@ def kernel_roofline(workload, octree, decoder, cfg, spool, points, n_surf_fn, la
         "frac_of_measured_copy_6290GBs": achieved / 6290.0,
         "compulsory_bytes": int(sum(rows) * 32 * 2 + 24 * points),
         # the honest roofs: real HBM bytes (PMC) against HBM peak; the algorithmic bytes as if all served by L2; the
-        # matrix pipe (issued MFMA FLOP incl. padding, useful decoder FLOP, and the PMC busy counter)
+        # matrix pipe (issued MFMA FLOP incl. padding, useful decoder FLOP, the PMC busy counter) and the fp32 datapath
+        # the MFMAs share with the vector instructions (PMC: MFMA busy + VALU issue cycles over SIMD-cycles)
         "hbm_frac_measured": hbm_meas, "l2_frac": l2_frac,
         "mfma_issued_tflops": issued_tf, "mfma_issued_frac": issued_tf / MFMA_F32_PEAK_TF,
         "mfma_useful_frac": useful_tf / MFMA_F32_PEAK_TF, "mfma_util": mfma_util,
-        "regime": "latency/issue-bound: no roof is above %.2f (hbm measured %s, L2 %.2f, MFMA issued %.2f); `bound` names "
-                  "the nearest one" % (max(l2_frac, fracs["hbm"], fracs["mfma"]),
-                                       "n/a" if hbm_meas is None else "%.2f" % hbm_meas, l2_frac, fracs["mfma"]),
+        "fp32_datapath_util": dp_util,
+        "tcp_active_frac": pmc.get("tcp_active_frac") if pmc else None,
+        "regime": "bound by the SIMD fp32 datapath (MFMA + VALU, which do not overlap) plus exposed gather / atomic "
+                  "latency: hbm measured %s, L2 %.2f, MFMA issued %.2f, fp32 datapath %s; `bound` names the nearer of the "
+                  "two contract roofs" % ("n/a" if hbm_meas is None else "%.2f" % hbm_meas, l2_frac,
+                                          issued_tf / MFMA_F32_PEAK_TF, "n/a" if dp_util is None else "%.2f" % dp_util),
         "launch_geometry": {k: info[k] for k in ("workgroups", "waves", "tile_points", "lds_bytes")},
         "pmc_source": None if pmc is None else pmc.get("source"),
     }
