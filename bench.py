@@ -429,13 +429,19 @@ def main():
 
     def step_body(i):
         """global sorted draw (+ clear grads in the same pass) -> fused step on this rank's slice (-> exchange)"""
-        gidx = spool.draw(n_global, zero=reducer.flat)
-        idx = gidx[rank * points:(rank + 1) * points] if world > 1 else gidx
-        n_surf = (spool.weight[gidx.long()] > 0).sum() if opts.ekional_loss_on else None  # global, no collective
+        # this rank's contiguous slice of the ONE global sorted draw (same seed / draw count on every rank): only the
+        # slice's indices are generated (shine_sample_sorted_slice), so the draw does not grow with the world size
+        idx = spool.draw(points, zero=reducer.flat, n_global=n_global, slice_begin=rank * points)
+        n_surf = None
+        if opts.ekional_loss_on:  # global surface count: local count + an 8-byte all-reduce
+            n_surf = (spool.weight[idx.long()] > 0).sum()
+            if use_dist:
+                reducer.all_reduce_scalar(n_surf)
         loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx)
         if use_dist:
             if exchange == "touched":
-                shine_dp.mark_touched(octree, spool, gidx, flags)
+                shine_dp.mark_touched(octree, spool, idx, flags)  # this rank's rows ...
+                reducer.or_reduce_flags(flags)                    # ... OR-ed into the global row set
                 reducer.all_reduce_touched(flags)
             else:
                 reducer.all_reduce_grads()

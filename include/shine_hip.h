@@ -236,6 +236,14 @@ int shine_plan_batch(const shine_tables* t, const shine_step_config* cfg, const 
 int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,
                         void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
 
+/* the same draw for ONE data-parallel rank: only draws [slice_begin, slice_begin + slice_n) of the global sorted batch of
+ * n draws are written (idx_out [slice_n]); every rank passes the same (seed, stream id) and its own slice, so the ranks'
+ * slices are the contiguous parts of one i.i.d. batch at 1/world of the writing cost.  stream_state: device
+ * uint64[2] (graph-replayable, as shine_sample_sorted_dev) or NULL to use stream_id. */
+int shine_sample_sorted_slice(int64_t pool_size, int64_t n, int64_t slice_begin, int64_t slice_n, uint64_t seed,
+                              uint64_t stream_id, uint64_t* stream_state, int32_t* idx_out, void* zero_ptr,
+                              size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
+
 /* ---- Mesher.query_points (utils/mesher.py:33-108): query_feature(coord, faster=True) (model/feature_octree.py:237-244,
  *      :267-286) + Decoder.sdf (model/decoder.py:49-63) for n grid points in one launch.
  *      sdf_out[n] f32 = (negate ? -1 : +1) * sdf   (the mesher negates, mesher.py:69,92), may be NULL;

@@ -56,9 +56,13 @@ __global__ __launch_bounds__(256) void k_sample_pass1(double* block_sum, long lo
   if (threadIdx.x == 0) block_sum[blockIdx.x] = t;
 }
 
+// [lo, lo + cnt): the part of the n sorted draws this launch writes (idx[k - lo]); block b of the launch is block
+// blk0 + b of the whole draw.  A data-parallel rank draws only its contiguous slice of the GLOBAL batch this way: pass 1
+// still covers all n + 1 spacings (compute only), pass 2 only the slice's blocks.
 __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, int nblocks, long long n, long long pool,
                                                       unsigned long long seed, unsigned long long stream,
-                                                      unsigned long long* stream_dev, int* idx) {
+                                                      unsigned long long* stream_dev, int* idx, int blk0, long long lo,
+                                                      long long cnt) {
   __shared__ double s_red[4];
   __shared__ double s_wave_pre[4];
   if (stream_dev) stream = stream_dev[0];
@@ -67,11 +71,11 @@ __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, i
   for (int b = threadIdx.x; b < nblocks; b += 256) {
     const double v = block_sum[b];
     total += v;
-    if (b < (int)blockIdx.x) before += v;
+    if (b < blk0 + (int)blockIdx.x) before += v;
   }
   before = block_sum_256(before, s_red);
   total = block_sum_256(total, s_red);
-  const long long k0 = (long long)blockIdx.x * SB + threadIdx.x * 4;
+  const long long k0 = (long long)(blk0 + blockIdx.x) * SB + threadIdx.x * 4;
   double e[4], run = 0.0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -94,9 +98,9 @@ __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, i
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     s += e[j];
-    if (k0 + j < n) {
+    if (k0 + j < n && k0 + j >= lo && k0 + j < lo + cnt) {
       long long v = (long long)((s / total) * (double)pool);
-      idx[k0 + j] = (int)(v < 0 ? 0 : (v >= pool ? pool - 1 : v));
+      idx[k0 + j - lo] = (int)(v < 0 ? 0 : (v >= pool ? pool - 1 : v));
     }
   }
   if (stream_dev) {  // the last block to finish advances the stream for the next replay (every block has read it by then)
@@ -120,8 +124,11 @@ using namespace shine;
 
 static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id,
                               unsigned long long* stream_dev, int32_t* idx_out, void* zero_ptr, size_t zero_bytes,
-                              void* workspace, size_t* workspace_bytes, void* stream) {
-  if (!workspace_bytes || n < 0 || pool_size < 1 || pool_size > 0x7fffffffll)
+                              void* workspace, size_t* workspace_bytes, void* stream, int64_t slice_begin = 0,
+                              int64_t slice_n = -1) {
+  if (slice_n < 0) slice_n = n - slice_begin;
+  if (!workspace_bytes || n < 0 || pool_size < 1 || pool_size > 0x7fffffffll || slice_begin < 0 || slice_n < 0 ||
+      slice_begin + slice_n > n)
     return set_error(SHINE_E_INVALID, "shine_sample_sorted: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const long long n1 = (long long)n + 1;  // n draws + the closing spacing
@@ -144,11 +151,24 @@ static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint6
                      (unsigned long long)stream_id, (const unsigned long long*)stream_dev, (float4*)zero_ptr,
                      zero_ptr ? (long long)(zero_bytes / 16) : 0ll);
   SHINE_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_sample_pass2, dim3((unsigned)nblocks), dim3(256), 0, st, bs, (int)nblocks, (long long)n,
+  // pass 2 over the blocks that hold the slice (an empty slice still runs one block: it advances the device stream id)
+  const long long b0 = slice_n > 0 ? slice_begin / SB : 0;
+  const long long b1 = slice_n > 0 ? (slice_begin + slice_n - 1) / SB : 0;
+  hipLaunchKernelGGL(k_sample_pass2, dim3((unsigned)(b1 - b0 + 1)), dim3(256), 0, st, bs, (int)nblocks, (long long)n,
                      (long long)pool_size, (unsigned long long)seed, (unsigned long long)stream_id, stream_dev,
-                     (int*)idx_out);
+                     (int*)idx_out, (int)b0, (long long)slice_begin, (long long)slice_n);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
+}
+
+// Data-parallel draw: rank r wants draws [slice_begin, slice_begin + slice_n) of the ONE global sorted batch of n draws
+// every rank agrees on (same seed and stream id everywhere).  idx_out [slice_n].  stream_state: device uint64[2] as in
+// shine_sample_sorted_dev, or NULL to use stream_id.
+extern "C" int shine_sample_sorted_slice(int64_t pool_size, int64_t n, int64_t slice_begin, int64_t slice_n, uint64_t seed,
+                                         uint64_t stream_id, uint64_t* stream_state, int32_t* idx_out, void* zero_ptr,
+                                         size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream) {
+  return sample_sorted_impl(pool_size, n, seed, stream_id, (unsigned long long*)stream_state, idx_out, zero_ptr,
+                            zero_bytes, workspace, workspace_bytes, stream, slice_begin, slice_n);
 }
 
 extern "C" int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,

@@ -34,22 +34,41 @@ class SortedPool:
         self.size = int(coord.shape[0])
         self.tables_epoch = self.octree._tables_epoch
 
-    def draw(self, n, out=None, zero=None, graph_safe=False):
+    def draw(self, n, out=None, zero=None, graph_safe=False, n_global=None, slice_begin=0):
         """n sorted i.i.d. uniform sample indices (int32, device).  `zero`: optional contiguous float tensor cleared in
         the same pass (the flat gradient bucket, i.e. opt.zero_grad()).  `graph_safe`: the stream id is read from (and
-        advanced in) device memory, so a captured HIP graph of this call draws a fresh batch at every replay."""
+        advanced in) device memory, so a captured HIP graph of this call draws a fresh batch at every replay.
+        Data parallel: `n_global` / `slice_begin` — this call returns draws [slice_begin, slice_begin + n) of ONE global
+        sorted batch of n_global draws that every rank agrees on (same seed, same draw count): the rank's contiguous
+        slice of the node-ordered global batch without generating the other ranks' indices."""
         dev = self.coord.device
         lib = _lib.lib()
         stream = _lib.current_stream_handle()
-        ws = self._ws.get((n, self.size))
+        sliced = n_global is not None and (int(n_global) != n or slice_begin)
+        nd = int(n_global) if sliced else n  # the draw whose spacings pass 1 sums
+        ws = self._ws.get((nd, self.size))
         if ws is None:
             need = C.c_size_t(0)
-            _lib.check(lib.shine_sample_sorted(self.size, n, self.seed, 0, None, None, 0, None, C.byref(need), stream),
+            _lib.check(lib.shine_sample_sorted(self.size, nd, self.seed, 0, None, None, 0, None, C.byref(need), stream),
                        "shine_sample_sorted")
-            ws = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev), n, int(need.value))
-            self._ws[(n, self.size)] = ws
+            ws = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev), nd, int(need.value))
+            self._ws[(nd, self.size)] = ws
         idx = out if out is not None else torch.empty(n, dtype=torch.int32, device=dev)
         need = C.c_size_t(ws[2])
+        if sliced:
+            state = None
+            if graph_safe:
+                if self._stream_state is None:
+                    self._stream_state = torch.tensor([self.draws, 0], dtype=torch.int64, device=dev)
+                state = self._stream_state.data_ptr()
+            _lib.check(lib.shine_sample_sorted_slice(self.size, nd, int(slice_begin), n, self.seed, self.draws, state,
+                                                     idx.data_ptr(), zero.data_ptr() if zero is not None else None,
+                                                     zero.numel() * zero.element_size() if zero is not None else 0,
+                                                     ws[0].data_ptr(), C.byref(need), stream),
+                       "shine_sample_sorted_slice")
+            if not graph_safe:
+                self.draws += 1
+            return idx
         if graph_safe:
             if self._stream_state is None:
                 self._stream_state = torch.tensor([self.draws, 0], dtype=torch.int64, device=dev)

@@ -492,3 +492,32 @@ def test_planned_ragged_batches_on_the_point_level_kernel(n, eik, levels):
     for k, (p, r, r64) in enumerate(zip(dec.fused_params(), ref["mlp_grads"], wide["mlp_grads"])):
         assert rel_err(p.grad, r64) <= TOL, "decoder grad %d (wide oracle)" % k
         assert rel_err(p.grad, r) <= TOL + rel_err(r, r64), "decoder grad %d (fp32 oracle)" % k
+
+
+@pytest.mark.parametrize("n_global,world", [(4096, 2), (1 << 18, 8), (100003, 4)])
+def test_rank_slices_of_the_global_draw(n_global, world):
+    """Data parallel: every rank draws only its contiguous slice of ONE global sorted batch
+    (shine_sample_sorted_slice).  The slices of all ranks, concatenated, must be exactly the global draw."""
+    from shine_mapping_amd.sampler import SortedPool
+
+    fx = load_golden("maicity_bce_L3")
+    cfg, octree, dec = product_from_golden(fx)
+    octree._require_tables(with_ranks=True)
+    sp = SortedPool(octree, fx["coord"].cuda().repeat(40, 1), fx["sdf_label"].cuda().repeat(40), fx["weight"].cuda().repeat(40),
+                    seed=77)
+    for draw_no in (0, 5):
+        sp.draws = draw_no
+        whole = sp.draw(n_global).clone()
+        per = (n_global + world - 1) // world
+        parts = []
+        for r in range(world):
+            lo = min(r * per, n_global)
+            cnt = min(per, n_global - lo)
+            if cnt == 0:
+                continue
+            sp.draws = draw_no  # every rank is at the same draw count
+            parts.append(sp.draw(cnt, n_global=n_global, slice_begin=lo).clone())
+        torch.cuda.synchronize()
+        got = torch.cat(parts)
+        assert torch.equal(got, whole)
+        assert bool((whole[1:] >= whole[:-1]).all())
