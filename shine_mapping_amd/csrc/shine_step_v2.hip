@@ -37,11 +37,11 @@ constexpr int V2_DFP = 20;                     // pitch of the [feature][point] 
 constexpr int V2_IDS = LCAP * 8 * V2_WP;       // ids [LCAP][8][16] int32
 constexpr int V2_W = LCAP * 8 * V2_WP;         // w   [LCAP][8][16]
 constexpr int V2_R2 = 2 * 32 * V2_TT;          // two transpose tiles [32][20]; second life: df / J / cq
-constexpr int V2_DF = 0, V2_J = 8 * V2_DFP, V2_CQ = 16 * V2_DFP;
+constexpr int V2_DF = 0, V2_CQ = 16 * V2_DFP;
 constexpr int V2_WAVE_FLOATS = V2_IDS + V2_W + V2_R2;  // 2304 floats = 9216 B per wave
 constexpr int V2_OPA1 = 0, V2_OPA2 = 4 * 64, V2_OPA2T = 20 * 64, V2_OPA1T = 36 * 64, V2_OPTOTAL = 44 * 64;
 constexpr int V2_BIG = 12;                     // waves per workgroup of the full-chip launch (V2_BIG / 4 per SIMD)
-constexpr int V2_MFMA_BCE = 68;                // 16x16x4 MFMAs per 16-point tile: 4 + 16, 16 + 8, 16 + 8
+// 68 16x16x4 MFMAs per 16-point tile: 4 + 16, 16 + 8, 16 + 8
 
 static_assert(V2_DFP == V2_TT, "f_wr addresses both the transpose rows and the df rows");
 static_assert(V2_CQ + LCAP * 8 * V2_WP <= V2_R2, "df/J/cq must fit the transpose region");
@@ -58,7 +58,7 @@ __device__ __forceinline__ f32x4 zero4() {
 }
 
 template <int L, int WAVES, bool PROF>
-__global__ __launch_bounds__(WAVES * 64, WAVES == V2_BIG ? V2_BIG / 4 : 4) void k_step_v2(V1Args a) {
+__global__ __launch_bounds__(WAVES * 64, WAVES == V2_BIG ? V2_BIG / 4 : 2) void k_step_v2(V1Args a) {
   constexpr int NT = WAVES * 64;
   __shared__ float s_opA[V2_OPTOTAL];
   __shared__ float s_bias[100];
@@ -111,8 +111,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V2_BIG ? V2_BIG / 4 : 4) void 
   int* U_ids = reinterpret_cast<int*>(U);  // [LCAP][8][16]
   float* U_w = U + V2_IDS;                 // [LCAP][8][16]
   float* R2 = U + V2_IDS + V2_W;
-  float* TL = R2;
-  float* TR = R2 + 32 * V2_TT;
 
   // Per-lane LDS base addresses: every staging access below is one of these + a compile-time offset (DS instructions
   // carry a 16-bit immediate).  They are re-derived from an opaque lane value at the top of every tile, which keeps
