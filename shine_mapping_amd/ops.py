@@ -29,6 +29,9 @@ class StepOptions:
     ekional_loss_on: bool = False     # (sic) config key of the reference
     weight_e: float = 0.1
     loss_weight_on: bool = False      # BCEWithLogitsLoss(weight=|weight|), utils/loss.py:18-19 (False in all shipped yamls)
+    auto_plan_min: int = 65536        # a batch handed over WITHOUT an order / plan (the reference's get_batch) of at least
+                                      # this many points is planned first (shine_plan_batch: node order + hash slots, 3
+                                      # small launches) and runs on the planned-batch kernel; 0 switches it off
     n_global: Optional[int] = None    # global batch size under data parallelism (defaults to local N)
     decoder_grad_on: Optional[bool] = None  # default: any decoder parameter requires grad (freeze_model, tools.py:188)
     kernel_variant: int = 0           # 0 auto; 1 the simple v0 kernel (on-device cross-check); 2 / 3 force the 32- /
@@ -141,6 +144,13 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
     coord = octree._check_coord(coord.detach())
     n = idx.numel() if pool_mode else coord.shape[0]
     dev = coord.device
+    if (not pool_mode and perm is None and slots is None and opts.auto_plan_min and n >= opts.auto_plan_min
+            and (int(opts.kernel_variant) & 0xff) in (0, 4) and octree.featured_level_num <= 4):
+        # an unordered batch: neighbouring lanes hit unrelated nodes.  Measured (tools/unordered_bench.py, whole call): 2^18
+        # points x 4 levels 320 -> 143 us, 2^20 x 3 with the eikonal term 889 -> 447 us; break-even at 32-64 k points
+        from .dp import plan_batch
+
+        perm, slots = plan_batch(octree, coord)
     sdf_label = _f32(sdf_label, "sdf_label")
     eik = bool(opts.ekional_loss_on)
     if bool(opts.loss_weight_on) and weight is None:

@@ -521,3 +521,32 @@ def test_rank_slices_of_the_global_draw(n_global, world):
         got = torch.cat(parts)
         assert torch.equal(got, whole)
         assert bool((whole[1:] >= whole[:-1]).all())
+
+
+@pytest.mark.parametrize("name", ["maicity_bce_L4", "kitti_eik_L3"])
+def test_unordered_batches_are_planned_automatically(name):
+    """A batch handed over without an order (the reference's get_batch: torch.randint) of >= StepOptions.auto_plan_min
+    points is planned first and runs on the planned-batch kernel: same results as the in-kernel-probing path."""
+    from shine_mapping_amd import fused_train_step
+
+    fx = load_golden(name)
+    cfg, octree, dec = product_from_golden(fx)
+    torch.manual_seed(5)
+    reps = 9
+    c = (fx["coord"].repeat(reps, 1) + 1e-5 * torch.randn(fx["coord"].shape[0] * reps, 3)).cuda().contiguous()
+    l = fx["sdf_label"].repeat(reps).cuda().contiguous()
+    w = fx["weight"].repeat(reps).cuda().contiguous()
+    assert c.shape[0] >= 16384
+    res = []
+    for auto in (0, 8192):
+        for p in list(octree.hier_features) + dec.fused_params():
+            p.grad = None
+        opts = step_options(fx)
+        opts.auto_plan_min = auto
+        loss, pred, g = fused_train_step(octree, dec, c, l, w, opts, want_grad_x=True)
+        torch.cuda.synchronize()
+        res.append((float(loss), pred.clone(), [p.grad.clone() for p in list(octree.hier_features) + dec.fused_params()]))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * max(1.0, abs(res[0][0]))
+    assert abs_err(res[0][1], res[1][1]) <= 2e-5
+    for a, b in zip(res[0][2], res[1][2]):
+        assert rel_err(a, b) <= TOL
