@@ -244,6 +244,21 @@ int shine_sample_sorted_slice(int64_t pool_size, int64_t n, int64_t slice_begin,
                               uint64_t stream_id, uint64_t* stream_state, int32_t* idx_out, void* zero_ptr,
                               size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
 
+/* ---- data-parallel exchange of the rows a step touched (the reference is single-GPU: no counterpart).
+ *      flags[l]: uint8 [rows[l]] from shine_mark_touched (OR-reduced over the ranks), rows[l] = the level's row count
+ *      WITHOUT the trash row (= the trash row's index).
+ *      shine_touched_index: ascending ids of the flagged rows per level -> idx_out[l] (capacity rows[l]) and
+ *        counts_dev[l] (device int64); workspace == NULL returns the required bytes.
+ *      shine_touched_pack: msg = [the listed rows of level 0, level 1, ... (8 floats each)][the L trash rows]; counts =
+ *        the HOST copy of counts_dev (the message size is needed on the host for the collective anyway).
+ *      shine_touched_unpack: the reverse; clears flags[l] at the listed rows when flags is given. */
+int shine_touched_index(int32_t n_levels, const uint8_t* const* flags, const int64_t* rows, int32_t* const* idx_out,
+                        int64_t* counts_dev, void* workspace, size_t* workspace_bytes, void* stream);
+int shine_touched_pack(int32_t n_levels, float* const* grads, const int32_t* const* idx, const int64_t* counts,
+                       const int64_t* rows, float* msg, void* stream);
+int shine_touched_unpack(int32_t n_levels, float* const* grads, const int32_t* const* idx, const int64_t* counts,
+                         const int64_t* rows, uint8_t* const* flags, const float* msg, void* stream);
+
 /* ---- Mesher.query_points (utils/mesher.py:33-108): query_feature(coord, faster=True) (model/feature_octree.py:237-244,
  *      :267-286) + Decoder.sdf (model/decoder.py:49-63) for n grid points in one launch.
  *      sdf_out[n] f32 = (negate ? -1 : +1) * sdf   (the mesher negates, mesher.py:69,92), may be NULL;

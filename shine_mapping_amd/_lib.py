@@ -83,6 +83,12 @@ _SIGNATURES = {
                                           C.POINTER(C.c_size_t), _P]),
     "shine_sample_sorted_slice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, _P,
                                             C.c_size_t, _P, C.POINTER(C.c_size_t), _P]),
+    "shine_touched_index": (C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, _P,
+                                      C.POINTER(C.c_size_t), _P]),
+    "shine_touched_pack": (C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     _P, _P]),
+    "shine_touched_unpack": (C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int64), C.POINTER(_P), _P, _P]),
     "shine_train_step_workspace_bytes": (C.c_size_t, [C.POINTER(StepConfig), C.c_int64]),
     "shine_train_step_info": (C.c_int, [C.POINTER(StepConfig), C.c_int64, C.POINTER(C.c_int64)]),
     "shine_mark_touched": (C.c_int, [_P, C.POINTER(StepConfig), _P, _P, _P, C.c_int64, C.POINTER(C.c_int64),

@@ -184,10 +184,55 @@ class TouchedRowReducer(GradReducer):
                 self.dist.all_reduce(f, op=self.dist.ReduceOp.MAX, group=self.group)
         return flags
 
+    def _device_exchange(self, flags):
+        """CUDA path: row lists, pack and unpack are library kernels (shine_touched_index / _pack / _unpack): ~10 launches
+        and ONE host read (the L row counts = the message size) around the collective."""
+        feats = self.params[:self.n_feat]
+        L = self.n_feat
+        dev = feats[0].device
+        lib = _lib.lib()
+        stream = _lib.current_stream_handle()
+        rows = [int(p.shape[0]) - 1 for p in feats]
+        st = getattr(self, "_dev_state", None)
+        if st is None or st["rows"] != rows or st["dev"] != dev:
+            need = C.c_size_t(0)
+            _lib.check(lib.shine_touched_index(L, None, _lib.i64_array(rows), None, None, None, C.byref(need), stream),
+                       "shine_touched_index")
+            st = dict(rows=rows, dev=dev, ws=torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev),
+                      ws_bytes=int(need.value), idx=[torch.empty(max(r, 1), dtype=torch.int32, device=dev) for r in rows],
+                      counts=torch.zeros(L, dtype=torch.int64, device=dev), rows_arr=_lib.i64_array(rows))
+            self._dev_state = st
+        need = C.c_size_t(st["ws_bytes"])
+        flag_ptrs = _lib.ptr_array([f.data_ptr() for f in flags])
+        idx_ptrs = _lib.ptr_array([t.data_ptr() for t in st["idx"]])
+        _lib.check(lib.shine_touched_index(L, flag_ptrs, st["rows_arr"], idx_ptrs, st["counts"].data_ptr(),
+                                           st["ws"].data_ptr(), C.byref(need), stream), "shine_touched_index")
+        counts = st["counts"].cpu().tolist()  # the message size: the one host read of the exchange
+        n_rows = int(sum(counts))
+        F = feats[0].shape[1]
+        n_dec = sum(p.numel() for p in self.params[self.n_feat:])
+        feat_total = sum(p.numel() for p in feats)
+        msg = torch.empty((n_rows + L) * F + n_dec, dtype=torch.float32, device=dev)
+        grad_ptrs = _lib.ptr_array([p.grad.data_ptr() for p in feats])
+        counts_arr = _lib.i64_array(counts)
+        _lib.check(lib.shine_touched_pack(L, grad_ptrs, idx_ptrs, counts_arr, st["rows_arr"], msg.data_ptr(), stream),
+                   "shine_touched_pack")
+        if n_dec:  # the decoder grads sit behind the feature tables in the flat bucket: one contiguous copy
+            msg[(n_rows + L) * F:].copy_(self._flat[feat_total:feat_total + n_dec])
+        self.last_rows, self.last_bytes = n_rows, msg.numel() * 4
+        if self.dist is not None:
+            self.dist.all_reduce(msg, op=self.dist.ReduceOp.SUM, group=self.group)
+        _lib.check(lib.shine_touched_unpack(L, grad_ptrs, idx_ptrs, counts_arr, st["rows_arr"], flag_ptrs, msg.data_ptr(),
+                                            stream), "shine_touched_unpack")
+        if n_dec:
+            self._flat[feat_total:feat_total + n_dec].copy_(msg[(n_rows + L) * F:])
+
     def all_reduce_touched(self, flags):
         """flags: per level uint8 [rows_l + 1] (or [rows_l]); identical on all ranks.  Clears them for the next step."""
         self._ensure_flat()
         feats = self.params[:self.n_feat]
+        if feats[0].is_cuda:
+            return self._device_exchange(flags)
         idx = []
         for p, f in zip(feats, flags):
             f = f[: p.shape[0] - 1]

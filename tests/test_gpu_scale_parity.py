@@ -550,3 +550,52 @@ def test_unordered_batches_are_planned_automatically(name):
     assert abs_err(res[0][1], res[1][1]) <= 2e-5
     for a, b in zip(res[0][2], res[1][2]):
         assert rel_err(a, b) <= TOL
+
+
+def test_touched_row_exchange_device_path():
+    """TouchedRowReducer on CUDA tensors: row lists / pack / unpack are library kernels.  With a stand-in collective that
+    doubles the message (two identical ranks) exactly the flagged rows, the trash rows and the decoder grads must come back
+    doubled, everything else untouched, the flags cleared — and the message must equal the torch-indexing path's."""
+    from shine_mapping_amd import dp
+
+    class TwoIdenticalRanks:
+        class ReduceOp:
+            SUM = "sum"
+
+        def __init__(self):
+            self.msgs = []
+
+        def all_reduce(self, t, op=None, group=None):
+            self.msgs.append(t.detach().cpu().clone())
+            t.mul_(2.0)
+
+    torch.manual_seed(0)
+    rows = [37, 1000, 70001]
+    feats = [torch.nn.Parameter(torch.randn(r + 1, 8, device="cuda")) for r in rows]
+    mlp = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in (256, 32, 1024, 32, 32, 1)]
+    for p in feats + mlp:
+        p.grad = torch.randn_like(p)
+    flags = [(torch.rand(r + 1, device="cuda") < frac).to(torch.uint8) for r, frac in zip(rows, (0.5, 0.0, 0.1))]
+    before = [p.grad.clone() for p in feats + mlp]
+    fl0 = [f.clone() for f in flags]
+    fake = TwoIdenticalRanks()
+    red = dp.TouchedRowReducer(feats, mlp, fake)
+    red.all_reduce_touched(flags)
+    torch.cuda.synchronize()
+    n_touched = sum(int(f[:r].sum()) for f, r in zip(fl0, rows))
+    assert red.last_rows == n_touched
+    for p, b, f, r in zip(feats, before[:3], fl0, rows):
+        m = f[:r].bool()
+        assert torch.equal(p.grad[:r][m], 2 * b[:r][m]) and torch.equal(p.grad[:r][~m], b[:r][~m])
+        assert torch.equal(p.grad[r], 2 * b[r])  # trash row
+    for p, b in zip(mlp, before[3:]):
+        assert torch.equal(p.grad, 2 * b)
+    assert all(int(f[:r].sum()) == 0 for f, r in zip(flags, rows))
+    # the same exchange through the torch-indexing path (what the gloo tests run) builds the same message
+    cpu_feats = [torch.nn.Parameter(p.detach().cpu()) for p in feats]
+    cpu_mlp = [torch.nn.Parameter(p.detach().cpu()) for p in mlp]
+    for p, b in zip(cpu_feats + cpu_mlp, before):
+        p.grad = b.cpu().clone()
+    fake2 = TwoIdenticalRanks()
+    dp.TouchedRowReducer(cpu_feats, cpu_mlp, fake2).all_reduce_touched([f.cpu() for f in fl0])
+    assert torch.equal(fake.msgs[0], fake2.msgs[0])
