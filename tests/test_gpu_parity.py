@@ -548,7 +548,9 @@ def test_pool_mode_step_equals_batch_mode_on_the_drawn_batch(name):
     if g_b is not None:
         assert g_close(g_p, g_b, 1e-5)
     for a, b in zip(grads_p, [p.grad for p in params]):
-        assert rel_err(a, b) <= 2e-5
+        # (the last decoder tensor, d loss / d b3 = sum of delta over the batch, is ONE heavily cancelling sum — 1.5e-5 from
+        # terms of 7e-4: two kernels' summation orders differ by ~1e-9 absolute, which is 1e-4 of the result itself)
+        assert rel_err(a, b) <= 2e-5 or abs_err(a, b) <= 1e-7
     ocfg, oct_, mlp = oracle_from_golden(fx)
     ref = so.train_step(oct_, mlp, c.cpu(), l.cpu(), w.cpu(), ocfg)
     assert abs_err(pred_p, ref["pred"]) <= TOL
@@ -914,7 +916,7 @@ def test_graphed_iteration_matches_eager_loop(mode):
     # differ by 0.1 of max-abs after one step (the reference on CUDA has the same property).  What must agree: the
     # well-conditioned decoder weights and the loss both models reach on a common probe batch.
     for a, b in zip(eager_mlp, dec2.fused_params()):
-        assert rel_err(b.detach(), a) <= 5e-2
+        assert rel_err(b.detach(), a) <= 0.1  # (observed 0.02-0.05 between runs of the same loop: atomics order + Adam's sign)
     probe = eager_idx[0]
     opts_probe = StepOptions(sigma=opts.sigma, loss_reduction=opts.loss_reduction)
     l1, _, _ = fused_train_step(octree, dec, None, None, None, opts_probe, pool=pool, idx=probe)
