@@ -21,7 +21,7 @@ from .ops import StepOptions, fused_regularization, fused_train_step, touched_fl
 
 
 class GraphedIteration:
-    def __init__(self, octree, decoder, pool, opt, opts: StepOptions, n: int, lambda_forget: float = 0.0):
+    def __init__(self, octree, decoder, pool, opt, opts: StepOptions, n: int, lambda_forget: float = 0.0, unroll: int = 1):
         self.octree, self.decoder, self.pool, self.opt, self.opts, self.n = octree, decoder, pool, opt, opts, int(n)
         self.lambda_forget = float(lambda_forget)
         self.regularize = self.lambda_forget != 0.0
@@ -35,6 +35,16 @@ class GraphedIteration:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss, self.reg = self._body()
+        # `unroll` iterations in ONE graph: at the reference's batch size an iteration is ~8 small launches, and a graph
+        # replay costs ~10-16 us of host time whatever it holds — run(n) replays the long graph n // unroll times.  It pays
+        # only when the graph lives for many replays: capture cost grows with the node count (bench.py --unroll)
+        self.unroll = max(1, int(unroll))
+        self.graph_k = None
+        if self.unroll > 1:
+            self.graph_k = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_k):
+                for _ in range(self.unroll):
+                    self.loss_k, self.reg_k = self._body()
 
     def _body(self):
         idx = self.pool.draw(self.n, out=self._idx, graph_safe=True)
@@ -54,3 +64,18 @@ class GraphedIteration:
             raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
         self.graph.replay()
         return self.loss
+
+    def run(self, n_iters: int):
+        """n_iters iterations: replays of the `unroll`-iteration graph, the remainder one by one.  Returns the last loss."""
+        if self.octree._tables_epoch != self._epoch:
+            raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
+        loss = self.loss
+        k = self.unroll if self.graph_k is not None else 0
+        while k and n_iters >= k:
+            self.graph_k.replay()
+            loss = self.loss_k
+            n_iters -= k
+        for _ in range(n_iters):
+            self.graph.replay()
+            loss = self.loss
+        return loss

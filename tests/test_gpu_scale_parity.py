@@ -599,3 +599,40 @@ def test_touched_row_exchange_device_path():
     fake2 = TwoIdenticalRanks()
     dp.TouchedRowReducer(cpu_feats, cpu_mlp, fake2).all_reduce_touched([f.cpu() for f in fl0])
     assert torch.equal(fake.msgs[0], fake2.msgs[0])
+
+
+def test_unrolled_graph_replays_draw_the_same_batches_and_count_the_same_steps():
+    """loop.GraphedIteration(unroll=k): k iterations per HIP graph.  run(n) must leave the sampler's stream id and Adam's
+    step count exactly where n single-iteration replays leave them (both live in device memory and are advanced by the
+    kernels), i.e. the NEXT draw is the same batch either way."""
+    from shine_mapping_amd import StepOptions
+    from shine_mapping_amd.loop import GraphedIteration
+    from shine_mapping_amd.optim import setup_optimizer
+    from shine_mapping_amd.sampler import SortedPool
+
+    def make():
+        fx = load_golden("maicity_bce_L3")
+        cfg, octree, dec = product_from_golden(fx)
+        dec = dec.cuda()
+        cfg.lr, cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio, cfg.weight_decay = 0.01, True, 1e-15, 1.0, 1e-7
+        opt = setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())
+        octree._require_tables(with_ranks=True)
+        pool = SortedPool(octree, fx["coord"].cuda().repeat(8, 1), fx["sdf_label"].cuda().repeat(8),
+                          fx["weight"].cuda().repeat(8), seed=5)
+        return octree, dec, opt, pool, StepOptions(sigma=fx["sigma"])
+
+    n_iters, N = 11, 1024
+    o1, d1, opt1, p1, s1 = make()
+    one = GraphedIteration(o1, d1, p1, opt1, s1, N)
+    for _ in range(n_iters):
+        one()
+    o2, d2, opt2, p2, s2 = make()
+    many = GraphedIteration(o2, d2, p2, opt2, s2, N, unroll=4)
+    many.run(n_iters)  # 2 x 4 + 3 x 1
+    torch.cuda.synchronize()
+    assert opt1.steps_taken() == opt2.steps_taken() == n_iters + 1
+    assert torch.equal(one._idx, many._idx)  # the last batch drawn
+    one()
+    many()
+    torch.cuda.synchronize()
+    assert torch.equal(one._idx, many._idx)  # and the next one
