@@ -147,6 +147,27 @@ def test_oracle_bit_identical_to_live_reference():
             mg.GOLDEN_DIR = old
 
 
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_import.available(), reason="needs /root/reference (authoring container)")
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_weighted_bce_of_the_oracle_is_the_reference_function(reduction):
+    """loss_weight_on (off in every shipped yaml, so no golden fixture exercises it): the oracle's weighted BCE and its
+    gradient against the reference's own sdf_bce_loss(weighted=True) (utils/loss.py:17-24), to the bit."""
+    R = ref_import.install()
+    from oracle import shine_oracle as so
+
+    torch.manual_seed(3)
+    pred = (3.0 * torch.randn(777)).requires_grad_(True)
+    label = 0.05 * torch.randn(777)
+    w = torch.rand(777) + 0.1
+    sigma = 0.0123
+    ours = so.sdf_bce_loss(pred, label, sigma, reduction, weight=w)
+    (g_ours,) = torch.autograd.grad(ours, pred)
+    ref = R.sdf_bce_loss(pred, label, sigma, w, True, reduction)
+    (g_ref,) = torch.autograd.grad(ref, pred)
+    assert torch.equal(ours, ref) and torch.equal(g_ours, g_ref)
+
+
 def test_node_ranks_are_a_z_order_over_all_levels():
     """FeatureOctree._host_node_ranks (the host statement of shine_tables_rank_nodes): ranks are a permutation, every
     node's descendants occupy a contiguous rank range that ends right before the node's own bucket."""
