@@ -281,8 +281,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     last_slot = row_last(slot);
     // smooth-step weights of this level, in the reference's association (model/feature_octree.py:186-193)
     float w[8];
-    const Axis X = axis_weight_rt(poly, x0, lv_res), Y = axis_weight_rt(poly, x1, lv_res),
-               Z = axis_weight_rt(poly, x2, lv_res);
+    Axis X = axis_weight_rt(poly, x0, lv_res), Y = axis_weight_rt(poly, x1, lv_res), Z = axis_weight_rt(poly, x2, lv_res);
+    if (EIK && !hit) X.dt = Y.dt = Z.dt = 0.f;  // a miss: every d w_c / d x carries exactly one of these factors
     corner_weights(X.t, Y.t, Z.t, w);
     if (!hit) {
 #pragma unroll
@@ -408,9 +408,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
             const float rr[8] = {r0[c].x, r0[c].y, r0[c].z, r0[c].w, r1[c].x, r1[c].y, r1[c].z, r1[c].w};
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
-              const float dz = hit ? dwc[e] : 0.f;
 #pragma unroll
-              for (int q = 0; q < 8; ++q) Ag[q][e] = fmaf(dz, rr[q], Ag[q][e]);
+              for (int q = 0; q < 8; ++q) Ag[q][e] = fmaf(dwc[e], rr[q], Ag[q][e]);  // (zero for a miss: dt = 0 above)
             }
           }
         }
@@ -720,7 +719,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
       float dwc[3];
       corner_dw(X, Y, Z, c, dwc);
       const float cq = a.sigma * (dwc[0] * qv[0] + dwc[1] * qv[1] + dwc[2] * qv[2]);
-      st_w[c * V3_WP] = hit ? fmaf(delta, w[c], cq) : 0.f;
+      st_w[c * V3_WP] = fmaf(delta, w[c], cq);  // a miss stages 0: w = 0 and dt = 0
     }
     if (g == 0) R2[V3_DL + o_pt] = delta;  // the trash rows need delta J (their weights sum to 1)
     __builtin_amdgcn_sched_barrier(0);  // phase boundary
