@@ -6,19 +6,23 @@
 //   backward cur_loss.backward()           shine_batch.py:208-209 (closed form, SURVEY.md §8a math contract)
 //
 // Same algorithm, staging layout and outputs as shine_step_v2.hip.  What the round-2 measurements said about v2
-// (profiles/r02_*): a wave spends ~19-24 k cycles on a 16-point tile, about half of it ISSUING instructions one at a
-// time (~1100 VALU + ~600 SALU per tile; 68 MFMAs are only 2.2 k cycles), the rest waiting on three dependent memory
-// round trips; with three waves per SIMD nothing else is left to run.  So this kernel removes instructions:
+// (profiles/r02_*): ~1100 VALU + ~600 scalar instructions per 16-point tile next to 68 MFMAs, and — the hardware fact that
+// decides the design — exact-fp32 MFMA and the VALU work of another wave do NOT overlap on a SIMD
+// (tools/ubench/mfma_valu_overlap.hip; SQ_VALU_MFMA_COEXEC_CYCLES = 0): the decoder's matrix work and every vector
+// instruction queue for one fp32 datapath.  So this kernel removes instructions and trades waves for registers:
 //   * query: lane (pt, g) owns LEVEL g of point pt (v2: a corner pair of every level).  The per-level work — hash slot,
-//     node-run masks, smooth-step weights, offsets — is done ONCE per wave instruction instead of once per level:
-//     ~190 VALU per tile instead of ~640; one slot / eight ids per lane; the node-run masks of all four levels come
-//     out of ONE 64-bit ballot; the run carry is a DPP row broadcast.  Each lane gathers the eight 32-B corner rows of
-//     its level (sixteen 16-B loads, all in flight together: ONE round trip after the ids) and sums them with its
-//     eight weights; a reduce-scatter over g (v_permlane32_swap / v_permlane16_swap, gfx950) leaves features
-//     (2g, 2g+1) of the point in lane g — the B operand of layer 1, exactly as in v2;
+//     node-run masks, smooth-step weights, offsets — is done ONCE per wave instruction instead of once per level; one
+//     slot / eight ids per lane; the node-run masks of all four levels come out of ONE 64-bit ballot; the run carry is a
+//     DPP row broadcast.  Each lane gathers the eight 32-B corner rows of its level (sixteen 16-B loads, four corners in
+//     flight at a time) and sums them with its eight weights; a reduce-scatter over g (v_permlane32_swap /
+//     v_permlane16_swap, gfx950) leaves features (2g, 2g+1) of the point in lane g — the B operand of layer 1, as in v2.
+//     Measured: 1084 -> 744 VALU instructions per tile (SQ_INSTS_VALU);
 //   * loss: hardware transcendentals (v_exp_f32 / v_rcp_f32 / v_log_f32) instead of libm forms: ~25 VALU, not ~190;
-//   * decoder / weight grads / scatter / flush: as in v2.
-// Planned or pool batches only (the hash slots come with the batch); a batch without a plan runs on k_step_v2.
+//   * 8 waves per CU (2 per SIMD, <= 256 VGPRs) instead of 12: 69 vs 74.5 us — more waves do not help this kernel;
+//   * eikonal build (EIK): the closed-form chain of shine_step_v1.hip on 16-point tiles, 240 VGPRs, no spills;
+//   * decoder / weight grads / scatter / flush: as in v2 (the scatter prefetches its LDS operands one level ahead).
+// Planned or pool batches only (the hash slots come with the batch); a batch without a plan runs on k_step_v2 / v1, or is
+// planned first by the Python layer (StepOptions.auto_plan_min).
 #include "shine_step_common.hpp"
 
 namespace shine {
