@@ -869,6 +869,25 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
   const int L = a.n_levels;
+  // where this entry's sum goes; its current value is requested NOW, together with the partial sums (the read-modify-write
+  // at the end was a second dependent round trip of this ~7 us kernel)
+  float* dst = nullptr;
+  if (part == 0 && idx < PART_FLOATS) {
+    if (idx < SHINE_MLP_PARAMS) {
+      if (a.decoder_grad_on) {
+        if (idx < MLP_B1) dst = a.grad_mlp[0] + idx;
+        else if (idx < MLP_W2) dst = a.grad_mlp[1] + (idx - MLP_B1);
+        else if (idx < MLP_B2) dst = a.grad_mlp[2] + (idx - MLP_W2);
+        else if (idx < MLP_W3) dst = a.grad_mlp[3] + (idx - MLP_B2);
+        else if (idx < MLP_B3) dst = a.grad_mlp[4] + (idx - MLP_W3);
+        else dst = a.grad_mlp[5];
+      }
+    } else {
+      const int t = idx - PART_TRASH, sl = t >> 3, q = t & 7;
+      if (sl < L && a.lv[sl].grad) dst = a.lv[sl].grad + a.rows[sl] * F + q;
+    }
+  }
+  const float old = dst ? *dst : 0.f;
   float s = 0.f;
   if (idx < PART_FLOATS) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -913,25 +932,11 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
     s_dred[part][lane] = d;
   }
   __syncthreads();
-  if (part == 0 && idx < PART_FLOATS) {
+  if (dst) {
     float tot = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) tot += s_red[k][lane];
-    if (idx < SHINE_MLP_PARAMS) {
-      if (a.decoder_grad_on) {
-        float* d;
-        if (idx < MLP_B1) d = a.grad_mlp[0] + idx;
-        else if (idx < MLP_W2) d = a.grad_mlp[1] + (idx - MLP_B1);
-        else if (idx < MLP_B2) d = a.grad_mlp[2] + (idx - MLP_W2);
-        else if (idx < MLP_W3) d = a.grad_mlp[3] + (idx - MLP_B2);
-        else if (idx < MLP_B3) d = a.grad_mlp[4] + (idx - MLP_W3);
-        else d = a.grad_mlp[5];
-        *d += tot;
-      }
-    } else {
-      const int t = idx - PART_TRASH, sl = t >> 3, q = t & 7;
-      if (sl < L && a.lv[sl].grad) a.lv[sl].grad[a.rows[sl] * F + q] += tot;
-    }
+    *dst = old + tot;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_parts) {
     double ls = 0.0, cs = 0.0, es = 0.0;
