@@ -24,7 +24,10 @@ struct InterpArgs {
 
 template <bool POLY, bool SECOND>
 __global__ __launch_bounds__(256) void k_interp_bwd(InterpArgs a) {
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < a.n; p += (long long)gridDim.x * 256) {
+  const int lane = threadIdx.x & 63;
+  for (long long base = (long long)blockIdx.x * 256; base < a.n; base += (long long)gridDim.x * 256) {
+    const bool valid = base + threadIdx.x < a.n;  // the loop itself stays wave-uniform: the trash-row sums are wave-wide
+    const long long p = valid ? base + threadIdx.x : a.n - 1;
     const float x0 = a.coord[3 * p], x1 = a.coord[3 * p + 1], x2 = a.coord[3 * p + 2];
     float g[F];
     {
@@ -57,17 +60,18 @@ __global__ __launch_bounds__(256) void k_interp_bwd(InterpArgs a) {
         ids[0] = v0.x; ids[1] = v0.y; ids[2] = v0.z; ids[3] = v0.w;
         ids[4] = v1.x; ids[5] = v1.y; ids[6] = v1.z; ids[7] = v1.w;
       }
+      float csum = 0.f;  // a miss: all eight corners address the trash row (index -1, :205,231), which receives sum_c
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const float coef = SECOND ? (dw[c][0] * q0 + dw[c][1] * q1 + dw[c][2] * q2) : w[c];
-        const long long row = slot >= 0 ? (long long)ids[c] : Lv.rows;  // -1 -> trash row (:205,231)
-        if (Lv.grad) {
-          float* dst = Lv.grad + row * F;
+        csum += coef;
+        if (Lv.grad && slot >= 0 && valid) {
+          float* dst = Lv.grad + (long long)ids[c] * F;
 #pragma unroll
           for (int i = 0; i < F; ++i) atomic_add_f32(dst + i, coef * g[i]);
         }
         if (slot >= 0 && (SECOND ? a.out_g != nullptr : a.out_x != nullptr)) {
-          const float4* rp = reinterpret_cast<const float4*>(Lv.feat + row * F);
+          const float4* rp = reinterpret_cast<const float4*>(Lv.feat + (long long)ids[c] * F);
           float4 r0 = rp[0], r1 = rp[1];
           const float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
           if (SECOND) {
@@ -83,7 +87,18 @@ __global__ __launch_bounds__(256) void k_interp_bwd(InterpArgs a) {
           }
         }
       }
+      // one atomic per wave and feature for the trash row instead of 64 per missing point on the same 32 bytes (free-space
+      // samples outside the mapped shell miss at every level: same-address atomics serialise at the memory controller)
+      if (Lv.grad && __any(valid && slot < 0)) {
+        const float cm = (valid && slot < 0) ? csum : 0.f;
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+          const float tsum = wave_sum(cm * g[i]);
+          if (lane == 0 && tsum != 0.f) atomic_add_f32(Lv.grad + Lv.rows * F + i, tsum);
+        }
+      }
     }
+    if (!valid) continue;
     if (!SECOND && a.out_x) {
       a.out_x[3 * p] = ox[0];
       a.out_x[3 * p + 1] = ox[1];
