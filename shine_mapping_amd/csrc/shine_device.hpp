@@ -138,6 +138,37 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// wave-uniform read-only data (decoder weights) through the constant address space: uniform-address loads from it are
+// scalar (s_load_dwordx*), and VALU instructions take the SGPR operand directly.  Only for memory no kernel of the same
+// launch writes.
+typedef const float __attribute__((address_space(4))) cfloat;
+__device__ __forceinline__ cfloat* uniform_ro(const float* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (cfloat*)p;
+#pragma clang diagnostic pop
+}
+
+// wave-local LDS hand-off: DS ops of one wave execute in order; this only stops the compiler reordering them
+// (a workgroup-scope __builtin_amdgcn_fence would also drain vmcnt, i.e. wait for every gather/atomic in flight)
+__device__ __forceinline__ void wave_lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Hide a uniform value / pointer from the optimiser (no instruction).  opaque(H) as a trip count keeps a loop over weight
+// rows ROLLED (an `unroll 2` pragma alone is followed by a full unroll of the remaining 16 trips); relaunder(p) once per
+// loop iteration keeps loads through p inside that iteration (they are loop-invariant, and 1377 hoisted weights is
+// ~1300 spilled SGPRs).
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+__device__ __forceinline__ cfloat* relaunder(cfloat* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 // hardware fp32 atomic add (global_atomic_add_f32), no CAS loop
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 

@@ -5,8 +5,9 @@
 //   backward-backward  (for get_gradient(create_graph=True) + eikonal, utils/tools.py:175-185, shine_batch.py:182-185)
 //                      given gg = d loss / d(dx):  dg_p += sum_{l,c} (dw.gg) F_l[id] ;  dF_l[id] += (dw.gg) g_p
 //                      (the second derivative wrt x itself is not produced: coord is a leaf whose .grad nobody reads)
-// Forward is shine_forward(feat_out=...).  These two kernels are lane = point with fp32 atomics: correctness tier,
-// the throughput tier is the fused step.
+// Forward is shine_forward(feat_out=...).  These two kernels are lane = point (unordered batches: no node runs to
+// merge), the feature-grad atomics are issued with the lanes transposed to (point, feature); the throughput tier is the
+// fused step.
 #include "shine_internal.hpp"
 
 namespace shine {
@@ -24,7 +25,10 @@ struct InterpArgs {
 
 template <bool POLY, bool SECOND>
 __global__ __launch_bounds__(256) void k_interp_bwd(InterpArgs a) {
+  __shared__ float s_g[4 * 64 * F];
   const int lane = threadIdx.x & 63;
+  float* const gt = s_g + (threadIdx.x >> 6) * 64 * F;
+  const int sub = lane >> 3, fi = lane & 7;
   for (long long base = (long long)blockIdx.x * 256; base < a.n; base += (long long)gridDim.x * 256) {
     const bool valid = base + threadIdx.x < a.n;  // the loop itself stays wave-uniform: the trash-row sums are wave-wide
     const long long p = valid ? base + threadIdx.x : a.n - 1;
@@ -35,6 +39,17 @@ __global__ __launch_bounds__(256) void k_interp_bwd(InterpArgs a) {
       float4 g0 = gp[0], g1 = gp[1];
       g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
     }
+    // Feature-grad scatter with the lanes TRANSPOSED: one atomic instruction covers 8 points x the 8 features of one
+    // corner row each (8 x 32 contiguous bytes) instead of 64 different rows x 4 bytes — an eighth of the memory-side
+    // transactions.  g goes through LDS once per tile ([point][feature] -> lane (point & 7 group, feature)), the corner
+    // ids and coefficients of the source point come by shuffle.
+    float gval[8];
+    wave_lds_fence();  // the previous tile's reads are done
+    reinterpret_cast<float4*>(gt + lane * F)[0] = make_float4(g[0], g[1], g[2], g[3]);
+    reinterpret_cast<float4*>(gt + lane * F)[1] = make_float4(g[4], g[5], g[6], g[7]);
+    wave_lds_fence();
+#pragma unroll
+    for (int G = 0; G < 8; ++G) gval[G] = gt[G * 64 + lane];
     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
     if (SECOND) {
       q0 = a.gg[3 * p];
@@ -61,15 +76,14 @@ __global__ __launch_bounds__(256) void k_interp_bwd(InterpArgs a) {
         ids[4] = v1.x; ids[5] = v1.y; ids[6] = v1.z; ids[7] = v1.w;
       }
       float csum = 0.f;  // a miss: all eight corners address the trash row (index -1, :205,231), which receives sum_c
+      float coefs[8];
+      int sids[8];  // scatter targets: -1 = nothing (a miss goes to the trash row below, a padding lane nowhere)
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const float coef = SECOND ? (dw[c][0] * q0 + dw[c][1] * q1 + dw[c][2] * q2) : w[c];
+        coefs[c] = coef;
         csum += coef;
-        if (Lv.grad && slot >= 0 && valid) {
-          float* dst = Lv.grad + (long long)ids[c] * F;
-#pragma unroll
-          for (int i = 0; i < F; ++i) atomic_add_f32(dst + i, coef * g[i]);
-        }
+        sids[c] = (slot >= 0 && valid) ? ids[c] : -1;
         if (slot >= 0 && (SECOND ? a.out_g != nullptr : a.out_x != nullptr)) {
           const float4* rp = reinterpret_cast<const float4*>(Lv.feat + (long long)ids[c] * F);
           float4 r0 = rp[0], r1 = rp[1];
@@ -84,6 +98,17 @@ __global__ __launch_bounds__(256) void k_interp_bwd(InterpArgs a) {
             ox[0] = fmaf(dw[c][0], dot, ox[0]);
             ox[1] = fmaf(dw[c][1], dot, ox[1]);
             ox[2] = fmaf(dw[c][2], dot, ox[2]);
+          }
+        }
+      }
+      if (Lv.grad) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+#pragma unroll
+          for (int G = 0; G < 8; ++G) {
+            const int id = __shfl(sids[c], G * 8 + sub, 64);
+            const float cf = __shfl(coefs[c], G * 8 + sub, 64);
+            if (id >= 0) atomic_add_f32(Lv.grad + (long long)id * F + fi, cf * gval[G]);
           }
         }
       }

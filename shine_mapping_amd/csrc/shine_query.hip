@@ -4,8 +4,9 @@
 // marching-cubes mask of :78-86/:99-104 — one launch, nothing but the two outputs leaves the chip.
 //
 // Grid-structured queries are perfectly coherent (neighbouring lanes share voxels), so the gathers hit L1/L2 and
-// the kernel is bound by the decoder arithmetic: lane = point, the 1377 decoder weights live in LDS and are read
-// as wave-uniform 16-B broadcasts (no bank conflicts), h1 stays in registers, h2 is consumed as it is produced.
+// the kernel is bound by the decoder arithmetic: lane = point, the 1377 decoder weights are read through the constant
+// address space (scalar loads, SGPR operands: no VGPR or LDS read per weight), h1 stays in registers, h2 is consumed as
+// it is produced.
 // Bytes per query: 12 in, 5 out.
 #include "shine_internal.hpp"
 
@@ -24,16 +25,13 @@ struct QueryArgs {
 
 template <int L, bool POLY>
 __global__ __launch_bounds__(256) void k_query_points(QueryArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_mlp[SHINE_MLP_PARAMS + 3];
+  // decoder weights: wave-uniform, read-only -> scalar loads into SGPRs that the FMAs take as operands (device.hpp)
+  cfloat* W1 = nullptr, *B1 = nullptr, *W2 = nullptr, *B2 = nullptr, *W3 = nullptr, *B3 = nullptr;
   if (a.sdf_out) {  // wave-uniform
-    for (int i = threadIdx.x; i < H * F; i += 256) s_mlp[MLP_W1 + i] = a.mlp[0][i];
-    for (int i = threadIdx.x; i < H; i += 256) s_mlp[MLP_B1 + i] = a.mlp[1][i];
-    for (int i = threadIdx.x; i < H * H; i += 256) s_mlp[MLP_W2 + i] = a.mlp[2][i];
-    for (int i = threadIdx.x; i < H; i += 256) s_mlp[MLP_B2 + i] = a.mlp[3][i];
-    for (int i = threadIdx.x; i < H; i += 256) s_mlp[MLP_W3 + i] = a.mlp[4][i];
-    if (threadIdx.x == 0) s_mlp[MLP_B3] = a.mlp[5][0];
+    W1 = uniform_ro(a.mlp[0]), B1 = uniform_ro(a.mlp[1]), W2 = uniform_ro(a.mlp[2]), B2 = uniform_ro(a.mlp[3]);
+    W3 = uniform_ro(a.mlp[4]), B3 = uniform_ro(a.mlp[5]);
   }
-  __syncthreads();
+  const int rows = opaque(H);
 
   const long long stride = (long long)gridDim.x * 256;
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < a.n; p += stride) {
@@ -84,26 +82,22 @@ __global__ __launch_bounds__(256) void k_query_points(QueryArgs a) {
     }
     if (a.sdf_out) {
       float h1[H];
+      cfloat *const W1i = relaunder(W1), *const B1i = relaunder(B1);  // keep the loads inside this iteration
 #pragma unroll
       for (int j = 0; j < H; ++j) {
-        const float4 wa = *reinterpret_cast<const float4*>(s_mlp + MLP_W1 + j * F);
-        const float4 wb = *reinterpret_cast<const float4*>(s_mlp + MLP_W1 + j * F + 4);
-        float z = s_mlp[MLP_B1 + j];
-        z += wa.x * f[0] + wa.y * f[1] + wa.z * f[2] + wa.w * f[3];
-        z += wb.x * f[4] + wb.y * f[5] + wb.z * f[6] + wb.w * f[7];
+        float z = B1i[j];
+#pragma unroll
+        for (int q = 0; q < F; ++q) z = fmaf(W1i[j * F + q], f[q], z);
         h1[j] = fmaxf(z, 0.f);
       }
-      float y = s_mlp[MLP_B3];
-#pragma unroll 4
-      for (int j = 0; j < H; ++j) {
-        const float* wr = s_mlp + MLP_W2 + j * H;
-        float z = s_mlp[MLP_B2 + j];
+      float y = B3[0];
+      // layer 2 + 3 as a ROLLED loop over the 32 weight rows (two s_load_dwordx16 each): h2 is consumed as produced
+#pragma clang loop vectorize(disable) interleave(disable) unroll_count(2)
+      for (int j = 0; j < rows; ++j) {
+        float z = B2[j];
 #pragma unroll
-        for (int k = 0; k < H; k += 4) {
-          const float4 wv = *reinterpret_cast<const float4*>(wr + k);
-          z += wv.x * h1[k] + wv.y * h1[k + 1] + wv.z * h1[k + 2] + wv.w * h1[k + 3];
-        }
-        y += s_mlp[MLP_W3 + j] * fmaxf(z, 0.f);
+        for (int k = 0; k < H; ++k) z = fmaf(W2[j * H + k], h1[k], z);
+        y = fmaf(W3[j], fmaxf(z, 0.f), y);
       }
       a.sdf_out[p] = a.sign * y;
     }

@@ -65,13 +65,6 @@ struct V1Args {
 
 __device__ __forceinline__ long long clk() { return (long long)__builtin_readcyclecounter(); }
 
-// wave-local LDS hand-off: DS ops of one wave execute in order; this only stops the compiler reordering them
-// (a workgroup-scope __builtin_amdgcn_fence would also drain vmcnt, i.e. wait for every gather/atomic in flight)
-__device__ __forceinline__ void wave_lds_fence() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // sum over the 16 lanes of a DPP row, result in every lane of the row (4 VALU ops, no LDS traffic)
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
