@@ -425,7 +425,8 @@ def main():
         exchange = "touched" if reducer.dense_bytes() > (64 << 20) else "dense"
     octree._require_tables(with_ranks=True)
     # ONE pool order and ONE random stream on every rank: the global draw is common knowledge
-    spool = SortedPool(octree, pool.coord, pool.sdf_label, pool.weight, seed=1000)
+    # (canonical: the plan leaves the samples of one node in atomic-retirement order, which differs between processes)
+    spool = SortedPool(octree, pool.coord, pool.sdf_label, pool.weight, seed=1000, canonical=use_dist)
     flags = shine_dp.mark_touched(octree, spool, spool.draw(8)) if (use_dist and exchange == "touched") else None
     if flags is not None:
         for f in flags:

@@ -16,8 +16,14 @@ from .dp import plan_batch
 
 
 class SortedPool:
-    def __init__(self, octree, coord, sdf_label, weight, seed=42):
+    def __init__(self, octree, coord, sdf_label, weight, seed=42, canonical=False):
+        """`canonical`: order the samples of one node by their original pool index.  The plan's counting sort places the
+        samples of a node in whatever order its atomics retire, so two processes (or two runs) hold the same pool in
+        different within-node orders: still a valid pool — draws stay i.i.d. uniform — but not the SAME draw.  Data-parallel
+        ranks that want literally one global batch (and anyone who wants run-to-run reproducible draws) pass True; it costs
+        one device sort of the pool per rebuild."""
         self.octree = octree
+        self.canonical = bool(canonical)
         self.seed = int(seed)
         self.draws = 0
         self._ws = {}  # per batch size, never replaced: captured HIP graphs bake the address in
@@ -26,6 +32,13 @@ class SortedPool:
 
     def rebuild(self, coord, sdf_label, weight):
         perm, slots = plan_batch(self.octree, coord)
+        if self.canonical and perm.numel() > 1:
+            # runs of identical slot rows = the samples of one node (or interchangeable misses): sort each run by index
+            change = torch.ones(perm.numel(), dtype=torch.bool, device=perm.device)
+            change[1:] = (slots[1:] != slots[:-1]).any(dim=1)
+            key = (torch.cumsum(change, 0) << 32) + perm.long()
+            order = torch.argsort(key)
+            perm, slots = perm[order].contiguous(), slots[order].contiguous()
         p = perm.long()
         self.coord = coord[p].contiguous()
         self.sdf_label = sdf_label[p].contiguous()
