@@ -202,6 +202,20 @@ int shine_regularize(int32_t n_levels, const float* const* feats, const float* c
                      const float* const* importance, float* const* grad_feats, unsigned char* const* touched,
                      const int64_t* rows, const int32_t* grad_on, float lambda_forget, double* reg_out, void* stream);
 int shine_importance_accumulate(float* importance, float* grad, int64_t rows, void* stream);
+/*      shine_importance_sweep = the whole of cal_feature_importance's chunk loop (utils/incre_learning.py:27-40) in one
+ *      call.  coord / sdf_label / weight (or NULL) / slots: a node-ordered pool as for pool-mode shine_train_step
+ *      (cfg->sorted_input = 2, eikonal off, decoder_grad_on = 0); idx: the chunks' members (sorted sample indices into the
+ *      pool) stored chunk after chunk; chunk_begin: HOST int64[n_chunks + 1] offsets into idx.  Per chunk: the fused step
+ *      with inv_n = 1 / chunk size (or 1 under reduction_sum) accumulating into grad_feats, then importance[s] +=
+ *      |grad_feats[s]|, grad_feats[s] = 0, importance[s][trash row] = 0 for every level.  grad_feats must be zero on
+ *      entry (and are zero on return); pred_scratch: device float[max chunk size]; workspace as for shine_train_step of
+ *      the largest chunk. */
+int shine_importance_sweep(const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                           const float* sdf_label, const float* weight, const int32_t* idx, const int32_t* slots,
+                           const int64_t* chunk_begin, int32_t n_chunks, const float* const* feats, const int64_t* rows,
+                           const float* const* mlp, float* pred_scratch, float* const* grad_feats,
+                           float* const* importance, double* loss_parts, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 /* ---- fused dense Adam (next row f-1): opt.step() [+ opt.zero_grad()] of shine_batch.py:208-210 for the optimiser of
  *      setup_optimizer (utils/tools.py:57-83): torch.optim.Adam semantics (betas, eps, L2 weight decay added to the

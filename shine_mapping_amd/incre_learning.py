@@ -5,36 +5,66 @@ Per chunk of the frame's pool the reference runs query + decode + BCE + backward
 Here the chunk's forward+backward is one fused step with the decoder frozen (only feature grads are needed) and the
 epilogue is one kernel per level (shine_importance_accumulate).
 """
+import ctypes as C
 import math
 
 import torch
 
 from . import _lib
 from .dp import plan_batch
-from .ops import StepOptions, _dense_grad, fused_train_step
+from .ops import StepOptions, _dense_grad, _workspace
 
 
 def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduction="mean", loss_weight_on=False):
-    """Same signature as the reference; `data` needs .coord_pool and .sdf_label_pool (utils/incre_learning.py:14-26)."""
+    """Same signature as the reference; `data` needs .coord_pool and .sdf_label_pool (utils/incre_learning.py:14-26).
+
+    The reference walks the pool in chunks [n*bs*down_rate, (n+1)*bs*down_rate) taking every down_rate-th sample
+    (:27-31); a chunk's gradient is summed before the abs (:36-38), so chunk MEMBERSHIP is part of the result, the order
+    inside a chunk is not.  Here the whole pool is planned once (node order + hash slots), the node-ordered samples are
+    partitioned by chunk with one stable device sort, and shine_importance_sweep runs the chunk loop (fused step with the
+    decoder frozen + epilogue) on the other side of the ABI: no per-chunk Python, slicing or planning."""
     # loss_weight_on has no effect here, as in the reference: it passes weight=None (utils/incre_learning.py:32), and
     # nn.BCEWithLogitsLoss(weight=None) is the unweighted loss
-    sample_count = data.coord_pool.shape[0]
+    dev = octree.hier_features[0].device
+    coord_pool = data.coord_pool.to(dev)
+    label_pool = data.sdf_label_pool.to(dev, torch.float32)
+    sample_count = coord_pool.shape[0]
     batch_interval = bs * down_rate
     iter_n = math.ceil(sample_count / batch_interval)
-    opts = StepOptions(sigma=float(sigma), loss_reduction=loss_reduction, decoder_grad_on=False)
-    stream = _lib.current_stream_handle()
-    for p in octree.hier_features:
-        if p.grad is not None:
-            p.grad.zero_()
+    if iter_n == 0:
+        return
+    t = octree._require_tables(with_ranks=True)
+    perm, slots = plan_batch(octree, coord_pool)  # sorted position j holds pool sample perm[j]
+    p = perm.long()
+    coord_s = octree._check_coord(coord_pool)[p].contiguous()
+    label_s = label_pool[p].contiguous()
+    # chunk of every node-ordered sample; the samples the stride skips go behind the last chunk
+    off = p % batch_interval
+    key = torch.where(off % down_rate == 0, p // batch_interval, torch.full_like(p, iter_n))
+    idx = torch.argsort(key, stable=True).to(torch.int32)  # within a chunk: ascending sorted position = node order
+    begin = [0]
     for n in range(iter_n):
-        head = n * batch_interval
-        tail = min((n + 1) * batch_interval, sample_count)
-        batch_coord = data.coord_pool[head:tail:down_rate].contiguous()
-        batch_label = data.sdf_label_pool[head:tail:down_rate].contiguous()
-        perm, slots = plan_batch(octree, batch_coord)
-        fused_train_step(octree, mlp, batch_coord, batch_label, None, opts, perm=perm, slots=slots)
-        for i in range(len(octree.importance_weight)):
-            g = _dense_grad(octree.hier_features[i])
-            imp = octree.importance_weight[i]
-            _lib.check(_lib.lib().shine_importance_accumulate(imp.data_ptr(), g.data_ptr(), imp.shape[0] - 1, stream),
-                       "shine_importance_accumulate")
+        head, tail = n * batch_interval, min((n + 1) * batch_interval, sample_count)
+        begin.append(begin[-1] + (tail - head + down_rate - 1) // down_rate)
+    max_chunk = max(b - a for a, b in zip(begin[:-1], begin[1:]))
+    opts = StepOptions(sigma=float(sigma), loss_reduction=loss_reduction, decoder_grad_on=False)
+    cfg = octree.step_config(sigma=float(sigma), weight_e=0.0, eikonal_on=0,
+                             reduction_sum=1 if loss_reduction == "sum" else 0, decoder_grad_on=0, sorted_input=2,
+                             n_global=max_chunk, kernel_variant=int(opts.kernel_variant), loss_weight_on=0,
+                             inv_n=1.0)
+    grads = [_dense_grad(f) for f in octree.hier_features]
+    for g in grads:
+        g.zero_()
+    pred = torch.empty(max_chunk, dtype=torch.float32, device=dev)
+    loss_parts = torch.empty(4, dtype=torch.float64, device=dev)
+    ws = _workspace(dev, cfg)
+    lib = _lib.lib()
+    _lib.check(
+        lib.shine_importance_sweep(
+            t.handle, C.byref(cfg), coord_s.data_ptr(), label_s.data_ptr(), None, idx.data_ptr(), slots.data_ptr(),
+            _lib.i64_array(begin), iter_n, octree.feature_ptrs(), octree.row_counts(),
+            _lib.ptr_array([q.data_ptr() for q in mlp.fused_params()]), pred.data_ptr(),
+            _lib.ptr_array([g.data_ptr() for g in grads]),
+            _lib.ptr_array([w.data_ptr() for w in octree.importance_weight]), loss_parts.data_ptr(), ws.data_ptr(),
+            ws.numel(), _lib.current_stream_handle()),
+        "shine_importance_sweep")

@@ -427,6 +427,37 @@ def test_fused_regulariser_and_importance_sweep_match_reference():
         assert float(a[-1].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("reduction,bs,down_rate,take", [("mean", 100, 3, 1001), ("sum", 4096, 1, 700), ("mean", 64, 2, 1024)])
+def test_importance_sweep_chunking_matches_oracle(reduction, bs, down_rate, take):
+    """cal_feature_importance's chunk loop runs behind the ABI (shine_importance_sweep): a chunk's gradient is summed
+    before the abs, so chunk MEMBERSHIP (head:tail:down_rate of the pool in its original order, a short last chunk, one
+    chunk larger than the pool) must be the reference's — utils/incre_learning.py:27-40 — as must the per-chunk 'mean'."""
+    import copy
+
+    from oracle import shine_oracle as so
+    from shine_mapping_amd.incre_learning import cal_feature_importance
+
+    fx = load_golden("ncd_reg_L3")
+    cfg, octree, dec = product_from_golden(fx)
+    ocfg, oct_, mlp = oracle_from_golden(fx)
+    ocfg = copy.copy(ocfg)
+    ocfg.loss_reduction = reduction
+    pool_c, pool_l = fx["coord"][:take].contiguous(), fx["sdf_label"][:take].contiguous()
+    for t in oct_.importance_weight:
+        t.zero_()
+    so.importance_sweep(oct_, mlp, pool_c, pool_l, ocfg, bs, down_rate)
+    for t in octree.importance_weight:
+        t.zero_()
+    data = type("Pool", (), {"coord_pool": pool_c.cuda(), "sdf_label_pool": pool_l.cuda()})()
+    cal_feature_importance(data, octree, dec, fx["sigma"], bs, down_rate, reduction)
+    torch.cuda.synchronize()
+    for a, b in zip(octree.importance_weight, oct_.importance_weight):
+        assert rel_err(a, b) <= TOL
+        assert float(a[-1].abs().max()) == 0.0
+    for f in octree.hier_features:  # the sweep leaves the gradients cleared (incre_learning.py:38)
+        assert float(f.grad.abs().max()) == 0.0
+
+
 def test_fused_adam_matches_torch_adam():
     """shine_adam_step vs torch.optim.Adam with the reference's groups (utils/tools.py:57-83): decoder with L2
     weight decay, one group per feature level, betas (0.9, 0.99), eps 1e-15; five steps, grads cleared in-pass."""
