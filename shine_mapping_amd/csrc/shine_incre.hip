@@ -4,7 +4,7 @@
 //       reg = sum_levels sum_{u in unique(hierarchical_indices)} importance[u] * (F[u] - F_last[u])^2
 //       The reference finds the touched rows with a sort-based unique() of 8N int64 per level per iteration; here
 //       the fused step leaves a byte flag per touched row (shine_train_step `touched`), and one row-parallel
-//       pass evaluates value and gradient and clears the flags.  grad_on[s] = 0 reproduces the reference's
+//       pass evaluates value and gradient and clears the flags (same launch).  grad_on[s] = 0 reproduces the reference's
 //       attached-clone quirk (:160): the term adds to the loss value but not to the gradient.
 //   shine_importance_accumulate  the per-chunk epilogue of cal_feature_importance   utils/incre_learning.py:36-40
 //       importance += |grad| ; grad = 0 ; importance[trash row] = 0
@@ -26,37 +26,42 @@ struct RegArgs {
   double* out;  // out[0] += reg (unweighted)
 };
 
+// lane = row: the sweep reads one flag byte per row (coalesced) and only the touched rows (a few thousand of ~200 k at
+// the reference's batch size) fetch their 3 x 32 bytes; the flag is cleared in the same pass.  (One thread per ELEMENT,
+// with a level search and a flag read each, took 28 us per iteration — more than the fused step itself.)
 __global__ __launch_bounds__(256) void k_regularize(RegArgs a) {
   __shared__ double s_red[4];
   double acc = 0.0;
-  const long long total = a.start[a.n_levels] * F;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long row_g = e / F;
-    const int q = (int)(e % F);
+  const long long total = a.start[a.n_levels];
+  for (long long row_g = (long long)blockIdx.x * 256 + threadIdx.x; row_g < total; row_g += (long long)gridDim.x * 256) {
     int s = 0;
     while (s + 1 < a.n_levels && row_g >= a.start[s + 1]) ++s;
     const long long r = row_g - a.start[s];
     if (a.touched[s][r]) {
-      const long long idx = r * F + q;
-      const float d = a.feat[s][idx] - a.last[s][idx];
-      const float w = a.imp[s][idx];
-      acc += (double)(w * d * d);
-      if (a.grad_on[s] && a.grad[s]) a.grad[s][idx] += 2.0f * a.lambda * w * d;  // one thread per element: no atomics
+      a.touched[s][r] = 0;
+      const float4* fp = reinterpret_cast<const float4*>(a.feat[s] + r * F);
+      const float4* lp = reinterpret_cast<const float4*>(a.last[s] + r * F);
+      const float4* ip = reinterpret_cast<const float4*>(a.imp[s] + r * F);
+      const float4 f0 = fp[0], f1 = fp[1], l0 = lp[0], l1 = lp[1], w0 = ip[0], w1 = ip[1];
+      const float d[F] = {f0.x - l0.x, f0.y - l0.y, f0.z - l0.z, f0.w - l0.w, f1.x - l1.x, f1.y - l1.y, f1.z - l1.z, f1.w - l1.w};
+      const float w[F] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int q = 0; q < F; ++q) acc += (double)(w[q] * d[q] * d[q]);
+      if (a.grad_on[s] && a.grad[s]) {  // one thread per row: no atomics
+        float4* gp = reinterpret_cast<float4*>(a.grad[s] + r * F);
+        float4 g0 = gp[0], g1 = gp[1];
+        const float k = 2.0f * a.lambda;
+        g0.x += k * w[0] * d[0]; g0.y += k * w[1] * d[1]; g0.z += k * w[2] * d[2]; g0.w += k * w[3] * d[3];
+        g1.x += k * w[4] * d[4]; g1.y += k * w[5] * d[5]; g1.z += k * w[6] * d[6]; g1.w += k * w[7] * d[7];
+        gp[0] = g0;
+        gp[1] = g1;
+      }
     }
   }
   acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(a.out, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
-}
-
-__global__ __launch_bounds__(256) void k_clear_touched(RegArgs a) {
-  const long long total = a.start[a.n_levels];
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    int s = 0;
-    while (s + 1 < a.n_levels && e >= a.start[s + 1]) ++s;
-    a.touched[s][e - a.start[s]] = 0;
-  }
 }
 
 __global__ __launch_bounds__(256) void k_importance(float* imp, float* grad, long long n_elems, long long trash_begin) {
@@ -109,6 +114,9 @@ extern "C" int shine_regularize(int32_t n_levels, const float* const* feats, con
   for (int s = 0; s < n_levels; ++s) {
     if (!feats[s] || !feats_last[s] || !importance[s] || !touched[s])
       return set_error(SHINE_E_INVALID, "shine_regularize: null level pointer");
+    if ((((size_t)feats[s] | (size_t)feats_last[s] | (size_t)importance[s] |
+          (size_t)(grad_feats && grad_feats[s] ? grad_feats[s] : nullptr)) & 15))
+      return set_error(SHINE_E_INVALID, "shine_regularize: level tensors must be 16-byte aligned");
     a.feat[s] = feats[s];
     a.last[s] = feats_last[s];
     a.imp[s] = importance[s];
@@ -120,13 +128,11 @@ extern "C" int shine_regularize(int32_t n_levels, const float* const* feats, con
   }
   hipStream_t st = (hipStream_t)stream;
   SHINE_HIP_CHECK(hipMemsetAsync(reg_out, 0, sizeof(double), st));
-  const long long total = a.start[n_levels] * F;
+  const long long total = a.start[n_levels];  // rows
   if (total == 0) return SHINE_OK;
   long long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_regularize, dim3((unsigned)blocks), dim3(256), 0, st, a);
-  SHINE_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_clear_touched, dim3((unsigned)blocks), dim3(256), 0, st, a);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }

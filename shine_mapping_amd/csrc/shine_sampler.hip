@@ -5,7 +5,7 @@
 // order.  If the POOL is kept in node order (shine_plan_batch on the whole pool, once per frame), a batch is in node
 // order as soon as its indices are sorted — and sorted i.i.d. uniform indices can be generated directly, without a
 // sort, from the order statistics of the uniform distribution:
-//       E_0..E_n ~ Exp(1) i.i.d.,  S_k = E_0 + .. + E_k,   U_(k) = S_k / S_n   (k < n)  are the sorted uniforms,
+//       E_0..E_n ~ Exp(1) i.i.d. (exp1v below),  S_k = E_0 + .. + E_k,   U_(k) = S_k / S_n   (k < n)  are the sorted uniforms,
 //       idx_k = floor(U_(k) * pool_size).
 // As a multiset this is exactly `randint` (sampling with replacement); only the order differs, which no loss term
 // depends on.  Two launches (block sums, then regenerate + scan + scale), no atomics, no scratch array.
@@ -13,13 +13,17 @@
 
 namespace shine {
 
-// counter-based generator: splitmix64 finaliser of (seed, stream, counter) -> uniform in (0,1]
-__device__ __forceinline__ double u01(unsigned long long seed, unsigned long long stream, unsigned long long k) {
+// counter-based generator: splitmix64 finaliser of (seed, stream, counter)
+// Exp(1) variate of draw k: -ln(u) with u on the 2^24 grid of (0,1], through the hardware fp32 log2 (v_log_f32, ~1 ulp)
+// — a fp64 log() is a ~1000-cycle dependent chain and was the whole cost of a small draw (11 us for 4096 draws).  The
+// running sums stay fp64; 24-bit variates truncate the exponential's tail at 16.6 (probability 6e-8).
+__device__ __forceinline__ double exp1v(unsigned long long seed, unsigned long long stream, unsigned long long k) {
   unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (stream * 0x100000001B3ull + k + 1);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);
-  return ((double)(z >> 11) + 1.0) * (1.0 / 9007199254740992.0);  // (0,1]
+  const float u = ((float)(unsigned int)(z >> 40) + 1.0f) * (1.0f / 16777216.0f);
+  return (double)(-0.693147180559945f * __builtin_amdgcn_logf(u));
 }
 
 // Two launches, no scratch array: the generator is counter-based, so pass 2 simply REGENERATES the variates of its
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256) void k_sample_pass1(double* block_sum, long lo
   double v = 0.0;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    if (k0 + j < n1) v += -log(u01(seed, stream, (unsigned long long)(k0 + j)));
+    if (k0 + j < n1) v += exp1v(seed, stream, (unsigned long long)(k0 + j));
   const double t = block_sum_256(v, s_red);
   if (threadIdx.x == 0) block_sum[blockIdx.x] = t;
 }
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, i
   double e[4], run = 0.0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    e[j] = (k0 + j <= n) ? -log(u01(seed, stream, (unsigned long long)(k0 + j))) : 0.0;
+    e[j] = (k0 + j <= n) ? exp1v(seed, stream, (unsigned long long)(k0 + j)) : 0.0;
     run += e[j];
   }
   // exclusive scan of the per-thread sums across the block: within the wave by shuffles, across waves via LDS
@@ -104,6 +108,79 @@ __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, i
     }
   }
   if (stream_dev) {  // the last block to finish advances the stream for the next replay (every block has read it by then)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(&stream_dev[1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
+        stream_dev[1] = 0ull;
+        __threadfence();
+        atomicAdd(&stream_dev[0], 1ull);
+      }
+    }
+  }
+}
+
+// Small draws (the reference's bs = 4096 is 5 blocks): ONE launch.  Every block first recomputes all the block sums
+// itself (at most FUSED_MAX_BLOCKS x 4 variates per thread, same arithmetic and summation order as pass 1, so the draw is
+// bit-identical to the two-launch form), then does pass 2's work for its own block.  One graph node less per iteration.
+constexpr int FUSED_MAX_BLOCKS = 16;
+
+__global__ __launch_bounds__(256) void k_sample_fused(int nblocks, long long n, long long pool, unsigned long long seed,
+                                                      unsigned long long stream, unsigned long long* stream_dev, int* idx,
+                                                      float4* zero_ptr, long long zero_n16) {
+  __shared__ double s_red[4];
+  __shared__ double s_wave_pre[4];
+  __shared__ double s_bs[FUSED_MAX_BLOCKS];
+  if (stream_dev) stream = stream_dev[0];
+  const long long n1 = n + 1;
+  const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (long long z = gt; z < zero_n16; z += (long long)gridDim.x * 256) zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = 0; b < nblocks; ++b) {
+    const long long k0 = (long long)b * SB + threadIdx.x * 4;
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < n1) v += exp1v(seed, stream, (unsigned long long)(k0 + j));
+    const double t = block_sum_256(v, s_red);
+    if (threadIdx.x == 0) s_bs[b] = t;
+  }
+  __syncthreads();
+  double before = 0.0, total = 0.0;
+  if ((int)threadIdx.x < nblocks) {
+    const double v = s_bs[threadIdx.x];
+    total += v;
+    if ((int)threadIdx.x < (int)blockIdx.x) before += v;
+  }
+  before = block_sum_256(before, s_red);
+  total = block_sum_256(total, s_red);
+  const long long k0 = (long long)blockIdx.x * SB + threadIdx.x * 4;
+  double e[4], run = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    e[j] = (k0 + j <= n) ? exp1v(seed, stream, (unsigned long long)(k0 + j)) : 0.0;
+    run += e[j];
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double inc = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) s_wave_pre[wv] = inc;
+  __syncthreads();
+  double wpre = 0.0;
+  for (int w = 0; w < wv; ++w) wpre += s_wave_pre[w];
+  double sacc = before + wpre + (inc - run);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sacc += e[j];
+    if (k0 + j < n) {
+      long long v = (long long)((sacc / total) * (double)pool);
+      idx[k0 + j] = (int)(v < 0 ? 0 : (v >= pool ? pool - 1 : v));
+    }
+  }
+  if (stream_dev) {  // as in pass 2: the last block to finish advances the stream id
     __syncthreads();
     if (threadIdx.x == 0) {
       __threadfence();
@@ -146,6 +223,13 @@ static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint6
     return SHINE_OK;
   }
   if (!idx_out) return set_error(SHINE_E_INVALID, "shine_sample_sorted: null output");
+  if (nblocks <= FUSED_MAX_BLOCKS && slice_begin == 0 && slice_n == n) {
+    hipLaunchKernelGGL(k_sample_fused, dim3((unsigned)nblocks), dim3(256), 0, st, (int)nblocks, (long long)n,
+                       (long long)pool_size, (unsigned long long)seed, (unsigned long long)stream_id, stream_dev,
+                       (int*)idx_out, (float4*)zero_ptr, zero_ptr ? (long long)(zero_bytes / 16) : 0ll);
+    SHINE_HIP_CHECK(hipGetLastError());
+    return SHINE_OK;
+  }
   double* bs = (double*)workspace;
   hipLaunchKernelGGL(k_sample_pass1, dim3((unsigned)nblocks), dim3(256), 0, st, bs, n1, (unsigned long long)seed,
                      (unsigned long long)stream_id, (const unsigned long long*)stream_dev, (float4*)zero_ptr,

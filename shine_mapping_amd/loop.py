@@ -20,6 +20,30 @@ import torch
 from .ops import StepOptions, fused_regularization, fused_train_step, touched_flags
 
 
+_CAPTURE_STREAM = {}
+
+
+def _capture(fn):
+    """Capture fn() into a new HIP graph on a side stream -> (graph, fn's result).  What `with torch.cuda.graph(g)` does,
+    minus its gc.collect() + torch.cuda.empty_cache(): incremental mapping re-captures the iteration every frame
+    (the parameters are re-allocated when the octree grows), and emptying the allocator's cache each time makes the next
+    frame's allocations go back to hipMalloc."""
+    dev = torch.cuda.current_device()
+    side = _CAPTURE_STREAM.get(dev)
+    if side is None:
+        side = _CAPTURE_STREAM[dev] = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g.capture_begin()
+        try:
+            out = fn()
+        finally:
+            g.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    return g, out
+
+
 class GraphedIteration:
     def __init__(self, octree, decoder, pool, opt, opts: StepOptions, n: int, lambda_forget: float = 0.0, unroll: int = 1):
         self.octree, self.decoder, self.pool, self.opt, self.opts, self.n = octree, decoder, pool, opt, opts, int(n)
@@ -31,20 +55,20 @@ class GraphedIteration:
         self._nsurf = torch.zeros((), dtype=torch.int64, device=pool.coord.device)
         self.loss = self.reg = None
         self._body()  # eager warm-up: allocates workspaces, optimiser state and device counters outside the capture
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss, self.reg = self._body()
+        self.graph, (self.loss, self.reg) = _capture(self._body)
         # `unroll` iterations in ONE graph: at the reference's batch size an iteration is ~8 small launches, and a graph
         # replay costs ~10-16 us of host time whatever it holds — run(n) replays the long graph n // unroll times.  It pays
         # only when the graph lives for many replays: capture cost grows with the node count (bench.py --unroll)
         self.unroll = max(1, int(unroll))
         self.graph_k = None
         if self.unroll > 1:
-            self.graph_k = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_k):
+            def body_k():
+                out = None
                 for _ in range(self.unroll):
-                    self.loss_k, self.reg_k = self._body()
+                    out = self._body()
+                return out
+
+            self.graph_k, (self.loss_k, self.reg_k) = _capture(body_k)
 
     def _body(self):
         idx = self.pool.draw(self.n, out=self._idx, graph_safe=True)
