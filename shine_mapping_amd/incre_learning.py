@@ -15,6 +15,23 @@ from .dp import plan_batch
 from .ops import StepOptions, _dense_grad, _workspace
 
 
+def chunk_partition(perm, sample_count, batch_interval, down_rate):
+    """The reference's chunks (pool[head:tail:down_rate] for head = n * batch_interval, utils/incre_learning.py:27-31) as
+    segments of node-ordered positions: perm[j] is the pool index of sorted position j.  Returns (idx int32 [kept],
+    begin list[iter_n + 1]): chunk n = idx[begin[n]:begin[n+1]], ascending (= node order) inside a chunk."""
+    iter_n = math.ceil(sample_count / batch_interval)
+    p = perm.long()
+    off = p % batch_interval
+    # the samples the stride skips go behind the last chunk
+    key = torch.where(off % down_rate == 0, p // batch_interval, torch.full_like(p, iter_n))
+    idx = torch.argsort(key, stable=True).to(torch.int32)
+    begin = [0]
+    for n in range(iter_n):
+        head, tail = n * batch_interval, min((n + 1) * batch_interval, sample_count)
+        begin.append(begin[-1] + (tail - head + down_rate - 1) // down_rate)
+    return idx, begin
+
+
 def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduction="mean", loss_weight_on=False):
     """Same signature as the reference; `data` needs .coord_pool and .sdf_label_pool (utils/incre_learning.py:14-26).
 
@@ -38,14 +55,7 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
     p = perm.long()
     coord_s = octree._check_coord(coord_pool)[p].contiguous()
     label_s = label_pool[p].contiguous()
-    # chunk of every node-ordered sample; the samples the stride skips go behind the last chunk
-    off = p % batch_interval
-    key = torch.where(off % down_rate == 0, p // batch_interval, torch.full_like(p, iter_n))
-    idx = torch.argsort(key, stable=True).to(torch.int32)  # within a chunk: ascending sorted position = node order
-    begin = [0]
-    for n in range(iter_n):
-        head, tail = n * batch_interval, min((n + 1) * batch_interval, sample_count)
-        begin.append(begin[-1] + (tail - head + down_rate - 1) // down_rate)
+    idx, begin = chunk_partition(perm, sample_count, batch_interval, down_rate)
     max_chunk = max(b - a for a, b in zip(begin[:-1], begin[1:]))
     opts = StepOptions(sigma=float(sigma), loss_reduction=loss_reduction, decoder_grad_on=False)
     cfg = octree.step_config(sigma=float(sigma), weight_e=0.0, eikonal_on=0,

@@ -15,6 +15,15 @@ from . import _lib
 from .dp import plan_batch
 
 
+def canonical_order(perm, slots):
+    """Positions that put the samples of every node (= every run of identical slot rows; interchangeable misses included)
+    in ascending pool-index order, runs left where they are.  perm [N] int32, slots [N, L] int32 in visiting order."""
+    change = torch.ones(perm.numel(), dtype=torch.bool, device=perm.device)
+    change[1:] = (slots[1:] != slots[:-1]).any(dim=1)
+    key = (torch.cumsum(change, 0) << 32) + perm.long()
+    return torch.argsort(key)
+
+
 class SortedPool:
     def __init__(self, octree, coord, sdf_label, weight, seed=42, canonical=False):
         """`canonical`: order the samples of one node by their original pool index.  The plan's counting sort places the
@@ -33,11 +42,7 @@ class SortedPool:
     def rebuild(self, coord, sdf_label, weight):
         perm, slots = plan_batch(self.octree, coord)
         if self.canonical and perm.numel() > 1:
-            # runs of identical slot rows = the samples of one node (or interchangeable misses): sort each run by index
-            change = torch.ones(perm.numel(), dtype=torch.bool, device=perm.device)
-            change[1:] = (slots[1:] != slots[:-1]).any(dim=1)
-            key = (torch.cumsum(change, 0) << 32) + perm.long()
-            order = torch.argsort(key)
+            order = canonical_order(perm, slots)
             perm, slots = perm[order].contiguous(), slots[order].contiguous()
         p = perm.long()
         self.coord = coord[p].contiguous()

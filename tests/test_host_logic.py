@@ -1,0 +1,55 @@
+"""CPU suite: host-side index logic around the HIP calls (no kernels are launched).
+
+* chunk_partition — the chunks of cal_feature_importance (utils/incre_learning.py:27-31: pool[head:tail:down_rate]) as
+  segments of a node-ordered permutation of the pool;
+* canonical_order — SortedPool(canonical=True): samples of one node in ascending pool-index order, nodes left in place.
+"""
+import math
+
+import pytest
+import torch
+
+
+@pytest.mark.parametrize("n,bs,down_rate", [(1, 4, 1), (1001, 100, 3), (700, 4096, 1), (1024, 64, 2), (8192, 4096, 2),
+                                            (8193, 4096, 2), (50001, 2048, 5)])
+def test_chunk_partition_reproduces_the_reference_slices(n, bs, down_rate):
+    from shine_mapping_amd.incre_learning import chunk_partition
+
+    g = torch.Generator().manual_seed(n)
+    perm = torch.randperm(n, generator=g).to(torch.int32)  # any visiting order of the pool
+    interval = bs * down_rate
+    idx, begin = chunk_partition(perm, n, interval, down_rate)
+    iter_n = math.ceil(n / interval)
+    assert len(begin) == iter_n + 1 and begin[0] == 0 and idx.dtype == torch.int32
+    pool = torch.arange(n)
+    for c in range(iter_n):
+        seg = idx[begin[c]:begin[c + 1]].long()
+        want = pool[c * interval:min((c + 1) * interval, n):down_rate]  # the reference's slice
+        assert torch.equal(torch.sort(perm.long()[seg]).values, want)
+        assert bool((seg[1:] > seg[:-1]).all())  # visiting order is kept inside a chunk
+    # what the stride skips sits behind the last chunk and is never read
+    assert begin[-1] == sum(len(range(c * interval, min((c + 1) * interval, n), down_rate)) for c in range(iter_n))
+
+
+def test_canonical_order_sorts_inside_nodes_only():
+    from shine_mapping_amd.sampler import canonical_order
+
+    g = torch.Generator().manual_seed(5)
+    n, L = 5000, 3
+    node = torch.sort(torch.randint(0, 300, (n,), generator=g)).values  # visiting order: by node
+    slots = torch.stack([node // 25, node // 5, node], dim=1).to(torch.int32)
+    slots[node % 7 == 0, 2] = -1  # some leaf-level misses: rows equal up to the coarser levels are interchangeable too
+    base = torch.randperm(n, generator=g).to(torch.int32)
+    order = canonical_order(base, slots)
+    p2, s2 = base[order], slots[order]
+    assert torch.equal(s2, slots)  # every run of identical rows stays where it was
+    same = (s2[1:] == s2[:-1]).all(dim=1)
+    assert bool((p2[1:][same] > p2[:-1][same]).all())  # ascending pool index inside a run
+    assert torch.equal(torch.sort(p2).values, torch.sort(base).values)
+    # two different within-node shuffles of the same pool end up identical
+    shuffled = base.clone()
+    for v in torch.unique(node)[:50]:
+        m = torch.nonzero(node == v).flatten()
+        shuffled[m] = base[m[torch.randperm(m.numel(), generator=g)]]
+    assert not torch.equal(shuffled, base)
+    assert torch.equal(shuffled[canonical_order(shuffled, slots)], p2)
