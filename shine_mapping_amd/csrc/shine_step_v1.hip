@@ -1022,6 +1022,8 @@ extern "C" size_t shine_train_step_workspace_bytes(const shine_step_config* cfg,
 // per point (3 x 2624 BCE, 6 x 2624 with the eikonal term)
 extern "C" int shine_train_step_info(const shine_step_config* cfg, int64_t n, int64_t* out) {
   if (!cfg || !out) return set_error(SHINE_E_INVALID, "shine_train_step_info: null argument");
+  if (cfg->n_levels < 1 || cfg->n_levels > SHINE_MAX_LEVELS)
+    return set_error(SHINE_E_INVALID, "shine_train_step_info: n_levels out of range");
   out[5] = cfg->eikonal_on ? 6 * 2624 : 3 * 2624;
   out[6] = out[7] = 0;
   if (v3_serves(cfg, true)) {  // 16-point tiles, v_mfma_f32_16x16x4_f32 = 2048 FLOP each (bench.py's steps are pool

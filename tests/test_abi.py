@@ -51,6 +51,40 @@ def test_host_side_argument_errors_do_not_need_a_gpu():
     assert lib.shine_tables_destroy(out) == 0
 
 
+def test_argument_checks_of_the_per_iteration_entry_points():
+    """Bad arguments are rejected with SHINE_E_INVALID (-1) before anything touches a device; workspace-size queries are
+    host arithmetic.  (The reference raises Python exceptions for the same misuse; the binding turns -1 into one.)"""
+    import pytest
+
+    from shine_mapping_amd import _lib
+
+    lib = _lib.lib()
+    C = ctypes
+    need = C.c_size_t(0)
+    # sampler: size query, then a slice that does not fit the draw / a pool that does not fit int32
+    assert lib.shine_sample_sorted(1000, 4096, 1, 0, None, None, 0, None, C.byref(need), None) == 0
+    assert need.value >= 5 * 8  # one fp64 block sum per 1024 draws (+ the closing spacing)
+    assert lib.shine_sample_sorted_slice(1000, 4096, 4000, 200, 1, 0, None, None, None, 0, None, C.byref(need), None) == -1
+    assert lib.shine_sample_sorted_slice(1000, 4096, -1, 10, 1, 0, None, None, None, 0, None, C.byref(need), None) == -1
+    assert lib.shine_sample_sorted(1 << 40, 16, 1, 0, None, None, 0, None, C.byref(need), None) == -1
+    assert lib.shine_sample_sorted(1000, 16, 1, 0, None, None, 0, None, None, None) == -1
+    assert b"shine_sample_sorted" in lib.shine_last_error() if hasattr(lib, "shine_last_error") else True
+    # importance sweep / regulariser: null handles and level counts
+    assert lib.shine_importance_sweep(None, None, None, None, None, None, None, None, 0, None, None, None, None, None, None,
+                                      None, None, 0, None) == -1
+    with pytest.raises(_lib.ShineHipError):
+        _lib.check(lib.shine_importance_sweep(None, None, None, None, None, None, None, None, 0, None, None, None, None, None,
+                                              None, None, None, 0, None), "shine_importance_sweep")
+    cfg = _lib.StepConfig()
+    cfg.n_levels = 3
+    assert lib.shine_train_step_workspace_bytes(C.byref(cfg), 4096) > 0
+    info = (C.c_int64 * 8)()
+    assert lib.shine_train_step_info(C.byref(cfg), 1 << 18, info) == 0
+    assert info[0] > 0 and info[2] in (16, 32) and info[4] <= 160 * 1024  # workgroups, tile points, LDS per workgroup
+    cfg.n_levels = 9
+    assert lib.shine_train_step_info(C.byref(cfg), 1 << 18, info) == -1
+
+
 def test_dropin_registers_the_reference_import_paths():
     """`import shine_mapping_amd.dropin` makes `from model.feature_octree import FeatureOctree` /
     `from model.decoder import Decoder` (shine_batch.py:13-14) resolve to this package, and nothing else."""
