@@ -51,6 +51,9 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 #ifndef SHINE_V3_DEDUP
 #define SHINE_V3_DEDUP 0
 #endif
+#ifndef SHINE_V3_PREDSCAT  // measurement builds only: branch-free run-length scatter (see phase 6)
+#define SHINE_V3_PREDSCAT 0
+#endif
 #ifndef SHINE_V3_ABL  // measurement builds only (tools/mk_variant.py): 1 no atomics, 2 no weight-grad phase, 4 no scatter
 #define SHINE_V3_ABL 0  // phase, 8 no row gathers; the product build compiles none of it
 #endif
@@ -795,6 +798,31 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
           float racc = run_acc[s];
           const unsigned int cm = (unsigned int)(chg64 >> (16 * s)) & 0xFFFFu;
           const unsigned int hm = (unsigned int)(hit64 >> (16 * s)) & 0xFFFFu;
+#if SHINE_V3_PREDSCAT
+          // measurement variant (tools/mk_variant.py -DSHINE_V3_PREDSCAT=1): the walk without branches — the run-start
+          // decision selects the exec mask of the atomic (SCC -> s_cselect_b64 exec) and the resets are v_cndmask
+          unsigned long long rmask = rhit ? ~0ull : 0ull;
+#pragma unroll
+          for (int p2 = 0; p2 < V3_TP; ++p2) {
+            const bool start = (cm >> p2) & 1u;
+            unsigned long long saved;
+            asm volatile(
+                "s_mov_b64 %[sv], exec\n\t"
+                "s_bitcmp1_b32 %[cm], %[bit]\n\t"
+                "s_cselect_b64 exec, %[rm], 0\n\t"
+                "global_atomic_add_f32 %[off], %[val], %[base]\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [sv] "=&s"(saved)
+                : [cm] "s"(cm), [bit] "n"(p2), [rm] "s"(rmask), [off] "v"((unsigned int)rid * 4u), [val] "v"(racc),
+                  [base] "s"(gbase)
+                : "scc", "memory");
+            racc = start ? 0.f : racc;
+            rid = start ? ((idr[p2] << 3) | sq) : rid;
+            rmask = start ? (((hm >> p2) & 1u) ? ~0ull : 0ull) : rmask;
+            racc = fmaf(wr[p2], dfr[p2], racc);
+          }
+          rhit = rmask != 0ull;
+#else
 #pragma unroll
           for (int p2 = 0; p2 < V3_TP; ++p2) {
             if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
@@ -805,6 +833,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
             }
             racc = fmaf(wr[p2], dfr[p2], racc);  // misses and padding lanes staged w = 0
           }
+#endif
           run_id[s] = rid;
           run_hit[s] = rhit;
           run_acc[s] = racc;
