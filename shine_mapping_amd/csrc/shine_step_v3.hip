@@ -51,6 +51,9 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 #ifndef SHINE_V3_DEDUP
 #define SHINE_V3_DEDUP 0
 #endif
+#ifndef SHINE_V3_MARK  // measurement builds only: touched-row flags set by the scatter instead of k_mark_touched
+#define SHINE_V3_MARK 0
+#endif
 #ifndef SHINE_V3_PREDSCAT  // measurement builds only: branch-free run-length scatter (see phase 6)
 #define SHINE_V3_PREDSCAT 0
 #endif
@@ -830,6 +833,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
               racc = 0.f;
               rid = (idr[p2] << 3) | sq;  // float offset of this lane's (corner row, feature)
               rhit = (int)((hm >> p2) & 1u);
+#if SHINE_V3_MARK
+              // measurement variant: the touched-row flags (unique(hierarchical_indices) without -1, for shine_regularize)
+              // are set here, at the run start of every hit node, by one lane per corner — no k_mark_touched launch
+              if (rhit && a.touched[s] && sq == 0) a.touched[s][idr[p2]] = 1;
+#endif
             }
             racc = fmaf(wr[p2], dfr[p2], racc);  // misses and padding lanes staged w = 0
           }
@@ -994,7 +1002,7 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
     return set_error(SHINE_E_INVALID, "shine_train_step_v3: workspace too small (shine_train_step_workspace_bytes)");
   a.partials = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  if (touched) {
+  if (touched && !SHINE_V3_MARK) {
     hipLaunchKernelGGL(k_mark_touched, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     SHINE_HIP_CHECK(hipGetLastError());
   }
