@@ -2,6 +2,7 @@
 """Run a script of this repo against a VARIANT library (tools/mk_variant.py) instead of the product build:
 
     python tools/run_with_lib.py tools/ab/lib_NAME.so bench.py --workload ncd-incre --no-cpu-baseline
+    python tools/run_with_lib.py tools/ab/lib_NAME.so -m pytest tests -m gpu -q -k regul
 
 For whole-loop measurements (frames/s of ncd-incre, Tier A iteration times) that tools/ab_build.py's kernel timing does
 not cover.  Measurement aid only: the product always loads shine_mapping_amd/lib/libshine_hip.so."""
@@ -19,5 +20,9 @@ if not os.path.isfile(lib_path):
 _lib.LIB_PATH = lib_path
 _lib._lib = None
 print("[run_with_lib] %s" % lib_path, file=sys.stderr)
-sys.argv = [script] + sys.argv[3:]
-runpy.run_path(os.path.join(ROOT, script) if not os.path.isabs(script) else script, run_name="__main__")
+if script == "-m":  # python tools/run_with_lib.py LIB -m pytest tests -m gpu -k regul
+    sys.argv = sys.argv[3:]
+    runpy.run_module(sys.argv[0], run_name="__main__", alter_sys=True)
+else:
+    sys.argv = [script] + sys.argv[3:]
+    runpy.run_path(os.path.join(ROOT, script) if not os.path.isabs(script) else script, run_name="__main__")
