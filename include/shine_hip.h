@@ -285,8 +285,8 @@ int shine_query_points(const shine_tables* t, const shine_step_config* cfg, cons
 /* ---- graph-replayable forms of the two calls whose per-iteration scalars are otherwise baked into a captured HIP
  *      graph: the scalars live in device memory and the kernels advance them, so ONE captured iteration
  *      {draw, shine_train_step, [shine_regularize], Adam} can be replayed for every iteration of a frame.
- *      stream_state: device uint64[2] = {stream id (read, then +1 by the launch), 0};  step_state: device int64[2] =
- *      {optimiser steps taken so far (this launch performs step [0]+1 and stores it), scratch};  lr_dev: device float[n_tensors]
+ *      stream_state: device uint64[2] = {stream id (read, then +1 by the launch), 0};  step_state: device int64[8] =
+ *      {optimiser steps taken so far (this launch performs step [0]+1 and stores it), scratch, 6 reserved (zeros)};  lr_dev: device float[n_tensors]
  *      (step_lr_decay, utils/tools.py:135-155, becomes a small device copy outside the graph). --------------------- */
 int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t seed, uint64_t* stream_state, int32_t* idx_out,
                             void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);

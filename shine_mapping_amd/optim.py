@@ -27,7 +27,7 @@ class FusedAdam:
         self.step_count = 0
         self.state = {}
         self._age = {}  # per-tensor step count, like torch.optim.Adam's state[p]["step"] (bias correction is per tensor)
-        self._dev = None  # (step_state int64[2], lr float[n]) for graph-replayable steps
+        self._dev = None  # (step_state int64[8], lr float[n]) for graph-replayable steps
 
     def _tensors(self):
         out = []
@@ -79,7 +79,8 @@ class FusedAdam:
                                           "(a parameter that started receiving grads later: use eager steps)")
             dev = ts[0][0].device
             if self._dev is None or self._dev[1].numel() != n:
-                self._dev = (torch.tensor([self.step_count, 0], dtype=torch.int64, device=dev),
+                # int64[8]: [0] steps taken, [1] the step's bias corrections; the rest is reserved (zeros)
+                self._dev = (torch.tensor([self.step_count, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int64, device=dev),
                              torch.tensor([t[3] for t in ts], dtype=torch.float32, device=dev))
             for p, m, v, _, _ in ts:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
