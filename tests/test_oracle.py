@@ -168,6 +168,37 @@ def test_weighted_bce_of_the_oracle_is_the_reference_function(reduction):
     assert torch.equal(ours, ref) and torch.equal(g_ours, g_ref)
 
 
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_import.available(), reason="needs /root/reference (authoring container)")
+@pytest.mark.parametrize("reduction,bs,down_rate,take", [("mean", 100, 3, 1001), ("sum", 4096, 1, 700), ("mean", 64, 2, 1024)])
+def test_importance_sweep_of_the_oracle_is_the_reference_loop(reduction, bs, down_rate, take):
+    """The chunking of cal_feature_importance (utils/incre_learning.py:15-40: head:tail:down_rate slices, a short last
+    chunk, the per-chunk 'mean') — the reference's own function, run unmodified on the oracle's octree / decoder objects
+    (it only duck-types them), against the oracle's restatement of the loop: bit-equal importance.  These are the cases
+    tests/test_gpu_parity.py::test_importance_sweep_chunking_matches_oracle holds the HIP sweep to."""
+    import copy
+
+    R = ref_import.install()
+    from oracle import shine_oracle as so
+
+    torch.set_num_threads(1)
+    fx = load_golden("ncd_reg_L3")
+    ocfg, oct_a, mlp_a = oracle_from_golden(fx)
+    _, oct_b, mlp_b = oracle_from_golden(fx)
+    ocfg = copy.copy(ocfg)
+    ocfg.loss_reduction = reduction
+    coord, label = fx["coord"][:take].contiguous(), fx["sdf_label"][:take].contiguous()
+    for o in (oct_a, oct_b):
+        for t in o.importance_weight:
+            t.zero_()
+    data = type("Pool", (), {"coord_pool": coord, "sdf_label_pool": label})()
+    decoder = type("Callable", (), {"__call__": lambda self, f: mlp_a.sdf(f)})()
+    R.cal_feature_importance(data, oct_a, decoder, so.sigma_sigmoid(ocfg), bs, down_rate, reduction)
+    so.importance_sweep(oct_b, mlp_b, coord, label, ocfg, bs, down_rate)
+    for a, b in zip(oct_a.importance_weight, oct_b.importance_weight):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0.0
+
+
 def test_node_ranks_are_a_z_order_over_all_levels():
     """FeatureOctree._host_node_ranks (the host statement of shine_tables_rank_nodes): ranks are a permutation, every
     node's descendants occupy a contiguous rank range that ends right before the node's own bucket."""
