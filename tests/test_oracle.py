@@ -199,6 +199,34 @@ def test_importance_sweep_of_the_oracle_is_the_reference_loop(reduction, bs, dow
         assert torch.equal(a, b) and float(a.abs().max()) > 0.0
 
 
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_import.available(), reason="needs /root/reference (authoring container)")
+@pytest.mark.parametrize("ratio", [1.0, 0.5])
+def test_optimizer_groups_are_the_reference_groups(ratio):
+    """setup_optimizer (utils/tools.py:57-83): decoder group with weight decay, then one group per feature level from the
+    leaf level up with lr *= lr_level_reduce_ratio, Adam(betas=(0.9, 0.99), eps=adam_eps).  The product's FusedAdam groups
+    and the oracle's torch.optim.Adam groups against the reference's own function (structure only: no step is taken)."""
+    R = ref_import.install()
+    from shine_mapping_amd.optim import setup_optimizer
+
+    fx = load_golden("ncd_reg_L3")
+    ocfg, oct_, mlp = oracle_from_golden(fx)
+    cfg = type("Cfg", (), dict(lr=0.01, weight_decay=1e-7, semantic_on=False, ray_loss=False, opt_adam=True, adam_eps=1e-15,
+                               lr_level_reduce_ratio=ratio, tree_level_feat=ocfg.tree_level_feat))()
+    feats = list(oct_.hier_features)
+    ref = R.setup_optimizer(cfg, feats, mlp.params(), None, None)
+    ours = setup_optimizer(cfg, feats, mlp.params())
+    orc = so.adam_param_groups(oct_, mlp, lr=0.01, weight_decay=1e-7, lr_level_reduce_ratio=ratio)
+    for opt in (ours, orc):
+        assert len(opt.param_groups) == len(ref.param_groups) == 1 + ocfg.tree_level_feat
+        for g, r in zip(opt.param_groups, ref.param_groups):
+            assert [id(p) for p in g["params"]] == [id(p) for p in r["params"]]
+            assert g["lr"] == r["lr"] and g.get("weight_decay", 0) == r.get("weight_decay", 0)
+    assert tuple(ours.betas) == tuple(ref.param_groups[0]["betas"]) == (0.9, 0.99)
+    assert ours.eps == ref.param_groups[0]["eps"] == 1e-15
+    assert all(tuple(g["betas"]) == (0.9, 0.99) and g["eps"] == 1e-15 for g in orc.param_groups)
+
+
 def test_node_ranks_are_a_z_order_over_all_levels():
     """FeatureOctree._host_node_ranks (the host statement of shine_tables_rank_nodes): ranks are a permutation, every
     node's descendants occupy a contiguous rank range that ends right before the node's own bucket."""
