@@ -227,6 +227,38 @@ def test_optimizer_groups_are_the_reference_groups(ratio):
     assert all(tuple(g["betas"]) == (0.9, 0.99) and g["eps"] == 1e-15 for g in orc.param_groups)
 
 
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_import.available(), reason="needs /root/reference (authoring container)")
+def test_product_decoder_and_losses_are_interchangeable_with_the_reference():
+    """Decoder (model/decoder.py:9-63): same state_dict keys and shapes as the reference's class, the reference's
+    pretrained/geo_decoder_8dim.pth loads strictly, and on CPU tensors (the composite branch) `sdf` equals the reference's
+    to the bit; sdf_bce_loss / get_gradient under the reference names (utils/loss.py:17-24, utils/tools.py:175-185)."""
+    import os
+
+    R = ref_import.install()
+    from model.decoder import Decoder as RefDecoder  # the reference's own module (ref_import put it on sys.path)
+
+    from shine_mapping_amd import Decoder, synth
+    from shine_mapping_amd.losses import get_gradient, sdf_bce_loss
+
+    cfg = synth.make_config("maicity", device="cpu")
+    torch.manual_seed(0)
+    ours, ref = Decoder(cfg), RefDecoder(cfg)
+    assert {k: tuple(v.shape) for k, v in ours.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    sd = torch.load(os.path.join(ref_import.REFERENCE_ROOT, "pretrained", "geo_decoder_8dim.pth"), map_location="cpu")
+    sd = sd.get("geo_decoder", sd) if isinstance(sd, dict) else sd
+    ours.load_state_dict(sd)
+    ref.load_state_dict(sd)
+    f = torch.randn(257, 8, requires_grad=True)
+    a, b = ours.sdf(f), ref.sdf(f)
+    assert torch.equal(a, b)
+    label, w = 0.05 * torch.randn(257), torch.rand(257) + 0.1
+    for weighted in (False, True):
+        for red in ("mean", "sum"):
+            assert torch.equal(sdf_bce_loss(a, label, 0.0123, w, weighted, red), R.sdf_bce_loss(b, label, 0.0123, w, weighted, red))
+    assert torch.equal(get_gradient(f, a), R.get_gradient(f, b))
+
+
 def test_node_ranks_are_a_z_order_over_all_levels():
     """FeatureOctree._host_node_ranks (the host statement of shine_tables_rank_nodes): ranks are a permutation, every
     node's descendants occupy a contiguous rank range that ends right before the node's own bucket."""
