@@ -8,7 +8,8 @@
 //       E_0..E_n ~ Exp(1) i.i.d. (exp1v below),  S_k = E_0 + .. + E_k,   U_(k) = S_k / S_n   (k < n)  are the sorted uniforms,
 //       idx_k = floor(U_(k) * pool_size).
 // As a multiset this is exactly `randint` (sampling with replacement); only the order differs, which no loss term
-// depends on.  Two launches (block sums, then regenerate + scan + scale), no atomics, no scratch array.
+// depends on.  Two launches (block sums, then regenerate + scan + scale) — one for draws of up to 16 blocks — no atomics
+// on the data path, no scratch array.
 #include "shine_internal.hpp"
 
 namespace shine {
