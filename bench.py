@@ -17,12 +17,22 @@ one frame.  With N>1 ranks (torch.distributed.run, one process per GPU, RCCL): O
 everywhere), rank r takes the r-th contiguous slice of P points (weak scaling), global normalisers come from the common
 draw, and the grads are exchanged dense (one flat all-reduce) or as touched rows only (--exchange).
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches this script under `torch.distributed.run` with N
+ranks on 127.0.0.1 (so `python bench.py --gpus 8` and the driver's explicit torchrun form run the same thing); fewer
+than N visible devices is an error, never a silent fall-back to one rank.
+
+The default invocation (no --workload, one GPU) also runs abbreviated legs of BASELINE configs 3 (`kitti`) and 4
+(`ncd-incre`) and embeds their lines under `configs`, so one driver-timed record covers configs 2, 3 and 4.
+
 One JSON line on rank 0: the driver's contract + `roofline` + `cpu_baseline` (DESIGN.md §5 explains every field).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,10 +42,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+for _p in (ROOT, os.path.join(ROOT, "tools")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
 # /opt/skills/guides/MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0      # spec (6290 measured copy)
 L2_PEAK_GBS = 34500.0      # aggregate L2
-MFMA_F32_PEAK_TF = 157.3   # exact-fp32 MFMA = vector rate
+MFMA_F32_PEAK_TF = 157.3   # exact-fp32 MFMA = the fp32 vector rate: 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+PEAK_CLOCK_GHZ = 2.4
+N_SIMD = 1024
+MFMA16_CYCLES = 32.0       # v_mfma_f32_16x16x4_f32 issue interval per SIMD (guide, per-instruction constants)
+# fp32-datapath cycles of one plain VALU wave-instruction.  The guide's SIMD-32 figure is 2; tools/ubench/mfma_valu_overlap
+# measures 2.3 with two waves per SIMD issuing independent v_fma_f32 (mode 4: 512 k instructions per SIMD in 0.545 ms at the
+# 2.165 GHz mode 0 implies) — profiles/r03_ubench_calibration.txt re-derives it with the PMC formula below.
+VALU_CYCLES = 2.3
 
 WORKLOADS = {
     "maicity": dict(preset="maicity", points=1 << 18, levels=4, frames=60, azimuths=450),
@@ -52,15 +73,30 @@ def algorithmic_bytes_per_point(levels: int, feat: int = 8) -> int:
 
 def pmc_record(workload, points, levels):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes (tools/collect_profiles.sh writes
-    profiles/r02_pmc_<workload>_<points>_L<levels>.json; bench.py cannot run the profiler on itself, so the figures are
-    only reported for a configuration they were measured on)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_%s_%d_L%d.json" % (workload, points, levels))
+    profiles/r03_pmc_<workload>_<points>_L<levels>.json; bench.py cannot run the profiler on itself).  A record is only
+    used while it describes the code that runs: tools/pmc_to_json.py stamps the sha256 of the kernel's machine code
+    (tools/kernel_hash.py) and the record is dropped — every PMC-derived field becomes null — when the loaded
+    libshine_hip.so holds a different kernel.  -> (record or None, reason)"""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_%s_%d_L%d.json" % (workload, points, levels))
     if not os.path.isfile(path):
-        return None
+        return None, "no counter file for this configuration"
     try:
-        return json.load(open(path))
-    except Exception:
-        return None
+        rec = json.load(open(path))
+    except Exception as e:
+        return None, "unreadable counter file (%s)" % e
+    try:
+        from kernel_hash import kernel_code_sha256
+        from shine_mapping_amd import _lib
+
+        want = rec.get("kernel_code_sha256")
+        name = rec.get("kernel") or ""
+        have = kernel_code_sha256(name, _lib.LIB_PATH) if name else None
+    except Exception as e:
+        return None, "kernel hash check failed (%s)" % e
+    if not want or want != have:
+        return None, "counter file describes another build of the kernel (sha256 %s..., loaded %s...)" % (
+            str(want)[:12], str(have)[:12])
+    return rec, "kernel code sha256 %s matches %s" % (want[:16], os.path.basename(path))
 
 
 def step_info(octree, cfg_eik, n):
@@ -108,14 +144,15 @@ def cpu_baseline(wl, seconds=12.0, n=4096, max_iters=400):
         return time.perf_counter() - t0, t1 - t0
 
     # torch's default (all host cores) is pathological for these small ops on a many-core host, so give the
-    # CPU path its best thread count: calibrate on one iteration each, then time with the winner.
-    best_t, best_threads = None, 1
+    # CPU path its best thread count: the MEDIAN of three iterations per candidate (after a warm-up), then time with the
+    # winner.  (One iteration per candidate let a single slow iteration pick the wrong count: the r02 figure moved 2x
+    # between boxes.)
+    calib = {}
     for threads in sorted({host_cores, min(host_cores, 32), min(host_cores, 8), 1}, reverse=True):
         torch.set_num_threads(threads)
         one_iteration()  # warm-up at this thread count
-        dt = one_iteration()[0]
-        if best_t is None or dt < best_t:
-            best_t, best_threads = dt, threads
+        calib[threads] = statistics.median(one_iteration()[0] for _ in range(3))
+    best_threads = min(calib, key=calib.get)
     torch.set_num_threads(best_threads)
     done, t_used, t_nopt, it = 0, 0.0, 0.0, 0
     while t_used < seconds and it < max_iters:
@@ -128,10 +165,11 @@ def cpu_baseline(wl, seconds=12.0, n=4096, max_iters=400):
         "value": done / max(t_used, 1e-9), "unit": "samples/s", "cores": best_threads, "kind": "port",
         "host_cores": host_cores, "value_without_adam": done / max(t_nopt, 1e-9),
         "ms_per_iteration": t_used / max(it, 1) * 1e3,
+        "thread_calibration_ms": {str(k): v * 1e3 for k, v in sorted(calib.items())},
         "sample": "%d whole iterations (query+decode+loss+backward+Adam step, the reference's timing(s)/total) of N=%d "
                   "(reference batch size) from the same pool/octree; oracle/shine_oracle.py train_step + "
-                  "torch.optim.Adam(betas=(0.9,0.99), eps=1e-15) on the reference's groups, torch %s CPU, thread count "
-                  "calibrated over {all,32,8,1}" % (it, n, torch.__version__),
+                  "torch.optim.Adam(betas=(0.9,0.99), eps=1e-15) on the reference's groups, torch %s CPU, thread count = "
+                  "best median of 3 iterations over {all,32,8,1}" % (it, n, torch.__version__),
     }
 
 
@@ -169,10 +207,10 @@ def gpu_iteration_n4096(wl, spool_seed, iters=300, n=4096):
             "what": "sorted draw + fused step + fused dense Adam, one HIP graph per iteration"}
 
 
-def run_incremental(args, dev):
+def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_seconds=12.0):
     """BASELINE config 4 (shine_incre.py:86-195): per frame {update -> optimiser re-creation -> pool plan -> 50 x
     {sorted draw, fused step (sum reduction, touched rows), regulariser, fused Adam} as ONE replayed HIP graph ->
-    importance sweep}.  A step = one frame."""
+    importance sweep}.  A step = one frame.  -> the bench record (dict)."""
     import numpy as np
 
     from shine_mapping_amd import Decoder, FeatureOctree, StepOptions, synth
@@ -182,11 +220,11 @@ def run_incremental(args, dev):
     from shine_mapping_amd.sampler import SortedPool
 
     spec = WORKLOADS["ncd-incre"]
-    bs = args.points or spec["points"]
+    bs = (args.points if args.workload == "ncd-incre" else 0) or spec["points"]
     iters = args.iters
-    n_frames = args.warmup + args.steps
+    n_frames = warmup + steps
     cfg = synth.make_config("ncd", device=dev, lr=0.01, opt_adam=True, adam_eps=1e-15, lr_level_reduce_ratio=1.0,
-                            tree_level_feat=args.levels or spec["levels"])
+                            tree_level_feat=(args.levels if args.workload == "ncd-incre" else 0) or spec["levels"])
     frames = list(synth.make_frames(cfg, frames=n_frames, beams=64, azimuths=spec["azimuths"], seed=42, device=dev))
     torch.manual_seed(0)
     octree, dec = FeatureOctree(cfg), Decoder(cfg)
@@ -195,8 +233,9 @@ def run_incremental(args, dev):
     loss = None
     torch.cuda.synchronize()
     t_start = None
+    pool = step = opt = None
     for fi, (coord, label, weight) in enumerate(frames):
-        if fi == args.warmup:
+        if fi == warmup:
             torch.cuda.synchronize()
             t_start = time.perf_counter()
         t0 = time.perf_counter()
@@ -223,24 +262,24 @@ def run_incremental(args, dev):
         t4 = time.perf_counter()
         split[fi] = (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)
     dt = time.perf_counter() - t_start
-    med = np.median(split[args.warmup:], axis=0) * 1e3
+    med = np.median(split[warmup:], axis=0) * 1e3
     wl = type("WL", (), {})()
     wl.cfg, wl.octree, wl.decoder = cfg, octree, dec
     wl.pool = type("P", (), {"coord": frames[-1][0], "sdf_label": frames[-1][1], "weight": frames[-1][2]})()
     out = {
-        "metric": "trained SDF samples/sec (fwd+bwd)", "value": args.steps * iters * bs / dt, "unit": "samples/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "metric": "trained SDF samples/sec (fwd+bwd)", "value": steps * iters * bs / dt, "unit": "samples/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": "ncd-like quad, incremental mode (shine_incre.py), N=%d, %d iterations/frame, sum reduction + "
-                        "regulariser lambda=%g, %d-level octree, fused Adam, importance sweep, device octree growth; a "
-                        "step = one frame" % (bs, iters, cfg.lambda_forget, cfg.tree_level_feat),
-            "points_per_iter_per_gpu": bs, "levels": cfg.tree_level_feat, "frames": args.steps,
+            "workload": "ncd-incre: ncd-like quad, incremental mode (shine_incre.py), N=%d, %d iterations/frame, sum "
+                        "reduction + regulariser lambda=%g, %d-level octree, fused Adam, importance sweep, device octree "
+                        "growth; a step = one frame" % (bs, iters, cfg.lambda_forget, cfg.tree_level_feat),
+            "points_per_iter_per_gpu": bs, "levels": cfg.tree_level_feat, "frames": steps,
             "samples_per_frame": int(np.mean([f[0].shape[0] for f in frames])),
             "corner_rows": [int(p.shape[0]) for p in octree.hier_features], "parallelism": "dp1",
             "launch": "%d iterations per hipgraph replay (loop.GraphedIteration), re-captured per frame" % args.unroll,
         },
-        "frames_per_s": args.steps / dt,
+        "frames_per_s": steps / dt,
         "per_frame_ms_median": {"update+ranks": med[0], "optimiser+pool plan": med[1],
                                 "%d iterations (incl. graph capture)" % iters: med[2], "importance sweep": med[3],
                                 "total": med[4]},
@@ -249,21 +288,32 @@ def run_incremental(args, dev):
     }
     # roofline of the dominant kernel at this batch size (HIP events around back-to-back launches of the fused kernel)
     out["roofline"] = kernel_roofline("ncd-incre", octree, dec, cfg, pool, bs, None)
-    if not args.no_cpu_baseline:
-        cb = cpu_baseline(wl, n=bs)
+    if with_cpu_baseline:
+        cb = cpu_baseline(wl, n=bs, seconds=cpu_seconds)
         out["cpu_baseline"] = cb
         gpu_iter = med[2] / iters * 1e-3
-        out["speedup_vs_cpu_baseline"] = (bs / gpu_iter) / cb["value"]
         out["like_for_like"] = {"n": bs, "gpu_samples_per_s_in_loop": bs / gpu_iter, "cpu_samples_per_s": cb["value"],
+                                "speedup": (bs / gpu_iter) / cb["value"],
                                 "note": "both sides: whole iterations incl. Adam at N=%d (the CPU side has no regulariser "
                                         "term: it would only make it slower)" % bs}
-    print(json.dumps(out))
+    return out
 
 
 def kernel_roofline(workload, octree, decoder, cfg, spool, points, n_surf_fn, launch_graph=True):
     """HIP events on the launch stream around R back-to-back launches of the fused kernel ALONE (kernel_variant bit
-    0x2000 skips the partial-sum reduction launch, so the bracket holds exactly what rocprofv3 reports for
-    shine::k_step_v1), averaged per launch; plus every roof it can be held against."""
+    0x2000 skips the partial-sum reduction launch, so the bracket holds exactly what rocprofv3 reports for the
+    shine::k_step_* kernel), averaged per launch, held against the roof that binds it.
+
+    `bound`/`achieved`/`peak`/`frac` describe ONE roof — the one with the larger fraction of
+      "mfma": the SIMD fp32 datapath.  Exact-fp32 MFMA runs on the same 64 FLOP/clk/SIMD lanes as the vector
+              instructions and the two do not overlap (tools/ubench/mfma_valu_overlap.hip), so the compute roof of this
+              kernel is the issued datapath work: (32 cycles x MFMAs + VALU_CYCLES x VALU instructions) per SIMD, expressed
+              in FLOP at 64 FLOP/clk against the 157.3 TFLOP/s peak.  The VALU count needs the PMC record; without one
+              only the MFMA share is counted (a lower bound).
+      "hbm":  SURVEY.md §8(d)'s algorithmic (no-reuse) bytes against 8 TB/s — binding only for maps beyond the
+              Infinity Cache (kitti-large); for cache-resident maps the figure is kept as `algorithmic` and does not
+              name the bound (it exceeds 1.0 there: the table is served by L1 / L2 / Infinity Cache).
+    """
     import copy
 
     from shine_mapping_amd import StepOptions, fused_train_step
@@ -311,105 +361,153 @@ def kernel_roofline(workload, octree, decoder, cfg, spool, points, n_surf_fn, la
     t = kernel_ms * 1e-3
     info = step_info(octree, eik, points)
     bpp = algorithmic_bytes_per_point(levels)
-    achieved = points * bpp / t / 1e9
+    alg_gbs = points * bpp / t / 1e9
     tiles = (points + info["tile_points"] - 1) // info["tile_points"]
+    mfma_per_tile = info["mfma_flop_per_tile"] / 2048.0  # 16x16x4: 2048 FLOP each
     issued_tf = tiles * info["mfma_flop_per_tile"] / t / 1e12
     useful_tf = points * info["useful_flop_per_point"] / t / 1e12
     rows = [int(p.shape[0]) for p in octree.hier_features]
-    pmc = pmc_record(workload, points, levels)
+    table_bytes = sum(rows) * 32
+    pmc, pmc_note = pmc_record(workload, points, levels)
+    ctr = pmc.get("counters_per_launch", {}) if pmc else {}
     traffic = float(pmc["hbm_bytes_per_launch"]) if pmc and pmc.get("hbm_bytes_per_launch") else None
     hbm_meas = None if traffic is None else traffic / t / 1e9 / HBM_PEAK_GBS
-    l2_frac = achieved / L2_PEAK_GBS
-    mfma_util = pmc.get("mfma_util") if pmc else None
-    # Exact-fp32 MFMA executes on the SIMD's fp32 FMA lanes and does NOT overlap VALU work of another wave
-    # (tools/ubench/mfma_valu_overlap.hip, profiles/r02_ubench_mfma_valu_overlap.txt: 0.473 ms MFMA-only, 0.307 ms
-    # VALU-only, 0.759 ms together), so the decoder's matrix work and the vector instructions share ONE datapath: its
-    # occupancy (PMC) is the compute roof of this kernel, not the MFMA rate alone.
-    dp_util = pmc.get("fp32_datapath_util") if pmc else None
-    fracs = {"hbm": hbm_meas if hbm_meas is not None else 0.0,
-             "mfma": dp_util if dp_util is not None else issued_tf / MFMA_F32_PEAK_TF}
-    bound = max(fracs, key=fracs.get)
-    return {
-        # SURVEY.md §8(d) figure: algorithmic (no-reuse) bytes / kernel time against the HBM peak
-        "bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_point": bpp,
-        "frac_of_measured_copy_6290GBs": achieved / 6290.0,
-        "compulsory_bytes": int(sum(rows) * 32 * 2 + 24 * points),
-        # the honest roofs: real HBM bytes (PMC) against HBM peak; the algorithmic bytes as if all served by L2; the
-        # matrix pipe (issued MFMA FLOP incl. padding, useful decoder FLOP, the PMC busy counter) and the fp32 datapath
-        # the MFMAs share with the vector instructions (PMC: MFMA busy + VALU issue cycles over SIMD-cycles)
-        "hbm_frac_measured": hbm_meas, "l2_frac": l2_frac,
-        "mfma_issued_tflops": issued_tf, "mfma_issued_frac": issued_tf / MFMA_F32_PEAK_TF,
-        "mfma_useful_frac": useful_tf / MFMA_F32_PEAK_TF, "mfma_util": mfma_util,
-        "fp32_datapath_util": dp_util,
-        "tcp_active_frac": pmc.get("tcp_active_frac") if pmc else None,
-        "regime": "bound by the SIMD fp32 datapath (MFMA + VALU, which do not overlap) plus exposed gather / atomic "
-                  "latency: hbm measured %s, L2 %.2f, MFMA issued %.2f, fp32 datapath %s; `bound` names the nearer of the "
-                  "two contract roofs" % ("n/a" if hbm_meas is None else "%.2f" % hbm_meas, l2_frac,
-                                          issued_tf / MFMA_F32_PEAK_TF, "n/a" if dp_util is None else "%.2f" % dp_util),
+    # issued fp32-datapath work of one launch, in cycles per SIMD-lane group and as FLOP at 64 FLOP/clk
+    n_mfma = tiles * mfma_per_tile
+    n_valu = None
+    if "SQ_INSTS_VALU" in ctr:  # SQ_INSTS_VALU counts the MFMAs too
+        n_valu = max(float(ctr["SQ_INSTS_VALU"]) - float(ctr.get("SQ_INSTS_MFMA", n_mfma)), 0.0)
+    dp_cycles = MFMA16_CYCLES * n_mfma + (VALU_CYCLES * n_valu if n_valu is not None else 0.0)
+    dp_tf = dp_cycles * 64.0 / t / 1e12
+    dp_frac = dp_tf / MFMA_F32_PEAK_TF
+    clk = pmc.get("kernel_shader_cycles") if pmc else None
+    in_cache = table_bytes * 2 < (200 << 20)  # features + grads inside the 256 MiB Infinity Cache
+    hbm_roof_frac = hbm_meas if hbm_meas is not None else (0.0 if in_cache else alg_gbs / HBM_PEAK_GBS)
+    if hbm_roof_frac > dp_frac and not in_cache:
+        roof = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS}
+    else:
+        roof = {"bound": "mfma", "achieved": dp_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": dp_frac}
+    roof.update({
+        "traffic": traffic, "kernel_ms": kernel_ms,
+        "what": ("issued fp32-datapath work (32 cycles x %.0f MFMA + %.1f cycles x %s VALU instructions per tile, 64 FLOP per "
+                 "cycle and SIMD) / kernel time, against the fp32 MFMA = vector peak" % (
+                     mfma_per_tile, VALU_CYCLES, "n/a" if n_valu is None else "%.0f" % (n_valu / tiles))
+                 if roof["bound"] == "mfma" else
+                 "SURVEY.md §8(d) algorithmic bytes / kernel time against the HBM peak (map beyond the Infinity Cache)"),
+        # SURVEY.md §8(d)'s no-reuse figure, always reported, never the bound of a cache-resident map
+        "algorithmic": {"bytes_per_point": bpp, "GBps": alg_gbs, "frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+                        "frac_of_measured_copy_6290GBs": alg_gbs / 6290.0,
+                        "note": "no-reuse model; > 1 means the table is served from L1 / L2 / Infinity Cache"},
+        "hbm": {"traffic_bytes": traffic, "frac": hbm_meas, "compulsory_bytes": int(sum(rows) * 32 * 2 + 24 * points),
+                "table_bytes": int(table_bytes),
+                "note": "PMC FETCH_SIZE x2 + WRITE_SIZE (guide §HBM; the x2 is calibrated for wide streams only, so the "
+                        "true read traffic of the 16-B row gathers lies between x1 and x2)"},
+        "datapath": {"mfma_per_tile": mfma_per_tile, "valu_per_tile": None if n_valu is None else n_valu / tiles,
+                     "valu_cycles_per_instruction": VALU_CYCLES, "frac": dp_frac,
+                     "frac_at_measured_clock": None if not clk else dp_cycles / (clk * N_SIMD),
+                     "mfma_issued_tflops": issued_tf, "mfma_issued_frac": issued_tf / MFMA_F32_PEAK_TF,
+                     "mfma_useful_frac": useful_tf / MFMA_F32_PEAK_TF, "mfma_busy_pmc": pmc.get("mfma_util") if pmc else None},
+        "wave_cycle_split": None if not pmc else pmc.get("wave_cycle_split"),
         "launch_geometry": {k: info[k] for k in ("workgroups", "waves", "tile_points", "lds_bytes")},
-        "pmc_source": None if pmc is None else pmc.get("source"),
-    }
+        "pmc": {"used": pmc is not None, "note": pmc_note, "source": None if pmc is None else pmc.get("source")},
+    })
+    return roof
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="default 200 (ncd-incre: 12 frames)")
-    ap.add_argument("--warmup", type=int, default=-1, help="default 20 (ncd-incre: 3 frames)")
-    ap.add_argument("--workload", default="maicity", choices=sorted(WORKLOADS))
-    ap.add_argument("--points", type=int, default=0, help="points per iteration per GPU (default: the workload's)")
-    ap.add_argument("--levels", type=int, default=0, help="tree_level_feat (default: the workload's)")
-    ap.add_argument("--frames", type=int, default=0, help="scans the synthetic map is built from")
-    ap.add_argument("--iters", type=int, default=50, help="ncd-incre: iterations per frame (config iters)")
-    ap.add_argument("--unroll", type=int, default=1,
-                    help="ncd-incre: iterations captured per HIP graph (measured: 1 -> 4.70 ms, 7 -> 5.15 ms, 12 -> 5.62 ms per "
-                         "frame of 50 iterations: the graph is re-captured every frame, and capturing 7x the nodes costs "
-                         "more than 43 saved replays)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "dense", "touched"],
-                    help="data-parallel gradient exchange: one flat all-reduce of the dense grads, or only the rows the "
-                         "global batch touched (auto: touched when the dense bucket exceeds 64 MB)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed (RCCL) and run the data-parallel code path even at world size 1")
-    args = ap.parse_args()
-    incre = args.workload == "ncd-incre"
-    if args.steps <= 0:
-        args.steps = 12 if incre else 200
-    if args.warmup < 0:
-        args.warmup = 3 if incre else 20
+# --------------------------------------------------------------------------------------------- launch / distributed
 
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def maybe_spawn(args, argv):
+    """`--gpus N` (N > 1) without a torchrun environment: become the launcher — N ranks of this script under
+    torch.distributed.run on 127.0.0.1, one per GPU — and exit with its return code.  Returns when this process is a
+    rank (or N == 1)."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if args.gpus > 1 and int(env_world) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node %d" % (
+                args.gpus, env_world, args.gpus))
+        return
+    if args.gpus <= 1:
+        return
+    if not args.launch_check:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible — refusing to fall back to fewer ranks" % (
+                args.gpus, have))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def init_ranks(args):
+    """-> (dist or None, world, rank, local_rank, backend).  RCCL (`nccl`) unless SHINE_BENCH_BACKEND says otherwise
+    (the CPU test of the launcher uses gloo)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
-        import torch.distributed as dist
+    if not use_dist:
+        return None, 1, 0, 0, None
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    import torch.distributed as dist
 
+    backend = os.environ.get("SHINE_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("bench.py: rank %d has no GPU (visible devices: %d)" % (rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
-        dist = None
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if use_dist else 0)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    if dist.get_world_size() != world:
+        raise SystemExit("bench.py: process group reports %d ranks, expected %d" % (dist.get_world_size(), world))
+    return dist, world, rank, local_rank, backend
 
-    if incre:
-        if world > 1:
-            raise SystemExit("ncd-incre is a single-GPU workload (BASELINE.json config 4)")
-        return run_incremental(args, dev)
 
+def launch_check(args, dist, world, rank, backend):
+    """--launch-check: prove the launcher and the rendezvous without touching a GPU (tests/test_bench_launch.py): every
+    rank contributes 1 to an all-reduce; rank 0 prints the contract fields that depend on the launch."""
+    t = torch.ones(1)
+    if dist is not None:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(t.item()),
+                          "world_size_reported": dist.get_world_size() if dist is not None else 1, "backend": backend,
+                          "config": {"parallelism": "dp%d" % world}, "gpus_requested": args.gpus}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------- batch workloads
+
+
+def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_baseline=True, with_like_for_like=True,
+              with_iteration=True, cpu_seconds=12.0):
+    """One batch-mode workload -> the bench record (dict on rank 0, None elsewhere)."""
     from shine_mapping_amd import StepOptions, fused_train_step, synth
     from shine_mapping_amd import dp as shine_dp
     from shine_mapping_amd.sampler import SortedPool
 
-    spec = WORKLOADS[args.workload]
-    levels = args.levels or spec["levels"]
-    points = args.points or spec["points"]
-    frames = args.frames or spec["frames"]
+    use_dist = dist is not None
+    own = workload == args.workload  # command-line overrides apply to the requested workload only
+    spec = WORKLOADS[workload]
+    levels = (args.levels if own else 0) or spec["levels"]
+    points = (args.points if own else 0) or spec["points"]
+    frames = (args.frames if own else 0) or spec["frames"]
     wl = synth.build_workload(spec["preset"], frames=frames, device=dev, seed=42, tree_level_feat=levels,
                               azimuths=spec["azimuths"])
     cfg, octree, decoder, pool = wl.cfg, wl.octree, wl.decoder, wl.pool
@@ -431,12 +529,15 @@ def main():
     if flags is not None:
         for f in flags:
             f.zero_()
+    idx_buf = torch.empty(points, dtype=torch.int32, device=dev)
 
-    def step_body(i):
-        """global sorted draw (+ clear grads in the same pass) -> fused step on this rank's slice (-> exchange)"""
+    def step_body():
+        """global sorted draw (+ clear grads in the same pass) -> fused step on this rank's slice (-> exchange).  The
+        draw's stream id lives in device memory (graph_safe), so every replay of the captured body draws a FRESH batch."""
         # this rank's contiguous slice of the ONE global sorted draw (same seed / draw count on every rank): only the
         # slice's indices are generated (shine_sample_sorted_slice), so the draw does not grow with the world size
-        idx = spool.draw(points, zero=reducer.flat, n_global=n_global, slice_begin=rank * points)
+        idx = spool.draw(points, out=idx_buf, zero=reducer.flat, graph_safe=True, n_global=n_global,
+                         slice_begin=rank * points)
         n_surf = None
         if opts.ekional_loss_on:  # global surface count: local count + an 8-byte all-reduce
             n_surf = (spool.weight[idx.long()] > 0).sum()
@@ -457,54 +558,55 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The loop body has no host sync and no allocation outside torch's allocator, so it is captured into HIP graphs and
-    # replayed (launch-bound inner loops belong in hipGraphs) — a ring of graphs, one per random stream id, since a
-    # replay would otherwise redraw the same batch.  With the dense exchange the RCCL all-reduce is captured with it; the
-    # touched-row exchange reads a row count on the host and stays eager.
+    # The loop body has no host sync and no allocation outside torch's allocator, so it is captured into ONE HIP graph
+    # and replayed (launch-bound inner loops belong in hipGraphs).  With the dense exchange the RCCL all-reduce is
+    # captured with it; the touched-row exchange reads a row count on the host and stays eager.
     launch = "eager"
-    graphs, graph_loss = [], []
-    ring = 8
+    graph, graph_loss = None, None
     if not args.no_graph and not (use_dist and exchange == "touched"):
         try:
-            for i in range(ring):
-                step_body(i)  # warm caches / allocate workspaces / RCCL channels outside capture
+            for _ in range(3):
+                step_body()  # warm caches / allocate workspaces / RCCL channels outside capture
             barrier()
-            for i in range(ring):
-                g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_):
-                    graph_loss.append(step_body(i))
-                graphs.append(g_)
-            launch = "hipgraph" + (" (all-reduce captured)" if use_dist else "")
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_loss = step_body()
+            launch = "hipgraph, fresh batch per replay" + (" (all-reduce captured)" if use_dist else "")
         except Exception as e:  # capture not possible on this stack: measure eagerly and say so
             print("graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
-            graphs, graph_loss, launch = [], [], "eager"
+            graph, graph_loss, launch = None, None, "eager"
             torch.cuda.synchronize()
 
-    def step(i):
-        if graphs:
-            graphs[i % len(graphs)].replay()
-            return graph_loss[i % len(graphs)]
-        return step_body(i)
+    def step():
+        if graph is not None:
+            graph.replay()
+            return graph_loss
+        return step_body()
 
-    for i in range(args.warmup):
-        step(i)
+    loss = None
+    for _ in range(warmup):
+        step()
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
+    for _ in range(steps):
+        loss = step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt, rank_ms = dt_local, None
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+        all_t = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_t, t)
+        per = [float(x) for x in all_t]
+        dt = max(per)
+        rank_ms = {"max": max(per) / steps * 1e3, "min": min(per) / steps * 1e3}
 
-    roof = kernel_roofline(args.workload, octree, decoder, cfg, spool, points, None, launch_graph=not args.no_graph)
+    roof = kernel_roofline(workload, octree, decoder, cfg, spool, points, None, launch_graph=not args.no_graph)
 
     # the reference's whole iteration (timing(s)/total, shine_batch.py:225): step + optimiser.  Fused Adam clears the
     # grads in the same pass.  Reported next to `value`, never instead of it.
     iter_ms = adam_ms = None
-    if not use_dist:
+    if not use_dist and with_iteration:
         from shine_mapping_amd.optim import setup_optimizer
 
         cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio = True, 1e-15, 1.0
@@ -512,20 +614,20 @@ def main():
             p.grad = torch.zeros_like(p)
         adam = setup_optimizer(cfg, list(octree.parameters()), decoder.fused_params())
 
-        def iteration(i):
+        def iteration():
             ix = spool.draw(points)
             ns = (spool.weight[ix.long()] > 0).sum() if opts.ekional_loss_on else None
             fused_train_step(octree, decoder, None, None, None, opts, n_surf=ns, pool=spool, idx=ix)
             adam.step(zero_grad=True)
 
-        for i in range(3):
-            iteration(i)
+        for _ in range(3):
+            iteration()
         torch.cuda.synchronize()
         ti = time.perf_counter()
-        for i in range(args.steps):
-            iteration(i)
+        for _ in range(steps):
+            iteration()
         torch.cuda.synchronize()
-        iter_ms = (time.perf_counter() - ti) / args.steps * 1e3
+        iter_ms = (time.perf_counter() - ti) / steps * 1e3
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
@@ -534,53 +636,138 @@ def main():
         torch.cuda.synchronize()
         adam_ms = e0.elapsed_time(e1) / 10
 
-    if rank == 0:
-        rows = [int(p.shape[0]) for p in octree.hier_features]
-        out = {
-            "metric": "trained SDF samples/sec (fwd+bwd)", "value": points * world * args.steps / dt,
-            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": "%s: %s, batch mode, %d points/iter/GPU, %d-level octree (levels %d..%d), F=8, decoder "
-                            "8-32-32-1, %s" % (args.workload,
-                                               {"maicity": "MaiCity-like 100 m street canyon",
-                                                "kitti": "KITTI-like 600 m polyline with two turns",
-                                                "kitti-large": "KITTI-like 8.4 km serpentine (map larger than the "
-                                                               "256 MiB Infinity Cache)"}[args.workload],
-                                               points, levels, cfg.tree_level_world - levels + 1, cfg.tree_level_world,
-                                               "BCE+eikonal" if cfg.ekional_loss_on else "BCE"),
-                "points_per_iter_per_gpu": points, "levels": levels, "frames": frames,
-                "pool_samples": int(pool.sdf_label.shape[0]), "corner_rows": rows,
-                "feature_table_bytes": int(sum(rows) * 32),
-                "batch_order": "sorted draw from the node-ordered pool (f-3); under DP one global draw, rank r takes the "
-                               "r-th contiguous slice",
-                "parallelism": "dp%d" % world, "launch": launch,
-                "grad_exchange": None if not use_dist else (
-                    "touched rows: %d rows, %.1f MB per step (dense bucket %.1f MB)" % (
-                        reducer.last_rows, reducer.last_bytes / 1e6, reducer.dense_bytes() / 1e6)
-                    if exchange == "touched" else "dense flat all-reduce, %.1f MB per step" % (reducer.dense_bytes() / 1e6)),
-            },
-            "roofline": roof,
-            "final_loss": float(loss),
-            "iteration_with_fused_adam": None if iter_ms is None else {
-                "ms_per_iteration": iter_ms, "samples_per_s": points / (iter_ms * 1e-3), "launch": "eager",
-                "dense_adam_ms": adam_ms,
-                "what": "sorted draw + fused step + fused dense Adam (also clears grads); reference timing(s)/total"},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl)
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank != 0:
+        return None
+    rows = [int(p.shape[0]) for p in octree.hier_features]
+    out = {
+        "metric": "trained SDF samples/sec (fwd+bwd)", "value": points * world * steps / dt,
+        "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "%s: %s, batch mode, %d points/iter/GPU, %d-level octree (levels %d..%d), F=8, decoder "
+                        "8-32-32-1, %s" % (workload,
+                                           {"maicity": "MaiCity-like 100 m street canyon",
+                                            "kitti": "KITTI-like 600 m polyline with two turns",
+                                            "kitti-large": "KITTI-like 8.4 km serpentine (map larger than the "
+                                                           "256 MiB Infinity Cache)"}[workload],
+                                           points, levels, cfg.tree_level_world - levels + 1, cfg.tree_level_world,
+                                           "BCE+eikonal" if cfg.ekional_loss_on else "BCE"),
+            "points_per_iter_per_gpu": points, "levels": levels, "frames": frames,
+            "pool_samples": int(pool.sdf_label.shape[0]), "corner_rows": rows,
+            "feature_table_bytes": int(sum(rows) * 32),
+            "batch_order": "sorted draw from the node-ordered pool (f-3); under DP one global draw, rank r takes the "
+                           "r-th contiguous slice",
+            "parallelism": "dp%d" % world, "launch": launch,
+            "world_size_reported": dist.get_world_size() if dist is not None else 1,
+            "rank_ms_per_step": rank_ms,
+            "grad_exchange": None if not use_dist else (
+                "touched rows: %d rows, %.1f MB per step (dense bucket %.1f MB)" % (
+                    reducer.last_rows, reducer.last_bytes / 1e6, reducer.dense_bytes() / 1e6)
+                if exchange == "touched" else "dense flat all-reduce, %.1f MB per step" % (reducer.dense_bytes() / 1e6)),
+        },
+        "roofline": roof,
+        "final_loss": float(loss),
+        "iteration_with_fused_adam": None if iter_ms is None else {
+            "ms_per_iteration": iter_ms, "samples_per_s": points / (iter_ms * 1e-3), "launch": "eager",
+            "dense_adam_ms": adam_ms,
+            "what": "sorted draw + fused step + fused dense Adam (also clears grads); reference timing(s)/total"},
+    }
+    if with_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(wl, seconds=cpu_seconds)
+        if with_like_for_like:
             try:
                 lf = gpu_iteration_n4096(wl, 77)
                 out["like_for_like"] = {
                     "n": 4096, "gpu": lf, "cpu_samples_per_s": out["cpu_baseline"]["value"],
                     "speedup": lf["samples_per_s"] / out["cpu_baseline"]["value"],
                     "note": "same N (4096, the reference's batch size) and the same iteration definition (incl. Adam) on "
-                            "both sides; `speedup_vs_cpu_baseline` divides the headline %d-point GPU step by this CPU figure"
+                            "both sides — the GPU/CPU ratio to quote; `value` is the %d-point step without the optimiser"
                             % points}
             except Exception as e:
                 out["like_for_like"] = {"error": str(e)}
+    return out
+
+
+def _release(dev):
+    import gc
+
+    gc.collect()
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="default 200 (ncd-incre: 12 frames)")
+    ap.add_argument("--warmup", type=int, default=-1, help="default 20 (ncd-incre: 3 frames)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: maicity (BASELINE config 2) plus abbreviated kitti and ncd-incre legs under `configs`")
+    ap.add_argument("--points", type=int, default=0, help="points per iteration per GPU (default: the workload's)")
+    ap.add_argument("--levels", type=int, default=0, help="tree_level_feat (default: the workload's)")
+    ap.add_argument("--frames", type=int, default=0, help="scans the synthetic map is built from")
+    ap.add_argument("--iters", type=int, default=50, help="ncd-incre: iterations per frame (config iters)")
+    ap.add_argument("--unroll", type=int, default=1,
+                    help="ncd-incre: iterations captured per HIP graph (measured: 1 -> 4.70 ms, 7 -> 5.15 ms, 12 -> 5.62 ms per "
+                         "frame of 50 iterations: the graph is re-captured every frame, and capturing 7x the nodes costs "
+                         "more than 43 saved replays)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="default invocation: skip the abbreviated kitti / ncd-incre legs")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "dense", "touched"],
+                    help="data-parallel gradient exchange: one flat all-reduce of the dense grads, or only the rows the "
+                         "global batch touched (auto: touched when the dense bucket exceeds 64 MB)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the data-parallel code path even at world size 1")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher / rendezvous check only (no GPU work): used by tests/test_bench_launch.py")
+    args = ap.parse_args()
+    maybe_spawn(args, sys.argv[1:])
+    dist, world, rank, local_rank, backend = init_ranks(args)
+    if args.launch_check:
+        return launch_check(args, dist, world, rank, backend)
+
+    default_run = args.workload is None
+    if default_run:
+        args.workload = "maicity"
+    incre = args.workload == "ncd-incre"
+    if args.steps <= 0:
+        args.steps = 12 if incre else 200
+    if args.warmup < 0:
+        args.warmup = 3 if incre else 20
+    if dist is None:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if dist is not None else 0)
+
+    if incre:
+        if world > 1:
+            raise SystemExit("ncd-incre is a single-GPU workload (BASELINE.json config 4)")
+        print(json.dumps(run_incremental(args, dev, args.steps, args.warmup,
+                                         with_cpu_baseline=not args.no_cpu_baseline)))
+        return
+
+    out = run_batch(args, args.workload, dist, world, rank, dev, args.steps, args.warmup,
+                    with_cpu_baseline=not args.no_cpu_baseline)
+    if default_run and world == 1 and not args.no_extra_configs:
+        # BASELINE configs 3 and 4 under the same driver clock: abbreviated legs (fewer steps, shorter CPU samples), each
+        # with its own roofline / cpu_baseline.  A failing leg is reported, never allowed to take the headline line down.
+        extra = {}
+        _release(dev)
+        try:
+            extra["kitti"] = run_batch(args, "kitti", None, 1, 0, dev, 60, 10, with_cpu_baseline=not args.no_cpu_baseline,
+                                       with_like_for_like=False, with_iteration=False, cpu_seconds=6.0)
+        except Exception as e:
+            extra["kitti"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        _release(dev)
+        try:
+            extra["ncd-incre"] = run_incremental(args, dev, 10, 3, with_cpu_baseline=not args.no_cpu_baseline,
+                                                 cpu_seconds=6.0)
+        except Exception as e:
+            extra["ncd-incre"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["configs"] = extra
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

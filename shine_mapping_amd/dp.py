@@ -71,7 +71,16 @@ class GradReducer:
         return t
 
 
-_WS = {}
+class _Scratch(dict):
+    """Module-level scratch registry: buffers under short keys, the byte counts the library asked for under key + (sizes...).
+    Only the LAST size query per buffer is remembered (clear_sizes), so the registry does not grow with the run."""
+
+    def clear_sizes(self, key):
+        for k in [k for k in self if len(k) > len(key) and k[:len(key)] == key]:
+            del self[k]
+
+
+_WS = _Scratch()
 
 
 def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
@@ -83,15 +92,19 @@ def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
     stream = _lib.current_stream_handle()
     wide = sum(cfg.sort_bits) > 32 or min(cfg.sort_bits) <= 0
     # rocPRIM's scratch depends on the number of key bits (onesweep passes), which grows with the map's bounding box
-    key = (str(coord.device), n, wide, tuple(cfg.sort_bits))
-    ent = _WS.get(key)
-    if ent is None:  # size query once per (device, batch size, key bits); the buffer is reused every iteration
-        need = C.c_size_t(0)
-        _lib.check(lib.shine_morton_sort(C.byref(cfg), None, n, None, None, C.byref(need), stream),
+    key = ("sort", str(coord.device))
+    skey = key + (n, wide, tuple(cfg.sort_bits))
+    sized = _WS.get(skey)
+    if sized is None:  # size query once per (batch size, key bits); ONE grow-only buffer per device behind it
+        q = C.c_size_t(0)
+        _lib.check(lib.shine_morton_sort(C.byref(cfg), None, n, None, None, C.byref(q), stream),
                    "shine_morton_sort")
-        ent = (torch.empty(int(need.value), dtype=torch.uint8, device=coord.device), int(need.value))
-        _WS[key] = ent
-    ws, need = ent[0], C.c_size_t(ent[1])
+        _WS.clear_sizes(key)
+        sized = _WS[skey] = int(q.value)
+    ent = _WS.get(key)
+    if ent is None or ent.numel() < sized:
+        ent = _WS[key] = torch.empty(max(sized + sized // 4, 1), dtype=torch.uint8, device=coord.device)
+    ws, need = ent, C.c_size_t(sized)
     perm = torch.empty(n, dtype=torch.int32, device=coord.device)
     _lib.check(
         lib.shine_morton_sort(C.byref(cfg), coord.data_ptr(), n, perm.data_ptr(), ws.data_ptr(), C.byref(need), stream),
@@ -114,15 +127,21 @@ def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None, _debug_va
     cfg = octree.step_config(kernel_variant=_debug_variant)
     lib = _lib.lib()
     stream = _lib.current_stream_handle()
-    key = ("plan", str(coord.device), n, octree._n_buckets)
-    ent = _WS.get(key)
-    if ent is None:
-        need = C.c_size_t(0)
-        _lib.check(lib.shine_plan_batch(t.handle, C.byref(cfg), None, n, None, None, None, 0, None, C.byref(need),
+    # ONE grow-only scratch buffer per device.  plan_batch never runs inside a captured graph, so replacing the buffer by a
+    # bigger one is safe; a cache keyed by (n, n_buckets) would pin another 20 B per sample for every distinct pool size of
+    # an incremental-mapping run (every frame's pool and every octree growth is a new key).
+    key = ("plan", str(coord.device))
+    sized = _WS.get(key + (n, octree._n_buckets))
+    if sized is None:
+        q = C.c_size_t(0)
+        _lib.check(lib.shine_plan_batch(t.handle, C.byref(cfg), None, n, None, None, None, 0, None, C.byref(q),
                                         stream), "shine_plan_batch")
-        ent = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=coord.device), int(need.value))
-        _WS[key] = ent
-    ws, need = ent[0], C.c_size_t(ent[1])
+        _WS.clear_sizes(key)
+        sized = _WS[key + (n, octree._n_buckets)] = int(q.value)
+    ent = _WS.get(key)
+    if ent is None or ent.numel() < sized:
+        ent = _WS[key] = torch.empty(max(sized + sized // 4, 1), dtype=torch.uint8, device=coord.device)
+    ws, need = ent, C.c_size_t(ent.numel())
     if out is not None:  # caller-owned (e.g. double-buffered) outputs
         perm, slots = out
         assert perm.dtype == torch.int32 and perm.numel() == n and slots.dtype == torch.int32 and slots.numel() == n * L

@@ -51,6 +51,10 @@ class SortedPool:
         self.slots = slots  # already in pool (= visiting) order
         self.size = int(coord.shape[0])
         self.tables_epoch = self.octree._tables_epoch
+        # sampler scratch of other pool sizes is dead weight (a graph captured for the old pool is invalid anyway: the
+        # tables epoch moved); without this an object rebuilt every frame pins one buffer per distinct frame size
+        for k in [k for k in self._ws if k[1] != self.size]:
+            del self._ws[k]
 
     def draw(self, n, out=None, zero=None, graph_safe=False, n_global=None, slice_begin=0):
         """n sorted i.i.d. uniform sample indices (int32, device).  `zero`: optional contiguous float tensor cleared in

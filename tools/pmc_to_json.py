@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Per-launch PMC figures of one kernel from several rocprofv3 --pmc runs (one db directory per counter group) -> the
-JSON record bench.py reads (profiles/r02_pmc_<workload>_<points>_L<levels>.json).
+JSON record bench.py reads (profiles/r03_pmc_<workload>_<points>_L<levels>.json).
 
-    python tools/pmc_to_json.py --kernel k_step_v1 --out profiles/r02_pmc_maicity_262144_L4.json \
+    python tools/pmc_to_json.py --kernel k_step_v --out profiles/r03_pmc_maicity_262144_L4.json \
         --meta workload=maicity points=262144 levels=4 -- /tmp/p_FETCH /tmp/p_WRITE /tmp/p_sq /tmp/p_mfma
 
 Every counter is summed over its instances (XCDs / SEs) per dispatch, then averaged over the dispatches of the kernel
@@ -14,7 +14,10 @@ import glob
 import json
 import os
 import sqlite3
+import sys
 from collections import Counter, defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def read_db(root, pat):
@@ -59,6 +62,9 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--meta", nargs="*", default=[])
     ap.add_argument("--command", default="")
+    ap.add_argument("--lib", default=None, help="library whose kernel code is hashed into the record (default: the in-tree .so)")
+    ap.add_argument("--valu-cycles", type=float, default=2.3,
+                    help="fp32-datapath cycles per plain VALU wave-instruction (profiles/r03_ubench_calibration.txt)")
     ap.add_argument("dirs", nargs="+")
     a = ap.parse_args()
     counters, launches, name, dur_us, grid, instances = {}, {}, None, {}, None, {}
@@ -74,6 +80,22 @@ def main():
            "kernel_us_under_profiler": dur_us, "command": a.command,
            "source": "rocprofv3 --kernel-trace --pmc <group> (one run per group), tools/collect_profiles.sh + "
                      "tools/pmc_to_json.py"}
+    # tie the counters to the code they were collected on: bench.py drops the record when the loaded library holds
+    # another build of this kernel (tools/kernel_hash.py)
+    try:
+        from kernel_hash import kernel_code_sha256
+
+        rec["kernel_code_sha256"] = kernel_code_sha256(name, a.lib)
+    except Exception as e:  # pragma: no cover
+        rec["kernel_code_sha256"] = None
+        rec["kernel_code_sha256_error"] = str(e)
+    if counters.get("SQ_WAVE_CYCLES", 0) > 0:
+        wc = counters["SQ_WAVE_CYCLES"]
+        rec["wave_cycle_split"] = {
+            "waiting_at_waitcnt_or_barrier": counters.get("SQ_WAIT_ANY", 0.0) / wc,
+            "issue_stalled": counters.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+            "issuing": counters.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
+            "formula": "SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES (disjoint, guide §PMC slots)"}
     for kv in a.meta:
         k, v = kv.split("=", 1)
         rec[k] = int(v) if v.isdigit() else v
@@ -94,20 +116,17 @@ def main():
         rec["mfma_util"] = busy / (kcycles * n_simd)
         rec["mfma_util_formula"] = ("SQ_VALU_MFMA_BUSY_CYCLES / ((SQ_BUSY_CYCLES / its instances) * 1024 SIMDs): the fraction "
                                     "of SIMD-cycles the matrix pipe is busy")
-        if "SQ_ACTIVE_INST_VALU" in counters:
-            # SQ_ACTIVE_INST_* count quad-cycles per wave (MI355X_MICROARCH.md); VALU issue slots include the MFMAs
-            # (~1 quad each), whose execution time is the busy counter above.  Exact-fp32 MFMA runs on the SIMD's
-            # fp32 FMA lanes and does not overlap VALU work of another wave (tools/ubench/mfma_valu_overlap.hip),
-            # so the two add up to the occupancy of ONE datapath.
-            valu = 4.0 * (counters["SQ_ACTIVE_INST_VALU"] - counters.get("SQ_INSTS_MFMA", 0.0))
+        if "SQ_INSTS_VALU" in counters:
+            # Exact-fp32 MFMA runs on the SIMD's fp32 FMA lanes and does not overlap VALU work of another wave
+            # (tools/ubench/mfma_valu_overlap.hip), so MFMA busy cycles and the plain VALU instructions' cycles add up to
+            # the occupancy of ONE datapath.  Cycles per VALU instruction: calibrated on the micro-benchmark
+            # (tools/calibrate_datapath.py -> profiles/r03_ubench_calibration.txt), not the 4 of the r02 record.
+            valu = a.valu_cycles * (counters["SQ_INSTS_VALU"] - counters.get("SQ_INSTS_MFMA", 0.0))
             rec["valu_busy_cycles_per_launch"] = valu
+            rec["valu_cycles_per_instruction"] = a.valu_cycles
             rec["fp32_datapath_util"] = (busy + valu) / (kcycles * n_simd)
-            rec["fp32_datapath_util_formula"] = ("(SQ_VALU_MFMA_BUSY_CYCLES + 4 * (SQ_ACTIVE_INST_VALU - SQ_INSTS_MFMA)) / "
-                                                 "(kernel shader cycles * 1024 SIMDs)")
-    if "TCP_GATE_EN1_sum" in counters and "kernel_shader_cycles" in rec:
-        # the *_sum counters are rocprofv3 derived metrics, already summed over the 256 TCPs (one instance in the db)
-        rec["tcp_active_frac"] = counters["TCP_GATE_EN1_sum"] / 256.0 / rec["kernel_shader_cycles"]
-        rec["tcp_active_frac_formula"] = "TCP_GATE_EN1_sum / 256 CUs / kernel shader cycles (clock-enabled cycles of the vector L1)"
+            rec["fp32_datapath_util_formula"] = ("(SQ_VALU_MFMA_BUSY_CYCLES + %.2f * (SQ_INSTS_VALU - SQ_INSTS_MFMA)) / "
+                                                 "(kernel shader cycles * 1024 SIMDs)" % a.valu_cycles)
     json.dump(rec, open(a.out, "w"), indent=1)
     print(json.dumps(rec, indent=1))
 

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(512, 2) void k(int mode, int iters, float* out) {
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const int only = argc > 1 ? atoi(argv[1]) : -1;  // one mode per process: the PMC calibration runs (tools/gpu_calibrate.sh)
   float* out;
   hipMalloc(&out, 256 * 512 * sizeof(float));
   hipEvent_t e0, e1;
@@ -55,6 +56,7 @@ int main() {
   const int iters = 4000;  // per wave: 8 x 4000 MFMAs (32 cycles each) or 64 x 4000 v_fma
   for (int rep = 0; rep < 2; ++rep)
     for (int mode = 0; mode < 5; ++mode) {
+      if (only >= 0 && mode != only) continue;
       hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, iters, out);
       hipDeviceSynchronize();
       hipEventRecord(e0);
