@@ -47,6 +47,12 @@ extern "C" int shine_train_step_v3(const shine_tables*, const shine_step_config*
                                    const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
                                    double*, unsigned char* const*, void*, size_t, void*);
 
+extern "C" int shine_train_step_v5(const shine_tables*, const shine_step_config*, const float*, const float*,
+                                   const float*, const int32_t*, const int32_t*, const int64_t*, int64_t,
+                                   const float* const*,
+                                   const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
+                                   double*, unsigned char* const*, void*, size_t, void*);
+
 namespace shine {
 // which configurations the 16-point-tile kernel serves when the caller leaves the choice to the library
 // (kernel_variant 0): BCE steps (the eikonal build stays on the 32-point kernel).  SHINE_KERNEL=v1 forces the 32-point one.
@@ -68,8 +74,20 @@ bool v3_serves(const shine_step_config* cfg, bool planned) {
   }();
   const int variant = cfg->kernel_variant & 0xff;
   if (!planned || cfg->n_levels > LCAP) return false;
-  if (variant == 4) return true;
+  if (variant == 4 || variant == 5) return true;
   return variant == 0 && !force_v1;
+}
+// the role-specialised form of the same kernel (shine_step_v5.hip): planned / pool batches large enough to fill its
+// per-SIMD pipelines (SHINE_V5_MIN_POINTS, default below; kernel_variant 5 forces it, 4 forces shine_step_v3.hip)
+bool v5_serves(const shine_step_config* cfg, bool planned, long long n) {
+  static const long long min_points = []() {
+    const char* e = getenv("SHINE_V5_MIN_POINTS");
+    return e ? atoll(e) : (1ll << 62);
+  }();
+  const int variant = cfg->kernel_variant & 0xff;
+  if (!planned || cfg->n_levels > LCAP) return false;
+  if (variant == 5) return true;
+  return variant == 0 && n >= min_points;
 }
 }  // namespace shine
 
@@ -115,6 +133,12 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
   // 16-point tiles: planned / pool batches (BCE or BCE + eikonal) run on the lane = (point, level) kernel
   // (shine_step_v3.hip); BCE batches without a plan (in-kernel probing) on shine_step_v2.hip; everything else that has
   // <= 4 levels on the 32-point kernel (shine_step_v1.hip).  kernel_variant 2 / 3 / 4 force v1 / v2 / v3.
+  if (variant == 5 && (!slots || cfg->n_levels > 4))
+    return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 5 needs a planned batch (slots) and <= 4 levels");
+  if (!force_v0 && workspace && workspace_bytes >= v2_need && shine::v5_serves(cfg, slots != nullptr, n))
+    return shine_train_step_v5(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
+                               grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,
+                               stream);
   if (!force_v0 && workspace && workspace_bytes >= v2_need && shine::v3_serves(cfg, slots != nullptr))
     return shine_train_step_v3(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
                                grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes,

@@ -97,9 +97,12 @@ V2Geometry v2_geometry(long long n);
 long long v2_lds_bytes(int wg_waves);
 V2Geometry v3_geometry(long long n);  // shine_step_v3.hip: tiles dealt evenly to every resident wave slot
 long long v3_lds_bytes(int wg_waves);
+V2Geometry v5_geometry(long long n, bool eik);  // shine_step_v5.hip: 16-wave workgroups of 4 role-specialised pipelines
+long long v5_lds_bytes(bool eik);
 // true when the 16-point-tile kernel serves this configuration (and is the faster one): see shine_api.hip
 bool v2_serves(const shine_step_config* cfg);
 bool v3_serves(const shine_step_config* cfg, bool planned);
+bool v5_serves(const shine_step_config* cfg, bool planned, long long n);
 
 // measurement aid (shine_debug_set_profile_buffer): per-wave phase cycle counters or null
 extern long long* g_prof_buffer;

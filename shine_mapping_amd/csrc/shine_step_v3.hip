@@ -23,23 +23,10 @@
 //   * decoder / weight grads / scatter / flush: as in v2 (the scatter prefetches its LDS operands one level ahead).
 // Planned or pool batches only (the hash slots come with the batch); a batch without a plan runs on k_step_v2 / v1, or is
 // planned first by the Python layer (StepOptions.auto_plan_min).
-#include "shine_step_common.hpp"
+#include "shine_tile16.hpp"
 
 namespace shine {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int V3_TP = 16;                      // points per tile
-constexpr int V3_WP = 16;                      // pitch of the [corner][point] staging rows
-constexpr int V3_TT = 20;                      // transpose tile pitch (floats, 16-B aligned rows)
-constexpr int V3_DFP = 20;                     // pitch of the [feature][point] rows
-constexpr int V3_IDS = LCAP * 8 * V3_WP;       // ids [LCAP][8][16] int32
-constexpr int V3_W = LCAP * 8 * V3_WP;         // w   [LCAP][8][16]
-constexpr int V3_R2 = 2 * 32 * V3_TT;          // two transpose tiles [32][20]; second life: df
-constexpr int V3_DF = 0, V3_DL = 8 * V3_DFP;    // df / J rows [8][20], then delta[16] (eikonal build)
-constexpr int V3_WAVE_FLOATS = V3_IDS + V3_W + V3_R2;  // 2304 floats = 9216 B per wave
-constexpr int V3_SLOT = 68;                    // pitch of one node's 8 x 8 corner rows in LDS (floats): conflict-free b128 reads
-constexpr int V3_OPA1 = 0, V3_OPA2 = 4 * 64, V3_OPA2T = 20 * 64, V3_OPA1T = 36 * 64, V3_OPTOTAL = 44 * 64;
 #ifndef SHINE_V3_BIG
 #define SHINE_V3_BIG 8
 #endif
@@ -60,39 +47,6 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 #ifndef SHINE_V3_ABL  // measurement builds only (tools/mk_variant.py): 1 no atomics, 2 no weight-grad phase, 4 no scatter
 #define SHINE_V3_ABL 0  // phase, 8 no row gathers; the product build compiles none of it
 #endif
-
-static_assert(V3_DFP == V3_TT, "f_wr addresses both the transpose rows and the df rows");
-static_assert(PART_STRIDE <= V3_WAVE_FLOATS, "each wave's partial vector aliases its staging region at the end");
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ f32x4 zero4() {
-  f32x4 z;
-  z[0] = z[1] = z[2] = z[3] = 0.f;
-  return z;
-}
-
-// sigmoid on the hardware transcendental units: 1 / (1 + 2^(-x log2 e)); exp2 overflow -> rcp(inf) = 0, as it should
-__device__ __forceinline__ float fast_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
-}
-
-// x + (the value lane ^ 32 holds in y)  for lanes < 32,   y + (the value lane ^ 32 holds in x)  for lanes >= 32:
-// v_permlane32_swap exchanges x[32..63] with y[0..31], after which both registers hold one own and one partner value.
-__device__ __forceinline__ float xsum32(float x, float y) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// the same across lane ^ 16 (v_permlane16_swap: x rows 1, 3 <-> y rows 0, 2)
-__device__ __forceinline__ float xsum16(float x, float y) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// lane 15 of each 16-lane row to every lane of the row (DPP row_newbcast:15), lane i-1 of the row to lane i (row_shr:1)
-__device__ __forceinline__ int row_last(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xF, 0xF, false); }
-__device__ __forceinline__ int row_prev(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false); }
 
 template <int L, int WAVES, bool EIK, bool PROF>
 __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_v3(V1Args a) {

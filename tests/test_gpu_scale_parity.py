@@ -26,7 +26,9 @@ def _workload(kind, levels, frames=8, seed=21, **over):
 # BASELINE.json config 2 (2^18 points, 4-level octree, BCE) and config 3 (2^20 points, L=3, eikonal), each with a ragged
 # tail (+37 / +1) so that the last tile is partial.  Reference: shine_batch.py:115-209.
 @pytest.mark.parametrize("kind,levels,n,variant", [("maicity", 4, (1 << 18) + 37, 0), ("maicity", 4, (1 << 18) + 37, 2),
-                                                   ("maicity", 3, (1 << 16) + 5, 3), ("kitti", 3, (1 << 20) + 1, 0)])
+                                                   ("maicity", 3, (1 << 16) + 5, 3), ("kitti", 3, (1 << 20) + 1, 0),
+                                                   ("maicity", 4, (1 << 18) + 37, 4), ("kitti", 3, (1 << 20) + 1, 4),
+                                                   ("maicity", 4, (1 << 18) + 37, 5), ("kitti", 3, (1 << 20) + 1, 5)])
 def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n, variant):
     from oracle import shine_oracle as so
     from shine_mapping_amd import StepOptions, fused_train_step
@@ -150,7 +152,8 @@ def test_sharded_hip_steps_sum_to_the_full_batch_golden(name, shards):
         assert rel_err(p.grad, r) <= TOL
 
 
-def test_pool_mode_regulariser_marks_the_drawn_rows():
+@pytest.mark.parametrize("variant", [4, 5])
+def test_pool_mode_regulariser_marks_the_drawn_rows(variant):
     """FeatureOctree.cal_regularization (model/feature_octree.py:246-255) after a POOL-mode step: the touched-row flags
     must be those of the drawn batch (the pool's slot table is indexed by sample id), so value and gradient of the
     regulariser equal the reference composite on pool.get_batch(idx)."""
@@ -166,7 +169,9 @@ def test_pool_mode_regulariser_marks_the_drawn_rows():
     sp.draw(300)
     idx = sp.draw(300)  # a sparse draw: the first 300 pool entries touch other rows than these
     touched = touched_flags(octree)
-    fused_train_step(octree, dec, None, None, None, step_options(fx), pool=sp, idx=idx, touched=touched)
+    sopts = step_options(fx)
+    sopts.kernel_variant = variant  # 4: k_mark_touched pass in front of the step; 5: flags set by the scatter waves
+    fused_train_step(octree, dec, None, None, None, sopts, pool=sp, idx=idx, touched=touched)
     L = cfg.tree_level_feat
     c, _, _ = sp.get_batch(idx)
     hidx = octree.get_indices(c.contiguous())
@@ -406,7 +411,7 @@ def test_ragged_batches_on_both_mfma_kernels(n, variant):
         assert rel_err(p.grad, r) <= TOL
 
 
-@pytest.mark.parametrize("mode", ["planned", "plain", "pool"])
+@pytest.mark.parametrize("mode", ["planned", "plain", "pool", "planned-v5", "pool-v5"])
 @pytest.mark.parametrize("name", ["maicity_bce_L4", "kitti_eik_L3"])
 def test_weighted_bce_matches_oracle(name, mode):
     """loss_weight_on (utils/loss.py:18-19, shine_batch.py:172-174): BCEWithLogitsLoss(weight=|weight|).  Planned and pool
@@ -424,6 +429,8 @@ def test_weighted_bce_matches_oracle(name, mode):
     w = fx["weight"] * (0.25 + 1.5 * torch.rand_like(fx["weight"]))  # keeps the sign (surface / free space), varies |w|
     opts = step_options(fx)
     opts.loss_weight_on = True
+    if mode.endswith("-v5"):
+        mode, opts.kernel_variant = mode[:-3], 5
     if mode == "pool":
         octree._require_tables(with_ranks=True)
         sp = SortedPool(octree, c.cuda(), l.cuda(), w.cuda(), seed=4)
@@ -445,12 +452,14 @@ def test_weighted_bce_matches_oracle(name, mode):
         assert rel_err(p.grad, r) <= TOL
 
 
+@pytest.mark.parametrize("variant", [4, 5])
 @pytest.mark.parametrize("levels", [1, 2, 3, 4])
 @pytest.mark.parametrize("eik", [False, True])
 @pytest.mark.parametrize("n", [1, 17, 300, 4099, 40000])
-def test_planned_ragged_batches_on_the_point_level_kernel(n, eik, levels):
-    """kernel_variant 4 (shine_step_v3.hip) on planned batches of awkward sizes and every level count: partial tiles,
-    waves without tiles, the 4-wave and the full-chip workgroup shapes, lanes of levels the tree does not have."""
+def test_planned_ragged_batches_on_the_point_level_kernel(n, eik, levels, variant):
+    """kernel_variant 4 (shine_step_v3.hip: one wave per tile) and 5 (shine_step_v5.hip: role-specialised waves) on planned
+    batches of awkward sizes and every level count: partial tiles, waves / pipelines without tiles, every workgroup shape,
+    lanes of levels the tree does not have."""
     from oracle import shine_oracle as so
     from shine_mapping_amd import Decoder, FeatureOctree, StepOptions, dp, fused_train_step, synth
 
@@ -469,7 +478,7 @@ def test_planned_ragged_batches_on_the_point_level_kernel(n, eik, levels):
     c, l, w = pc[sel].contiguous(), pl[sel].contiguous(), pw[sel].contiguous()
     w[0] = w[0].abs().clamp_min(1e-3)  # at least one surface sample: the reference's eikonal mean of an empty set is NaN
     perm, slots = dp.plan_batch(octree, c)
-    opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=eik, weight_e=cfg.weight_e, kernel_variant=4)
+    opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=eik, weight_e=cfg.weight_e, kernel_variant=variant)
     loss, pred, gx = fused_train_step(octree, dec, c, l, w, opts, want_grad_x=True, perm=perm, slots=slots)
     torch.cuda.synchronize()
     ocfg, oct_, mlp = oracle_from_product(octree, dec, cfg)
