@@ -44,6 +44,9 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 #ifndef SHINE_V3_PREDSCAT  // measurement builds only: branch-free run-length scatter (see phase 6)
 #define SHINE_V3_PREDSCAT 0
 #endif
+#ifndef SHINE_V3_PREFIX  // 1: prefix-sum scatter (scatter_level_prefix, shine_tile16.hpp) instead of the serial walk
+#define SHINE_V3_PREFIX 0
+#endif
 #ifndef SHINE_V3_ABL  // measurement builds only (tools/mk_variant.py): 1 no atomics, 2 no weight-grad phase, 4 no scatter
 #define SHINE_V3_ABL 0  // phase, 8 no row gathers; the product build compiles none of it
 #endif
@@ -755,7 +758,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
           float racc = run_acc[s];
           const unsigned int cm = (unsigned int)(chg64 >> (16 * s)) & 0xFFFFu;
           const unsigned int hm = (unsigned int)(hit64 >> (16 * s)) & 0xFFFFu;
-#if SHINE_V3_PREDSCAT
+#if SHINE_V3_PREFIX
+          {
+            f32x16 wv, dv;
+            i32x16 iv;
+#pragma unroll
+            for (int p2 = 0; p2 < V3_TP; ++p2) wv[p2] = wr[p2], dv[p2] = dfr[p2], iv[p2] = idr[p2];
+            scatter_level_prefix<!(SHINE_V3_ABL & 1)>(wv, iv, dv, cm, hm, sq, gbase, SHINE_V3_MARK ? a.touched[s] : nullptr, rid, rhit,
+                                                      racc);
+          }
+#elif SHINE_V3_PREDSCAT
           // measurement variant (tools/mk_variant.py -DSHINE_V3_PREDSCAT=1): the walk without branches — the run-start
           // decision selects the exec mask of the atomic (SCC -> s_cselect_b64 exec) and the resets are v_cndmask
           unsigned long long rmask = rhit ? ~0ull : 0ull;

@@ -45,12 +45,24 @@ constexpr int S5_BCE_FLOATS = S5_META + 64;
 constexpr int S5_AX = S5_BCE_FLOATS;
 constexpr int S5_A2 = S5_AX + 6 * 64;
 constexpr int S5_EIK_FLOATS = S5_A2 + 6 * 64;
-#ifndef SHINE_V5_GB
-#define SHINE_V5_GB 4
+#ifndef SHINE_V5_SLEEP  // s_sleep argument between two polls of a hand-off counter (units of 64 clocks)
+#define SHINE_V5_SLEEP 2
 #endif
-constexpr int V5_GB = SHINE_V5_GB;  // corner rows in flight per batch in the gather wave
 #ifndef SHINE_V5_SPIN
 #define SHINE_V5_SPIN (1 << 21)
+#endif
+#ifndef SHINE_V5_PRIO  // wave priorities by role: scatter 3 > gather 2 > decoder 0 (the scatter wave is the youngest of its
+#define SHINE_V5_PRIO 0  // SIMD and its dependent v_fmac chain queues behind the decoder waves' MFMAs)
+#endif
+#ifndef SHINE_V5_CH  // tiles per chunk of the interleaved tile assignment (0: one contiguous range per pipeline)
+#define SHINE_V5_CH 0
+#endif
+constexpr int V5_CH = SHINE_V5_CH;
+#ifndef SHINE_V5_PREFIX  // 1: prefix-sum scatter (scatter_level_prefix, shine_tile16.hpp) instead of the serial walk
+#define SHINE_V5_PREFIX 0
+#endif
+#ifndef SHINE_V5_ABL  // measurement builds only: 1 no atomics, 2 no weight-grad phase, 4 no scatter walk, 8 no row gathers
+#define SHINE_V5_ABL 0
 #endif
 #ifndef SHINE_V5_PROF  // measurement builds only (tools/mk_variant.py): per-wave cycle counters through a.prof
 #define SHINE_V5_PROF 0
@@ -68,6 +80,20 @@ __device__ __forceinline__ lds_vint* lds_word(int* p) {
   return (lds_vint*)p;
 #pragma clang diagnostic pop
 }
+typedef const void __attribute__((address_space(1))) gvoid;
+typedef void __attribute__((address_space(3))) lvoid;
+__device__ __forceinline__ gvoid* to_global(const float* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (gvoid*)p;
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ lvoid* to_lds(float* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (lvoid*)p;
+#pragma clang diagnostic pop
+}
 // wait until the single-writer sequence counter reaches `target` (bounded: sets the error word and goes on)
 __device__ __forceinline__ void wait_ge(int* flag, int target, int* err, long long& waited) {
   const long long t0 = SHINE_V5_PROF ? clk() : 0;
@@ -76,7 +102,7 @@ __device__ __forceinline__ void wait_ge(int* flag, int target, int* err, long lo
   for (;;) {
     const int v = __builtin_amdgcn_readfirstlane(*f);
     if (v >= target) break;
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(SHINE_V5_SLEEP);
     if (++spins > SHINE_V5_SPIN) {
       *lds_word(err) = 1;
       break;
@@ -94,16 +120,18 @@ __device__ __forceinline__ void publish(int* flag, int value) {
 template <int L, bool EIK, int ND>
 __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) {
   constexpr int V5_NT = (ND + 2) * V5_PIPES * 64;
-  constexpr int V5_PARTS = V5_PIPES * ND + V5_PIPES;  // partial vectors at the flush: decoder waves, then scatter waves
-  constexpr int K = EIK ? 3 : 4;  // ring depth (what the 160 KB of LDS leave room for)
+  // partial sums at the flush: one decoder-gradient vector per decoder wave, then the trash-row sums of the scatter waves
+  constexpr int DVEC = (SHINE_MLP_PARAMS + LCAP * 8 + 3) / 4 * 4, N_DVEC = V5_PIPES * ND;  // decoder grads + trash rows
+  constexpr int K = EIK ? 2 : 3;  // ring depth (what the 160 KB of LDS leave room for)
   constexpr int SLOT = EIK ? S5_EIK_FLOATS : S5_BCE_FLOATS;
-  static_assert(V5_PARTS * PART_STRIDE <= V5_PIPES * K * SLOT, "the flush re-uses the ring as partial vectors");
+  static_assert(N_DVEC * DVEC <= V5_PIPES * K * SLOT, "the flush re-uses the ring for the partial sums");
   __shared__ float s_opA[V3_OPTOTAL];
   __shared__ float s_bias[100];
   __shared__ double s_loss[4];
   __shared__ int s_sync[V5_PIPES][SY_WORDS];
   __shared__ float s_ring[V5_PIPES * K * SLOT];
   __shared__ float s_r2[V5_PIPES * ND][V3_R2];  // transpose scratch of the decoder waves
+  __shared__ float s_dma[V5_PIPES][8 * 256];  // landing zone of the gather wave's LDS-DMA rows: [corner 4..7][half][lane] x 16 B
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pl = wv & 3, role = wv >> 2;  // role < ND: decoder (tiles role mod ND), ND: gather, ND + 1: scatter
@@ -117,18 +145,39 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
   if (tid == 0) s_loss[0] = s_loss[1] = s_loss[2] = s_loss[3] = 0.0;
   __syncthreads();
 
-  // tiles: workgroup b owns [b T / B, (b + 1) T / B), its pipelines contiguous quarters of that
-  long long begin, end;
+  // Tiles.  V5_CH == 0: workgroup b owns [b T / B, (b + 1) T / B), its pipelines contiguous quarters of that.
+  // V5_CH > 0: the stream is cut into chunks of V5_CH tiles dealt round-robin to the 4 B pipelines of the launch — every
+  // pipeline gets a sample of the whole map instead of one neighbourhood, which evens out what contiguous ranges do not:
+  // ranges of free-space samples (all misses: nothing to gather or scatter) next to ranges on surfaces (a node run every
+  // few points).  Node runs restart at chunk borders (the gather wave forgets its last node there).
+  long long begin = 0;
+  const long long end = a.n;
   int njobs;
-  {
+  const long long n_pipes = (long long)gridDim.x * V5_PIPES, pid = (long long)blockIdx.x * V5_PIPES + pl;
+  if (V5_CH == 0) {
     const long long t0 = ((long long)blockIdx.x * a.tiles) / gridDim.x, t1 = ((long long)(blockIdx.x + 1) * a.tiles) / gridDim.x;
     const long long nt = t1 - t0;
     const long long lo = t0 + (pl * nt) / V5_PIPES, hi = t0 + ((pl + 1) * nt) / V5_PIPES;
     begin = V3_TP * lo;
-    const long long e = V3_TP * hi;
-    end = e < a.n ? e : a.n;
     njobs = (int)(hi - lo);
+  } else {
+    constexpr int CH = V5_CH > 0 ? V5_CH : 1;
+    const long long n_chunks = (a.tiles + CH - 1) / CH;
+    const long long mine = pid < n_chunks ? (n_chunks - pid + n_pipes - 1) / n_pipes : 0;  // chunks pid, pid + P, ...
+    njobs = (int)(mine * V5_CH);
+    if (mine > 0) {  // the stream's last chunk may be short
+      const long long last = pid + (mine - 1) * n_pipes;
+      const long long left = a.tiles - last * V5_CH;
+      if (left < V5_CH) njobs -= (int)(V5_CH - left);
+    }
   }
+  // position in the visiting order of the first point of this pipeline's j-th tile
+  auto tile_base = [&](long long j) -> long long {
+    if (V5_CH == 0) return begin + V3_TP * j;
+    constexpr int CH = V5_CH > 0 ? V5_CH : 1;
+    const long long c = pid + (j / CH) * n_pipes;
+    return V3_TP * (c * CH + (j % CH));
+  };
   int* const sync = s_sync[pl];
   float* const ring = s_ring + pl * K * SLOT;
   const long long t_loop = SHINE_V5_PROF ? clk() : 0;
@@ -139,9 +188,11 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
   float dw3c[8], db2acc[2] = {0.f, 0.f}, db2c[EIK ? 8 : 1], db1c[EIK ? 8 : 1];
   float db3 = 0.f, loss_acc = 0.f, eik_acc = 0.f;
   int cnt_acc = 0;
+  float trash[LCAP][2];  // trash rows (misses): sum over this lane's points of d loss_bce / d f_{2g+t}, per level
+#pragma unroll
+  for (int s = 0; s < LCAP; ++s) trash[s][0] = trash[s][1] = 0.f;
   // scatter waves
-  float trash_sum = 0.f;
-  const int sc = lane >> 3, sq = lane & 7;
+  const int sq = lane & 7;
 
   if (role < ND) {
     // ============================================================================================ D: decoder waves
@@ -164,6 +215,7 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
     const float inv_sigma = 1.0f / a.sigma;
     const float4* sb4 = reinterpret_cast<const float4*>(s_bias);
     float* const R2 = s_r2[ND * pl + role];
+    if (SHINE_V5_PRIO) __builtin_amdgcn_s_setprio(0);
     int lane_o = lane;
     int jk = role % K;  // slot of tile j = role, role + ND, ...
     for (int j = role; j < njobs; j += ND) {
@@ -268,9 +320,19 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
         // the scatter wave can start as soon as d loss / d f is staged: publish BEFORE the weight-grad phase
         df_wr[0] = sdf2[0];
         df_wr[V3_DFP] = sdf2[1];
+        const int4 hitw = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(slot) + S5_META + 56);
         publish(sync + SY_DPUB0 + role, j + 1);
+        {  // trash rows: a level the point misses sends d loss / d f there whole (the 8 corner weights of a node sum to 1)
+          const int hw[4] = {hitw.x, hitw.y, hitw.z, hitw.w};
+#pragma unroll
+          for (int s = 0; s < L; ++s) {
+            const bool miss = valid && !((hw[s] >> o_pt) & 1);
+            trash[s][0] += miss ? sdf2[0] : 0.f;
+            trash[s][1] += miss ? sdf2[1] : 0.f;
+          }
+        }
         // ============================================================== phase 5: decoder weight grads (transposed MFMA)
-        if (a.decoder_grad_on) {
+        if (a.decoder_grad_on && !(SHINE_V5_ABL & 2)) {
           const int i16 = lane & 15;
 #pragma unroll
           for (int r = 0; r < 8; ++r) {  // channel 16 (r >> 2) + 4 g + (r & 3)
@@ -375,10 +437,17 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
             const float cq = a.sigma * (dwc[0] * qv[0] + dwc[1] * qv[1] + dwc[2] * qv[2]);
             st_w[c * V3_WP] = lvhit ? fmaf(delta, w[c], cq) : 0.f;
           }
-          if (g == 0) slot[S5_DF + V3_DL + o_pt] = delta;
           df_wr[0] = J2[0];
           df_wr[V3_DFP] = J2[1];
+          const int4 hitw = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(slot) + S5_META + 56);
           publish(sync + SY_DPUB0 + role, j + 1);
+          const int hw[4] = {hitw.x, hitw.y, hitw.z, hitw.w};
+#pragma unroll
+          for (int s = 0; s < L; ++s) {  // trash rows: d loss_bce / d f = delta J (the eikonal terms cancel there)
+            const bool miss = valid && !((hw[s] >> o_pt) & 1);
+            trash[s][0] += miss ? delta * J2[0] : 0.f;
+            trash[s][1] += miss ? delta * J2[1] : 0.f;
+          }
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) r2[t] = a.sigma * (A2[t][0] * qv[0] + A2[t][1] * qv[1] + A2[t][2] * qv[2]);
@@ -470,13 +539,20 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
         lv_vals = a.lv[s].vals;
         lv_res = a.lv[s].res;
       }
+    if (SHINE_V5_PRIO) __builtin_amdgcn_s_setprio(2);
     int last_slot = -2;  // this lane's level: the node of the previous tile's last point (carries runs across tiles)
-    // point data of a tile, per lane (the four lanes of a point hold copies; the slot is the lane's own level's)
+    // Software pipeline over the dependent chain  position -> sample index -> {hash slot, coordinates} -> corner ids -> rows:
+    // the rows of tile j + 1 are requested right after the rows of tile j have been consumed (the one point of an iteration
+    // where everything in flight has landed), the corner ids of j + 1, the point data of j + 2 and the sample index of j + 3
+    // at the top of iteration j — so the rest of an iteration and the first half of the next cover the rows' round trip.
+    // Rows: corners 0-3 through registers, corners 4-7 global -> LDS directly (global_load_lds: no VGPRs).
     struct PD {
       int p;  // sample index (pool / batch), -1: no point
       float x0, x1, x2, label, weight;
-      int slot;
+      int slot;  // hash slot of this lane's level (-1: miss)
     };
+    auto pos = [&](int j) -> long long { return j < njobs ? tile_base(j) + pt : end; };  // past the last tile: nothing
+    auto load_pm = [&](long long i) -> int { return (a.perm && i < end) ? __builtin_nontemporal_load(a.perm + i) : 0; };
     auto load_pd = [&](long long i, int pm) -> PD {  // i = position in the visiting order; pm = perm[i] if there is a perm
       PD d = {-1, 0.f, 0.f, 0.f, 0.f, 0.f, -1};
       if (i < end) {
@@ -492,38 +568,61 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
       }
       return d;
     };
-    auto load_pm = [&](long long i) -> int { return (a.perm && i < end) ? __builtin_nontemporal_load(a.perm + i) : 0; };
-    auto load_ids = [&](int slot, int4& ia, int4& ib) {
+    auto load_ids = [&](int slot, int4& va, int4& vb) {
       const unsigned int sl = slot >= 0 ? (unsigned int)slot : 0u;
-      ia = lv_vals[2u * sl];
-      ib = lv_vals[2u * sl + 1u];
+      va = lv_vals[2u * sl];
+      vb = lv_vals[2u * sl + 1u];
     };
-    // prologue: the three dependent stages of the first tiles
-    int pm0 = load_pm(begin + pt), pm1 = load_pm(begin + V3_TP + pt), pm2 = load_pm(begin + 2 * V3_TP + pt);
-    PD cur = load_pd(begin + pt, pm0), nxt = load_pd(begin + V3_TP + pt, pm1);
-    int4 ia, ib;
-    load_ids(cur.slot, ia, ib);
+    float4 ra0[4], ra1[4];  // corner rows 0..3 of the tile in flight
+    auto issue_rows = [&](const int4& va, const int4& vb, bool hit) {  // a miss reads row 0 with weight 0 (no branches)
+      const int idv[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float* row = lv_feat + (size_t)(hit ? (unsigned int)idv[c] : 0u) * F;
+#if SHINE_V5_ABL & 8
+        ra0[c] = make_float4((float)idv[c], 1.f, 2.f, 3.f);
+        ra1[c] = ra0[c];
+        (void)row;
+#else
+        ra0[c] = *reinterpret_cast<const float4*>(row);
+        ra1[c] = *reinterpret_cast<const float4*>(row + 4);
+#endif
+      }
+#if !(SHINE_V5_ABL & 8)
+#pragma unroll
+      for (int c = 4; c < 8; ++c) {  // lane l's 16 bytes land at base + 16 l
+        const float* row = lv_feat + (size_t)(hit ? (unsigned int)idv[c] : 0u) * F;
+        __builtin_amdgcn_global_load_lds(to_global(row), to_lds(s_dma[pl] + (2 * (c - 4)) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(to_global(row + 4), to_lds(s_dma[pl] + (2 * (c - 4) + 1) * 256), 16, 0, 0);
+      }
+#endif
+    };
+    // prologue: the dependent stages of the first tiles, one after the other (once per pipeline)
+    int pm2;
+    PD cur, nxt;
+    int4 cia, cib;
+    {
+      const int pm0 = load_pm(pos(0)), pm1 = load_pm(pos(1));
+      pm2 = load_pm(pos(2));
+      cur = load_pd(pos(0), pm0), nxt = load_pd(pos(1), pm1);
+      load_ids(cur.slot, cia, cib);
+      issue_rows(cia, cib, cur.p >= 0 && cur.slot >= 0);
+    }
     int jk = 0;
     for (int j = 0; j < njobs; ++j) {
-      const long long base = begin + (long long)V3_TP * j;
+      const long long base = tile_base(j);
+      if (V5_CH > 0 && j % (V5_CH > 0 ? V5_CH : 1) == 0) last_slot = -2;  // a new chunk: no node carries over
       float* const slot = ring + jk * SLOT;
       int* const st_ids = reinterpret_cast<int*>(slot) + S5_IDS + (8 * g) * V3_WP + pt;
       float* const st_w = slot + S5_W + (8 * g) * V3_WP + pt;
       const bool valid = cur.p >= 0;
       const bool hit = valid && cur.slot >= 0;
-      const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-      // ---- issue: rows of tile j (first batch), ids of j + 1, point data of j + 2, sample index of j + 3
-      float4 r0[V5_GB], r1[V5_GB];
-#pragma unroll
-      for (int c = 0; c < V5_GB; ++c) {  // a miss reads row 0 with weight 0 (no branches)
-        const float* row = lv_feat + (size_t)(hit ? (unsigned int)ids[c] : 0u) * F;
-        r0[c] = *reinterpret_cast<const float4*>(row);
-        r1[c] = *reinterpret_cast<const float4*>(row + 4);
-      }
+      const int ids[8] = {cia.x, cia.y, cia.z, cia.w, cib.x, cib.y, cib.z, cib.w};
+      // ---- issue: corner ids of j + 1, point data of j + 2, sample index of j + 3 (the rows of j are already in flight)
       int4 nia, nib;
       load_ids(nxt.slot, nia, nib);
-      PD nx2 = load_pd(base + 2 * V3_TP + pt, pm2);
-      const int pm3 = load_pm(base + 3 * V3_TP + pt);
+      const PD nx2 = load_pd(pos(j + 2), pm2);
+      const int pm3 = load_pm(pos(j + 3));
       // ---- node-run boundaries of the ordered stream, all levels at once: bit 16 g + pt of one 64-bit ballot
       const int myslot = hit ? cur.slot : -1;
       const unsigned int validmask = (unsigned int)__ballot(valid) & 0xFFFFu;
@@ -562,39 +661,41 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
       float Ag[EIK ? 8 : 1][3];
 #pragma unroll
       for (int q = 0; q < (EIK ? 8 : 1); ++q) Ag[q][0] = Ag[q][1] = Ag[q][2] = 0.f;
+      auto accumulate = [&](int c, const float4& q0, const float4& q1) {
+        const float wc = w[c];
+        pf[0] = fmaf(wc, q0.x, pf[0]);
+        pf[1] = fmaf(wc, q0.y, pf[1]);
+        pf[2] = fmaf(wc, q0.z, pf[2]);
+        pf[3] = fmaf(wc, q0.w, pf[3]);
+        pf[4] = fmaf(wc, q1.x, pf[4]);
+        pf[5] = fmaf(wc, q1.y, pf[5]);
+        pf[6] = fmaf(wc, q1.z, pf[6]);
+        pf[7] = fmaf(wc, q1.w, pf[7]);
+        if (EIK) {
+          float dwc[3];
+          corner_dw(X, Y, Z, c, dwc);
+          const float rr[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
-      for (int cb = 0; cb < 8; cb += V5_GB) {
-        if (cb > 0) {
+          for (int e = 0; e < 3; ++e) {
 #pragma unroll
-          for (int c = 0; c < V5_GB; ++c) {
-            const float* row = lv_feat + (size_t)(hit ? (unsigned int)ids[cb + c] : 0u) * F;
-            r0[c] = *reinterpret_cast<const float4*>(row);
-            r1[c] = *reinterpret_cast<const float4*>(row + 4);
+            for (int q = 0; q < 8; ++q) Ag[q][e] = fmaf(dwc[e], rr[q], Ag[q][e]);  // (zero for a miss: dt = 0 above)
           }
         }
+      };
+      // everything this wave has in flight was issued at least half an iteration ago; the LDS-DMA rows have no VGPR the
+      // compiler could wait on, so the wait is explicit (and total: the counter is in order)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int c = 0; c < V5_GB; ++c) {
-          const float wc = w[cb + c];
-          pf[0] = fmaf(wc, r0[c].x, pf[0]);
-          pf[1] = fmaf(wc, r0[c].y, pf[1]);
-          pf[2] = fmaf(wc, r0[c].z, pf[2]);
-          pf[3] = fmaf(wc, r0[c].w, pf[3]);
-          pf[4] = fmaf(wc, r1[c].x, pf[4]);
-          pf[5] = fmaf(wc, r1[c].y, pf[5]);
-          pf[6] = fmaf(wc, r1[c].z, pf[6]);
-          pf[7] = fmaf(wc, r1[c].w, pf[7]);
-          if (EIK) {
-            float dwc[3];
-            corner_dw(X, Y, Z, cb + c, dwc);
-            const float rr[8] = {r0[c].x, r0[c].y, r0[c].z, r0[c].w, r1[c].x, r1[c].y, r1[c].z, r1[c].w};
+      for (int c = 0; c < 4; ++c) accumulate(c, ra0[c], ra1[c]);
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
-#pragma unroll
-              for (int q = 0; q < 8; ++q) Ag[q][e] = fmaf(dwc[e], rr[q], Ag[q][e]);  // (zero for a miss: dt = 0 above)
-            }
-          }
-        }
-        if (V5_GB < 8) __builtin_amdgcn_sched_barrier(0);
+      for (int c = 0; c < 4; ++c) {
+#if SHINE_V5_ABL & 8
+        const float4 q0 = make_float4((float)ids[4 + c], 1.f, 2.f, 3.f), q1 = q0;
+#else
+        const float4 q0 = *reinterpret_cast<const float4*>(s_dma[pl] + (2 * c) * 256 + 4 * lane);
+        const float4 q1 = *reinterpret_cast<const float4*>(s_dma[pl] + (2 * c + 1) * 256 + 4 * lane);
+#endif
+        accumulate(4 + c, q0, q1);
       }
       // ---- reduce-scatter of the per-level sums over the point's four lanes: lane g ends with features (2g, 2g+1)
       {
@@ -615,6 +716,12 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
           for (int t = 0; t < 2; ++t) slot[S5_A2 + (3 * t + e) * 64 + lane] = xsum16(h4[t], h4[2 + t]);
         }
       }
+      // ---- issue the rows of tile j + 1: its corner ids landed with the wait above, the LDS landing zone has been read (the
+      // features are reduced and staged, so nothing of tile j but its point data is live any more)
+      __builtin_amdgcn_sched_barrier(0);
+      wave_lds_fence();  // (the reads of the landing zone are done before the next DMA may overwrite it)
+      if (j + 1 < njobs) issue_rows(nia, nib, nxt.p >= 0 && nxt.slot >= 0);
+      __builtin_amdgcn_sched_barrier(0);
       // ---- meta: label / weight / output position of the 16 points, the three masks, the per-level hit bits
       {
         const long long po = a.pool_mode ? base + pt : (long long)cur.p;  // where this point's outputs go
@@ -636,11 +743,7 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
       }
       publish(sync + SY_GPUB, j + 1);
       // ---- rotate the pipeline registers
-      cur = nxt;
-      nxt = nx2;
-      ia = nia;
-      ib = nib;
-      pm2 = pm3;
+      cur = nxt, nxt = nx2, cia = nia, cib = nib, pm2 = pm3;
       if (++jk == K) jk = 0;
     }
   } else {
@@ -653,6 +756,7 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
       run_acc[s] = 0.f;
       run_hit[s] = 0;
     }
+    if (SHINE_V5_PRIO) __builtin_amdgcn_s_setprio(3);
     int lane_o = lane;
     int jk = 0;
     for (int j = 0; j < njobs; ++j) {
@@ -664,17 +768,13 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
       wait_ge(sync + SY_DPUB0 + (ND == 2 ? (j & 1) : 0), j + 1, sync + SY_ERR, waited);
       // the tile's masks (wave-uniform): one read, five lane broadcasts
       unsigned long long chg64, hit64;
-      unsigned int validmask;
       {
         const int mv = reinterpret_cast<const int*>(slot)[S5_META + 48 + (lane_o & 7)];
         const unsigned int c0 = (unsigned int)__builtin_amdgcn_readlane(mv, 0), c1 = (unsigned int)__builtin_amdgcn_readlane(mv, 1);
         const unsigned int h0 = (unsigned int)__builtin_amdgcn_readlane(mv, 2), h1 = (unsigned int)__builtin_amdgcn_readlane(mv, 3);
-        validmask = (unsigned int)__builtin_amdgcn_readlane(mv, 4);
         chg64 = ((unsigned long long)c1 << 32) | c0;
         hit64 = ((unsigned long long)h1 << 32) | h0;
       }
-      // this lane's trash level: the points that miss level sc
-      const unsigned int mymiss = sc < L ? (~(unsigned int)(hit64 >> (16 * (sc & 3))) & validmask) : 0u;
       float dfr[V3_TP];
 #pragma unroll
       for (int jj = 0; jj < V3_TP / 4; ++jj) {
@@ -690,22 +790,6 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
         wq[0][jj] = *reinterpret_cast<const float4*>(sc_w + 4 * jj);
         iq[0][jj] = *reinterpret_cast<const int4*>(sc_ids + 4 * jj);
       }
-      {  // trash rows: the plain sum of d loss_bce / d f over the misses (the 8 corner weights of a missed node sum to 1)
-        float dl[EIK ? V3_TP : 1];
-        if (EIK) {  // the staged vector is J: d loss_bce / d f = delta J
-#pragma unroll
-          for (int jj = 0; jj < V3_TP / 4; ++jj) {
-            const float4 v = *reinterpret_cast<const float4*>(slot + S5_DF + V3_DL + 4 * jj);
-            dl[4 * jj] = v.x, dl[4 * jj + 1] = v.y, dl[4 * jj + 2] = v.z, dl[4 * jj + 3] = v.w;
-          }
-        }
-#pragma unroll
-        for (int p2 = 0; p2 < V3_TP; ++p2) {
-          const unsigned int keep = 0u - ((mymiss >> p2) & 1u);
-          const float t = EIK ? dfr[p2] * dl[p2] : dfr[p2];
-          trash_sum += __uint_as_float(__float_as_uint(t) & keep);
-        }
-      }
 #pragma unroll
       for (int s = 0; s < L; ++s) {
         if (s + 1 < L) {
@@ -719,7 +803,7 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
           publish(sync + SY_SDONE, j + 1);
         }
         float* gbase = a.lv[s].grad;
-        if (gbase) {
+        if (gbase && !(SHINE_V5_ABL & 4)) {
           float wr[V3_TP];
           int idr[V3_TP];
 #pragma unroll
@@ -734,6 +818,15 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
           const unsigned int cm = (unsigned int)(chg64 >> (16 * s)) & 0xFFFFu;
           const unsigned int hm = (unsigned int)(hit64 >> (16 * s)) & 0xFFFFu;
           unsigned char* const tb = a.touched[s];
+#if SHINE_V5_PREFIX
+          {
+            f32x16 wv, dv;
+            i32x16 iv;
+#pragma unroll
+            for (int p2 = 0; p2 < V3_TP; ++p2) wv[p2] = wr[p2], dv[p2] = dfr[p2], iv[p2] = idr[p2];
+            scatter_level_prefix<!(SHINE_V5_ABL & 1)>(wv, iv, dv, cm, hm, sq, gbase, tb, rid, rhit, racc);
+          }
+#else
           if (cm == 0u) {  // no node boundary inside this tile at this level (the usual case at the coarse levels)
 #pragma unroll
             for (int p2 = 0; p2 < V3_TP; ++p2) racc = fmaf(wr[p2], dfr[p2], racc);
@@ -741,7 +834,7 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
 #pragma unroll
             for (int p2 = 0; p2 < V3_TP; ++p2) {
               if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
-                if (rhit) atomic_add_f32(gbase + (unsigned int)rid, racc);  // scalar branch
+                if (rhit && !(SHINE_V5_ABL & 1)) atomic_add_f32(gbase + (unsigned int)rid, racc);  // scalar branch
                 racc = 0.f;
                 rid = (idr[p2] << 3) | sq;  // float offset of this lane's (corner row, feature)
                 rhit = (int)((hm >> p2) & 1u);
@@ -752,6 +845,7 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
               racc = fmaf(wr[p2], dfr[p2], racc);  // misses and padding lanes staged w = 0
             }
           }
+#endif
           run_id[s] = rid;
           run_hit[s] = rhit;
           run_acc[s] = racc;
@@ -774,9 +868,15 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
     o[0] = role, o[1] = njobs, o[2] = t_loop - t_start, o[3] = now - t_loop, o[4] = waited, o[5] = o[6] = o[7] = 0;
   }
   __syncthreads();  // every role is done with the ring: it now holds the partial vectors (8 decoder + 4 scatter waves)
-  if (role == ND + 1 && sc < L) s_ring[(V5_PIPES * ND + pl) * PART_STRIDE + PART_TRASH + sc * 8 + sq] = trash_sum;
   if (role < ND) {
-    float* wvec = s_ring + (ND * pl + role) * PART_STRIDE;
+    float* wvec = s_ring + (ND * pl + role) * DVEC;
+#pragma unroll
+    for (int s = 0; s < L; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {  // features 2g + t of the 16 points of the DPP row
+        const float v = row16_sum(trash[s][t]);
+        if (pt == 0) wvec[SHINE_MLP_PARAMS + s * 8 + 2 * g + t] = v;
+      }
     if (a.decoder_grad_on) {
       const int jc = lane & 15, rr = lane >> 4;  // accumulator role: column jc, rows 4 rr + r
 #pragma unroll
@@ -825,10 +925,10 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
     if (idx >= mlp_lo) {
       if (idx < PART_TRASH) {
 #pragma unroll
-        for (int w = 0; w < V5_PIPES * ND; ++w) v += s_ring[w * PART_STRIDE + idx];
-      } else {
+        for (int w = 0; w < N_DVEC; ++w) v += s_ring[w * DVEC + idx];
+      } else {  // PART_TRASH == SHINE_MLP_PARAMS: the trash sums sit right behind the decoder grads in a wave's vector
 #pragma unroll
-        for (int w = V5_PIPES * ND; w < V5_PARTS; ++w) v += s_ring[w * PART_STRIDE + idx];
+        for (int w = 0; w < N_DVEC; ++w) v += s_ring[w * DVEC + idx];
       }
     }
     dst[idx] = v;
@@ -864,8 +964,9 @@ V2Geometry v5_geometry(long long n, bool eik) {
 }
 
 long long v5_lds_bytes(bool eik) {
-  const long long K = eik ? 3 : 4, slot = eik ? S5_EIK_FLOATS : S5_BCE_FLOATS;
-  return (long long)sizeof(float) * (V3_OPTOTAL + 100 + V5_PIPES * K * slot + V5_PIPES * v5_nd(eik) * V3_R2) + 4 * sizeof(double) +
+  const long long K = eik ? 2 : 3, slot = eik ? S5_EIK_FLOATS : S5_BCE_FLOATS;
+  return (long long)sizeof(float) * (V3_OPTOTAL + 100 + V5_PIPES * K * slot + V5_PIPES * v5_nd(eik) * V3_R2 +
+                                     V5_PIPES * 2048) + 4 * sizeof(double) +
          V5_PIPES * SY_WORDS * sizeof(int);
 }
 

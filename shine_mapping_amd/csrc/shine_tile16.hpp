@@ -89,4 +89,49 @@ __device__ __forceinline__ void load_decoder_operands(const V1Args& a, float* s_
   if (tid == 0) s_bias[96] = a.mlp[5][0];
 }
 
+// ---- feature-grad scatter of ONE level of ONE 16-point tile, lane = (corner, feature): prefix-sum form of the run-length walk.
+// The serial walk (test a run-start bit, branch, v_fmac — 16 times per level) is a chain of scalar compare -> taken branch ->
+// dependent VALU: ~60 cycles per point in the role-specialised kernel's scatter wave (profiles/r03_ab_experiments.txt block 3).
+// Here the 16 products are accumulated unconditionally into 16 REGISTERS P[p] = sum_{p' <= p} w[p'] df[p'] (16 v_fma, no
+// scalar work), and only the node runs that END inside the tile are visited — a wave-uniform loop over the set bits of the
+// run-start mask — taking  sum(run) = P[end - 1] - P[start - 1]  with a uniform dynamic register index (s_set_gpr_idx: no
+// LDS, no scratch).  A tile without a run start (the usual case at the coarse levels) is 16 fma and one add.
+// Rounding: a run's sum is a difference of two prefix sums of at most 16 terms — ~1e-6 of the largest term, against the
+// 1e-4-of-max-abs contract; the run's first partial (carried in from earlier tiles) is added exactly as before.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+template <bool ATOMICS>
+__device__ __forceinline__ void scatter_level_prefix(const f32x16& wr, const i32x16& idr, const f32x16& dfr, unsigned int cm,
+                                                     unsigned int hm, int sq, float* gbase, unsigned char* tb, int& rid,
+                                                     int& rhit, float& racc) {
+  f32x16 P;
+  P[0] = wr[0] * dfr[0];
+#pragma unroll
+  for (int p = 1; p < V3_TP; ++p) P[p] = fmaf(wr[p], dfr[p], P[p - 1]);  // misses and padding lanes staged w = 0
+  if (cm == 0u) {  // the open run covers the whole tile
+    racc += P[V3_TP - 1];
+    return;
+  }
+  unsigned int m = cm;
+  float prev = 0.f;
+  do {
+    const int st = __builtin_ctz(m);  // wave-uniform: a new node (or a run of misses) starts at point st
+    m &= m - 1u;
+    // (the index is forced into an SGPR: behind a VALU-derived select the compiler emits a waterfall loop around the move)
+    const int i0 = __builtin_amdgcn_readfirstlane(st > 0 ? st - 1 : 0);
+    float pv = P[i0];
+    if (st == 0) pv = 0.f;
+    if (rhit && ATOMICS) atomic_add_f32(gbase + (unsigned int)rid, racc + (pv - prev));  // close the open run
+    racc = 0.f;
+    prev = pv;
+    const int id = idr[st];
+    rid = (id << 3) | sq;  // float offset of this lane's (corner row, feature)
+    rhit = (int)((hm >> st) & 1u);
+    // touched-row flags (unique(hierarchical_indices) without -1): set at the run start of every hit node, one lane per corner
+    if (tb && rhit && sq == 0) tb[id] = 1;
+  } while (m);
+  racc = P[V3_TP - 1] - prev;  // the partial of the run that stays open
+}
+
 }  // namespace shine
