@@ -44,6 +44,9 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 #ifndef SHINE_V3_PREDSCAT  // measurement builds only: branch-free run-length scatter (see phase 6)
 #define SHINE_V3_PREDSCAT 0
 #endif
+#ifndef SHINE_V3_CH  // measurement builds: > 0 = the stream is cut into chunks of this many tiles dealt round-robin to ALL waves of
+#define SHINE_V3_CH 0  // the launch (node runs restart at chunk borders); 0 = one contiguous range per wave
+#endif
 #ifndef SHINE_V3_PREFIX  // 1: prefix-sum scatter (scatter_level_prefix, shine_tile16.hpp) instead of the serial walk
 #define SHINE_V3_PREFIX 0
 #endif
@@ -199,7 +202,29 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     begin = V3_TP * (t0 + lo);
     end_t = V3_TP * (t0 + hi);
   }
+#if SHINE_V3_CH > 0
+  // interleaved assignment: wave w of the launch owns chunks w, w + W, w + 2 W, ... (W waves, SHINE_V3_CH tiles per chunk)
+  const long long n_waves_all = (long long)gridDim.x * WAVES;
+  const long long n_chunks_all = (a.tiles + SHINE_V3_CH - 1) / SHINE_V3_CH;
+  int njobs = 0;
+  {
+    const long long mine = wave_g < n_chunks_all ? (n_chunks_all - wave_g + n_waves_all - 1) / n_waves_all : 0;
+    njobs = (int)(mine * SHINE_V3_CH);
+    if (mine > 0) {
+      const long long left = a.tiles - (wave_g + (mine - 1) * n_waves_all) * SHINE_V3_CH;
+      if (left < SHINE_V3_CH) njobs -= (int)(SHINE_V3_CH - left);
+    }
+  }
+  auto tile_base = [&](int j) -> long long {
+    return j < njobs ? V3_TP * ((wave_g + (long long)(j / SHINE_V3_CH) * n_waves_all) * SHINE_V3_CH + (j % SHINE_V3_CH)) : a.n;
+  };
+  begin = tile_base(0);
+  const long long end = a.n;
+  const long long second = tile_base(1);
+#else
   const long long end = end_t < a.n ? end_t : a.n;
+  const long long second = begin + V3_TP;
+#endif
 
   // software prefetch of the {perm -> coord, label, slot} chain, index two tiles ahead (as in v1 / v2)
   long long np = 0;
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   int nslot = -1;
   bool nvalid = begin + pt < end;
   int np2 = 0;
-  if (a.perm && begin + V3_TP + pt < end) np2 = a.perm[begin + V3_TP + pt];
+  if (a.perm && second + pt < end) np2 = a.perm[second + pt];
   if (nvalid) {
     np = a.perm ? (long long)a.perm[begin + pt] : begin + pt;
     const long long si = a.pool_mode ? np : begin + pt;
@@ -220,7 +245,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   }
   SHINE_STAMP(0)  // setup
 
+#if SHINE_V3_CH > 0
+  for (int jt = 0; jt < njobs; ++jt) {
+    const long long base = tile_base(jt);
+    if (jt % SHINE_V3_CH == 0) last_slot = -2;  // a new chunk: no node carries over
+#else
   for (long long base = begin; base < end; base += V3_TP) {
+#endif
     asm volatile("" : "+v"(lane_o));  // opaque per tile (see above)
     const int o_pt = lane_o & 15, o_g = lane_o >> 4;
     int* const st_ids = U_ids + (8 * o_g) * V3_WP + o_pt;   // staging writes (level o_g): + c * V3_WP
@@ -386,7 +417,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
 #endif
     // prefetch of tile t+1's point data, issued after every gather of this tile (vmcnt counts in order)
     {
-      const long long ni = base + V3_TP + pt;
+#if SHINE_V3_CH > 0
+      const long long ni = tile_base(jt + 1) + pt, ni2 = tile_base(jt + 2) + pt;
+#else
+      const long long ni = base + V3_TP + pt, ni2 = ni + V3_TP;
+#endif
       nvalid = ni < end;
       np = 0;
       nx0 = nx1 = nx2 = nlabel = nweight = 0.f;
@@ -401,7 +436,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
         nlabel = __builtin_nontemporal_load(a.label + np);
         if (EIK || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
       }
-      if (a.perm && ni + V3_TP < end) np2 = __builtin_nontemporal_load(a.perm + ni + V3_TP);
+      if (a.perm && ni2 < end) np2 = __builtin_nontemporal_load(a.perm + ni2);
     }
     // reduce-scatter of the per-level sums over the point's four lanes: lane g ends with features (2g, 2g+1)
     float f2[2];

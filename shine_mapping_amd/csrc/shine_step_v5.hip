@@ -52,10 +52,13 @@ constexpr int S5_EIK_FLOATS = S5_A2 + 6 * 64;
 #define SHINE_V5_SPIN (1 << 21)
 #endif
 #ifndef SHINE_V5_PRIO  // wave priorities by role: scatter 3 > gather 2 > decoder 0 (the scatter wave is the youngest of its
-#define SHINE_V5_PRIO 0  // SIMD and its dependent v_fmac chain queues behind the decoder waves' MFMAs)
+#define SHINE_V5_PRIO 1  // SIMD and its dependent v_fmac chain queues behind the decoder waves' MFMAs)
 #endif
 #ifndef SHINE_V5_CH  // tiles per chunk of the interleaved tile assignment (0: one contiguous range per pipeline)
-#define SHINE_V5_CH 0
+#define SHINE_V5_CH 4
+#endif
+#ifndef SHINE_V5_DYN  // 1: the chunks of a workgroup (b, b + B, b + 2 B, ...) are CLAIMED by its four gather waves from an LDS
+#define SHINE_V5_DYN 1  // counter instead of being dealt round-robin: a pipeline that drew expensive tiles simply claims fewer
 #endif
 constexpr int V5_CH = SHINE_V5_CH;
 #ifndef SHINE_V5_PREFIX  // 1: prefix-sum scatter (scatter_level_prefix, shine_tile16.hpp) instead of the serial walk
@@ -68,7 +71,7 @@ constexpr int V5_CH = SHINE_V5_CH;
 #define SHINE_V5_PROF 0
 #endif
 
-enum { SY_GPUB = 0, SY_DPUB0 = 1, SY_DPUB1 = 2, SY_SDONE = 3, SY_ERR = 4, SY_WORDS = 8 };
+enum { SY_GPUB = 0, SY_DPUB0 = 1, SY_DPUB1 = 2, SY_SDONE = 3, SY_ERR = 4, SY_TOTAL = 5, SY_WORDS = 8 };
 
 // The hand-off counters are read and written through explicit LDS (address space 3) pointers: behind a generic pointer the
 // compiler emits flat_load / flat_store, whose completion it tracks with vmcnt — every poll would drain the wave's
@@ -111,6 +114,31 @@ __device__ __forceinline__ void wait_ge(int* flag, int target, int* err, long lo
   asm volatile("" ::: "memory");
   if (SHINE_V5_PROF) waited += clk() - t0;
 }
+// the same for a consumer of tiles: false when tile j does not exist (the gather wave publishes the pipeline's tile count in
+// `total` once it knows it; INT_MAX until then)
+__device__ __forceinline__ bool wait_tile(int* flag, int* total, int j, int* err, long long& waited) {
+  const long long t0 = SHINE_V5_PROF ? clk() : 0;
+  lds_vint* const f = lds_word(flag);
+  lds_vint* const t = lds_word(total);
+  int spins = 0;
+  bool there = true;
+  for (;;) {
+    if (__builtin_amdgcn_readfirstlane(*f) >= j + 1) break;
+    if (__builtin_amdgcn_readfirstlane(*t) <= j) {
+      there = false;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(SHINE_V5_SLEEP);
+    if (++spins > SHINE_V5_SPIN) {
+      *lds_word(err) = 1;
+      there = false;
+      break;
+    }
+  }
+  asm volatile("" ::: "memory");
+  if (SHINE_V5_PROF) waited += clk() - t0;
+  return there;
+}
 // publish: every DS write of this wave so far is performed before the counter moves
 __device__ __forceinline__ void publish(int* flag, int value) {
   wave_lds_fence();
@@ -129,6 +157,7 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
   __shared__ float s_bias[100];
   __shared__ double s_loss[4];
   __shared__ int s_sync[V5_PIPES][SY_WORDS];
+  __shared__ int s_claim;  // SHINE_V5_DYN: chunks of this workgroup handed out so far
   __shared__ float s_ring[V5_PIPES * K * SLOT];
   __shared__ float s_r2[V5_PIPES * ND][V3_R2];  // transpose scratch of the decoder waves
   __shared__ float s_dma[V5_PIPES][8 * 256];  // landing zone of the gather wave's LDS-DMA rows: [corner 4..7][half][lane] x 16 B
@@ -141,8 +170,11 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
   const long long t_start = SHINE_V5_PROF ? clk() : 0;
 
   load_decoder_operands<V5_NT>(a, s_opA, s_bias, tid);
-  if (tid < V5_PIPES * SY_WORDS) (&s_sync[0][0])[tid] = 0;
-  if (tid == 0) s_loss[0] = s_loss[1] = s_loss[2] = s_loss[3] = 0.0;
+  if (tid < V5_PIPES * SY_WORDS) (&s_sync[0][0])[tid] = (tid % SY_WORDS) == SY_TOTAL ? 0x7fffffff : 0;
+  if (tid == 0) {
+    s_loss[0] = s_loss[1] = s_loss[2] = s_loss[3] = 0.0;
+    s_claim = 0;
+  }
   __syncthreads();
 
   // Tiles.  V5_CH == 0: workgroup b owns [b T / B, (b + 1) T / B), its pipelines contiguous quarters of that.
@@ -150,15 +182,19 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
   // pipeline gets a sample of the whole map instead of one neighbourhood, which evens out what contiguous ranges do not:
   // ranges of free-space samples (all misses: nothing to gather or scatter) next to ranges on surfaces (a node run every
   // few points).  Node runs restart at chunk borders (the gather wave forgets its last node there).
-  long long begin = 0;
-  const long long end = a.n;
-  int njobs;
+  int begin = 0;  // (positions fit 32 bits: shine_train_step_v5 refuses launches of 2^31 points or more)
+  const int end = (int)a.n;
+  int njobs = 0;  // static assignments: tiles of this pipeline (dynamic: known to the gather wave at the end only)
+  int tiles_done = 0;
+  constexpr int CHD = V5_CH > 0 ? V5_CH : 1;
+  static_assert(!SHINE_V5_DYN || V5_CH >= 4, "claiming one chunk ahead covers the gather wave's three-tile look-ahead");
+  const long long n_chunks_all = (a.tiles + CHD - 1) / CHD;
   const long long n_pipes = (long long)gridDim.x * V5_PIPES, pid = (long long)blockIdx.x * V5_PIPES + pl;
   if (V5_CH == 0) {
     const long long t0 = ((long long)blockIdx.x * a.tiles) / gridDim.x, t1 = ((long long)(blockIdx.x + 1) * a.tiles) / gridDim.x;
     const long long nt = t1 - t0;
     const long long lo = t0 + (pl * nt) / V5_PIPES, hi = t0 + ((pl + 1) * nt) / V5_PIPES;
-    begin = V3_TP * lo;
+    begin = (int)(V3_TP * lo);
     njobs = (int)(hi - lo);
   } else {
     constexpr int CH = V5_CH > 0 ? V5_CH : 1;
@@ -172,11 +208,10 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
     }
   }
   // position in the visiting order of the first point of this pipeline's j-th tile
-  auto tile_base = [&](long long j) -> long long {
+  auto tile_base = [&](int j) -> int {
     if (V5_CH == 0) return begin + V3_TP * j;
-    constexpr int CH = V5_CH > 0 ? V5_CH : 1;
-    const long long c = pid + (j / CH) * n_pipes;
-    return V3_TP * (c * CH + (j % CH));
+    const int c = (int)pid + (j / CHD) * (int)n_pipes;
+    return V3_TP * (c * CHD + (j % CHD));
   };
   int* const sync = s_sync[pl];
   float* const ring = s_ring + pl * K * SLOT;
@@ -218,7 +253,9 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
     if (SHINE_V5_PRIO) __builtin_amdgcn_s_setprio(0);
     int lane_o = lane;
     int jk = role % K;  // slot of tile j = role, role + ND, ...
-    for (int j = role; j < njobs; j += ND) {
+    for (int j = role;; j += ND) {
+      if (!wait_tile(sync + SY_GPUB, sync + SY_TOTAL, j, sync + SY_ERR, waited)) break;
+      ++tiles_done;
       asm volatile("" : "+v"(lane_o));  // opaque per tile: keeps pre-added LDS address variants out of loop-carried VGPRs
       const int o_pt = lane_o & 15, o_g = lane_o >> 4;
       float* const slot = ring + jk * SLOT;
@@ -227,7 +264,6 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
       float* const f_wr = R2 + (2 * o_g) * V3_TT + o_pt;       // [feature 2g (+1)][pt] rows
       float* const df_wr = slot + S5_DF + (2 * o_g) * V3_DFP + o_pt;
       const float* const opa = s_opA + lane_o;
-      wait_ge(sync + SY_GPUB, j + 1, sync + SY_ERR, waited);
       // ---- inputs of this tile: features (2g, 2g+1) of point pt, the point's label / weight / output position
       const float2 fin = *reinterpret_cast<const float2*>(slot + S5_F + 2 * lane_o);
       const float f2[2] = {fin.x, fin.y};
@@ -551,13 +587,43 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
       float x0, x1, x2, label, weight;
       int slot;  // hash slot of this lane's level (-1: miss)
     };
-    auto pos = [&](int j) -> long long { return j < njobs ? tile_base(j) + pt : end; };  // past the last tile: nothing
-    auto load_pm = [&](long long i) -> int { return (a.perm && i < end) ? __builtin_nontemporal_load(a.perm + i) : 0; };
-    auto load_pd = [&](long long i, int pm) -> PD {  // i = position in the visiting order; pm = perm[i] if there is a perm
+    // dynamic assignment: the chunk this wave works on and the one it has claimed next (claimed one chunk ahead, because the
+    // look-ahead of the load pipeline runs three tiles ahead of the tile being staged)
+    int gc_cur = -1, gc_next = -1;
+    int kcur = 0;
+    const int n_chunks_i = (int)n_chunks_all, n_tiles_i = (int)a.tiles;
+    auto claim = [&]() -> int {
+      int v = 0;
+      if (lane == 0) v = __hip_atomic_fetch_add(&s_claim, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      v = __builtin_amdgcn_readfirstlane(v);
+      const long long gc = (long long)blockIdx.x + (long long)v * gridDim.x;
+      return gc < n_chunks_i ? (int)gc : -1;
+    };
+    if (SHINE_V5_DYN) {
+      gc_cur = claim();
+      gc_next = claim();
+    } else {
+      *lds_word(sync + SY_TOTAL) = njobs;  // static assignment: the consumers know where the pipeline's stream ends
+    }
+    // first point (position in the visiting order) of this pipeline's j-th tile, or -1 when there is no such tile
+    auto tile_pos = [&](int j) -> int {
+      if (!SHINE_V5_DYN) return j < njobs ? tile_base(j) : -1;
+      const int k = j / CHD, off = j % CHD;
+      const int gc = k == kcur ? gc_cur : (k == kcur + 1 ? gc_next : -1);
+      if (gc < 0) return -1;
+      const int t = gc * CHD + off;
+      return t < n_tiles_i ? V3_TP * t : -1;
+    };
+    auto pos = [&](int j) -> int {  // this lane's point of that tile; past the last tile: nothing to load
+      const int b = tile_pos(j);
+      return b >= 0 ? b + pt : end;
+    };
+    auto load_pm = [&](int i) -> int { return (a.perm && i < end) ? __builtin_nontemporal_load(a.perm + i) : 0; };
+    auto load_pd = [&](int i, int pm) -> PD {  // i = position in the visiting order; pm = perm[i] if there is a perm
       PD d = {-1, 0.f, 0.f, 0.f, 0.f, 0.f, -1};
       if (i < end) {
-        const long long p = a.perm ? (long long)pm : i;
-        const long long si = a.pool_mode ? p : i;
+        const long long p = a.perm ? pm : i;
+        const long long si = a.pool_mode ? p : (long long)i;
         d.p = (int)p;
         if (lvl_on) d.slot = __builtin_nontemporal_load(a.slots + si * L + g);
         d.x0 = __builtin_nontemporal_load(a.coord + 3 * p);
@@ -609,9 +675,11 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
       issue_rows(cia, cib, cur.p >= 0 && cur.slot >= 0);
     }
     int jk = 0;
-    for (int j = 0; j < njobs; ++j) {
-      const long long base = tile_base(j);
-      if (V5_CH > 0 && j % (V5_CH > 0 ? V5_CH : 1) == 0) last_slot = -2;  // a new chunk: no node carries over
+    int j = 0;
+    for (;; ++j) {
+      const int base = tile_pos(j);
+      if (base < 0) break;
+      if (V5_CH > 0 && j % CHD == 0) last_slot = -2;  // a new chunk: no node carries over
       float* const slot = ring + jk * SLOT;
       int* const st_ids = reinterpret_cast<int*>(slot) + S5_IDS + (8 * g) * V3_WP + pt;
       float* const st_w = slot + S5_W + (8 * g) * V3_WP + pt;
@@ -720,15 +788,15 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
       // features are reduced and staged, so nothing of tile j but its point data is live any more)
       __builtin_amdgcn_sched_barrier(0);
       wave_lds_fence();  // (the reads of the landing zone are done before the next DMA may overwrite it)
-      if (j + 1 < njobs) issue_rows(nia, nib, nxt.p >= 0 && nxt.slot >= 0);
+      if (tile_pos(j + 1) >= 0) issue_rows(nia, nib, nxt.p >= 0 && nxt.slot >= 0);
       __builtin_amdgcn_sched_barrier(0);
       // ---- meta: label / weight / output position of the 16 points, the three masks, the per-level hit bits
       {
-        const long long po = a.pool_mode ? base + pt : (long long)cur.p;  // where this point's outputs go
+        const int po = a.pool_mode ? base + pt : cur.p;  // where this point's outputs go
         if (g == 0) {
           slot[S5_META + pt] = cur.label;
           slot[S5_META + 16 + pt] = cur.weight;
-          reinterpret_cast<int*>(slot)[S5_META + 32 + pt] = valid ? (int)po : -1;
+          reinterpret_cast<int*>(slot)[S5_META + 32 + pt] = valid ? po : -1;
         } else if (g == 1) {
           const int k = pt;  // words 48..: chg lo, chg hi, hit lo, hit hi, validmask, -, -, -, hit bits of levels 0..3
           int v = 0;
@@ -745,7 +813,14 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
       // ---- rotate the pipeline registers
       cur = nxt, nxt = nx2, cia = nia, cib = nib, pm2 = pm3;
       if (++jk == K) jk = 0;
+      if (SHINE_V5_DYN && (j + 1) % CHD == 0) {  // on to the chunk claimed earlier; claim the one after it
+        ++kcur;
+        gc_cur = gc_next;
+        gc_next = claim();
+      }
     }
+    tiles_done = j;
+    if (SHINE_V5_DYN) *lds_word(sync + SY_TOTAL) = j;  // (after the last tile's publish: LDS writes of a wave are in order)
   } else {
     // ============================================================================================ S: scatter wave
     int run_id[LCAP], run_hit[LCAP];
@@ -759,13 +834,14 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
     if (SHINE_V5_PRIO) __builtin_amdgcn_s_setprio(3);
     int lane_o = lane;
     int jk = 0;
-    for (int j = 0; j < njobs; ++j) {
+    for (int j = 0;; ++j) {
+      if (!wait_tile(sync + SY_DPUB0 + (ND == 2 ? (j & 1) : 0), sync + SY_TOTAL, j, sync + SY_ERR, waited)) break;
+      ++tiles_done;
       asm volatile("" : "+v"(lane_o));
       float* const slot = ring + jk * SLOT;
       const int* const sc_ids = reinterpret_cast<const int*>(slot) + S5_IDS + (lane_o >> 3) * V3_WP;  // + s * 8 * V3_WP + point
       const float* const sc_w = slot + S5_W + (lane_o >> 3) * V3_WP;
       const float* const sc_df = slot + S5_DF + (lane_o & 7) * V3_DFP;
-      wait_ge(sync + SY_DPUB0 + (ND == 2 ? (j & 1) : 0), j + 1, sync + SY_ERR, waited);
       // the tile's masks (wave-uniform): one read, five lane broadcasts
       unsigned long long chg64, hit64;
       {
@@ -865,7 +941,7 @@ __global__ __launch_bounds__((ND + 2) * V5_PIPES * 64) void k_step_v5(V1Args a) 
   if (SHINE_V5_PROF && a.prof && lane == 0) {  // [role, tiles, setup, loop, of which polling, -, -, -] per wave
     const long long now = clk();
     long long* o = a.prof + ((long long)blockIdx.x * (V5_NT / 64) + wv) * 8;
-    o[0] = role, o[1] = njobs, o[2] = t_loop - t_start, o[3] = now - t_loop, o[4] = waited, o[5] = o[6] = o[7] = 0;
+    o[0] = role, o[1] = tiles_done * (role < ND ? ND : 1), o[2] = t_loop - t_start, o[3] = now - t_loop, o[4] = waited, o[5] = o[6] = o[7] = 0;
   }
   __syncthreads();  // every role is done with the ring: it now holds the partial vectors (8 decoder + 4 scatter waves)
   if (role < ND) {
