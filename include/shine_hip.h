@@ -56,9 +56,9 @@ typedef struct shine_step_config {
   int32_t sorted_input;    /* 0: visit the batch as given; 1: through perm[] (shine_plan_batch / shine_morton_sort);
                               2: POOL mode — coord/label/weight/slots are a node-ordered sample pool, perm[] holds the
                               batch's sorted sample indices (shine_sample_sorted), outputs are written at batch position */
-  int32_t kernel_variant;  /* low byte — 0: auto (fastest kernel that supports the config), 1: the simple v0 kernel
-                              (lane = point), 2: the 32-point-tile MFMA kernel, 3: the 16-point-tile MFMA kernel that hashes
-                              and probes itself, 4: the 16-point-tile kernel for planned / pool batches (lane = point x level) */
+  int32_t kernel_variant;  /* low byte — 0 (or 4): the fused step (shine_step_v3.hip: planned / pool batches, <= 4 featured
+                              levels).  The CHECK library (libshine_check.so, tests / tools only) adds 1: the lane-per-point
+                              reference kernel (any batch, <= 8 levels) and 5: the role-specialised experimental kernel */
   float sigma;             /* sigma_sigmoid = ratio*sigma_m*scale      (shine_batch.py:87) */
   float weight_e;          /* eikonal weight                           (config weight_e) */
   double inv_n;            /* 1/N_global for "mean", 1 for "sum"       */
@@ -151,8 +151,9 @@ int shine_mlp_backward_backward(const float* feat, const float* grad_pred, const
 /* ---- fused training step: query + decode + sdf_bce_loss (utils/loss.py:17-24) [+ eikonal
  *      (shine_batch.py:182-185)] + the whole backward (shine_batch.py:208-209) in one pass.
  *      Inputs : coord [N,3], sdf_label [N], weight [N] (sign = surface/free, data_sampler.py:102-103),
- *               perm [N] int32 or NULL (visiting order), slots [N,L] int32 or NULL (per point IN VISITING ORDER the
- *               hash slot of its node at each level, -1 = miss; both come from shine_plan_batch),
+ *               perm [N] int32 (visiting order) and slots [N,L] int32 (per point IN VISITING ORDER the hash slot of its
+ *               node at each level, -1 = miss): both come from shine_plan_batch, or the batch is a pool draw
+ *               (sorted_input 2).  A batch without slots is refused (SHINE_E_INVALID) by the product library,
  *               n_surf: device int64 (global #weight>0) or NULL when eikonal off.
  *      Outputs: pred [N]; grad_x [N,3] or NULL; grad_feats[s] [rows_s+1, 8] and grad_mlp[6]
  *               ACCUMULATED INTO (caller zero-fills; matches autograd's dense grads incl. the
@@ -300,10 +301,8 @@ int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* g
  *      The stamped build is a separate template instantiation: the product kernel carries no profiling code. -------- */
 void shine_debug_set_profile_buffer(int64_t* buffer);
 
-/* ---- device self-test: D[32,32] = A[32,2] . B[2,32] through ONE v_mfma_f32_32x32x2_f32, written back with the
+/* ---- device self-test: D[16,16] = A[16,4] . B[4,16] through ONE v_mfma_f32_16x16x4_f32, written back with the
  *      accumulator lane map the fused kernel relies on (pins the MFMA operand layouts on the hardware). --- */
-int shine_selftest_mfma(const float* a, const float* b, float* d, void* stream);
-/* the same for v_mfma_f32_16x16x4_f32 (the 16-point-tile kernel): D[16,16] = A[16,4] . B[4,16] */
 int shine_selftest_mfma16(const float* a, const float* b, float* d, void* stream);
 /* cross-lane exchanges of the lane = (point, level) kernel (shine_step_v3.hip), 64 lanes each: through
  *  v_permlane32_swap  o32[l] = l < 32 ? x[l] + x[l + 32] : y[l] + y[l - 32];

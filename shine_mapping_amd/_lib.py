@@ -8,6 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libshine_hip.so")
+# the product's objects + the lane-per-point reference step (kernel_variant 1) + the experimental role-specialised step
+# (kernel_variant 5): loaded by tests / tools only, never by the product path
+CHECK_LIB_PATH = os.path.join(_HERE, "lib", "libshine_check.so")
 
 MAX_LEVELS = 8
 FEATURE_DIM = 8
@@ -96,7 +99,6 @@ _SIGNATURES = {
     "shine_mark_touched": (C.c_int, [_P, C.POINTER(StepConfig), _P, _P, _P, C.c_int64, C.POINTER(C.c_int64),
                                      C.POINTER(_P), _P]),
     "shine_morton_sort": (C.c_int, [C.POINTER(StepConfig), _P, C.c_int64, _P, _P, C.POINTER(C.c_size_t), _P]),
-    "shine_selftest_mfma": (C.c_int, [_P, _P, _P, _P]),
     "shine_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
     "shine_selftest_permlane": (C.c_int, [_P, _P, _P, _P, _P]),
     "shine_debug_set_profile_buffer": (None, [_P]),
@@ -117,6 +119,7 @@ _SIGNATURES = {
 }
 
 _lib = None
+_check = None
 
 
 class ShineHipError(RuntimeError):
@@ -144,6 +147,24 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     _lib = h
+    return h
+
+
+def check_lib():
+    """The CHECK library (tests / tools only): same ABI, plus the kernels behind StepOptions.kernel_variant 1 and 5.  Table
+    handles are plain process memory with one layout in both libraries, so a handle made by one works in the other."""
+    global _check
+    if _check is not None:
+        return _check
+    if not os.path.isfile(CHECK_LIB_PATH):
+        raise ShineHipError("libshine_check.so not found at %s — `python -m shine_mapping_amd.build` builds it next to the "
+                            "product library" % CHECK_LIB_PATH)
+    h = C.CDLL(CHECK_LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.restype = res
+        fn.argtypes = args
+    _check = h
     return h
 
 

@@ -1,8 +1,14 @@
-"""Build libshine_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+"""Build the HIP libraries for gfx950 in-tree (hipcc cross-compiles without a GPU).
 
     python -m shine_mapping_amd.build [--force]
 
-The .so lands in shine_mapping_amd/lib/ (git-ignored, but it travels with the gpurun snapshot).
+  lib/libshine_hip.so    the PRODUCT: csrc/*.hip — the fused step (shine_step_v3.hip) and everything around it
+  lib/libshine_check.so  the product's objects + csrc/check/*.hip (the role-specialised experimental step) + the training
+                         instantiations of the lane-per-point kernel (shine_step_v0.hip -DSHINE_V0_TRAIN=1): the on-device
+                         cross-check of the GPU tests and the step for trees with more than 4 featured levels.  Only
+                         tests / tools load it (StepOptions.kernel_variant 1 / 5).
+
+Both land in shine_mapping_amd/lib/ (git-ignored, but they travel with the gpurun snapshot).
 """
 import hashlib
 import os
@@ -15,6 +21,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libshine_hip.so")
+CHECK_LIB = os.path.join(LIBDIR, "libshine_check.so")
+CHECK_DIR = os.path.join(CSRC, "check")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(os.path.dirname(HERE), "include")]
@@ -26,7 +34,7 @@ def sources():
 
 def _digest():
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + ["../../include/shine_hip.h"]:
+    for f in sorted(os.listdir(CSRC)) + ["check/" + g for g in sorted(os.listdir(CHECK_DIR))] + ["../../include/shine_hip.h"]:
         p = os.path.join(CSRC, f)
         if os.path.isfile(p):
             h.update(f.encode())
@@ -40,31 +48,45 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "libshine_hip.stamp")
     dig = _digest()
-    if not force and os.path.isfile(LIB) and os.path.isfile(stamp) and open(stamp).read() == dig:
+    if not force and os.path.isfile(LIB) and os.path.isfile(CHECK_LIB) and os.path.isfile(stamp) and open(stamp).read() == dig:
         return LIB
     if not os.path.isfile(HIPCC):
         raise RuntimeError("hipcc not found at %s; cannot build libshine_hip.so" % HIPCC)
 
-    def compile_one(src):
-        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    def compile_one(job):
+        src_path, obj, extra = job
+        cmd = [HIPCC] + FLAGS + extra + ["-c", src_path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+            raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src_path, r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
         return obj
 
+    product = [(os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace(".hip", ".o")), []) for src in sources()]
+    check_only = [(os.path.join(CHECK_DIR, src), os.path.join(OBJDIR, "check_" + src.replace(".hip", ".o")), [])
+                  for src in sorted(f for f in os.listdir(CHECK_DIR) if f.endswith(".hip"))]
+    v0_train = (os.path.join(CSRC, "shine_step_v0.hip"), os.path.join(OBJDIR, "check_shine_step_v0_train.o"),
+                ["-DSHINE_V0_TRAIN=1"])
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, sources()))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        objs = list(ex.map(compile_one, product + check_only + [v0_train]))
+    n = len(product)
+    product_objs, check_objs = objs[:n], objs[n:]
+
+    def link(out, inputs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + inputs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+
+    link(LIB, product_objs)
+    # the check library: the same objects, the forward-only shine_step_v0.o replaced by the one that also trains
+    v0_obj = os.path.join(OBJDIR, "shine_step_v0.o")
+    link(CHECK_LIB, [o for o in product_objs if o != v0_obj] + check_objs)
     open(stamp, "w").write(dig)
     return LIB
 

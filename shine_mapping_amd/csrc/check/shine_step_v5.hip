@@ -26,7 +26,7 @@
 // sequence counters in LDS (g_pub, d_pub[2], s_done per pipeline), polled with ds_read + s_sleep; DS operations of one
 // wave execute in order, so {data writes, s_waitcnt lgkmcnt(0), counter write} publishes a slot without any barrier.
 // Every spin is bounded (a broken hand-off poisons the loss with NaN instead of hanging the GPU).
-#include "shine_tile16.hpp"
+#include "../shine_tile16.hpp"
 
 namespace shine {
 

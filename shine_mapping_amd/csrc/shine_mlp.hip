@@ -11,7 +11,7 @@
 // recomputed from `feat` in every pass (8 floats in, nothing saved between passes); weight grads contract over the
 // wave's 64 points through LDS staging rows into lane-owned accumulators that live across the tile loop, summed over the
 // workgroup's four waves and flushed once per workgroup with fp32 atomics.
-// This tier keeps the reference's drivers unchanged; the benchmarked path is the fused step (shine_step_v1.hip).
+// This tier keeps the reference's drivers unchanged; the benchmarked path is the fused step (shine_step_v3.hip).
 #include "shine_internal.hpp"
 
 namespace shine {

@@ -7,7 +7,7 @@
 //             origin / per-axis bits come from the map's voxel bounding box, so the code has bx+by+bz
 //             significant bits (23 for a 100 m x 16 m x 10 m street at 0.2 m) instead of 3*tree_level_world = 36
 //             (only locality matters here: the fused kernel detects node runs by comparing corner ids)
-//   perm    = argsort(key) by rocPRIM onesweep radix sort over exactly those bits: ceil(bits/8) passes.
+//   perm    = argsort(key) by rocPRIM's radix sort over exactly those bits.
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -47,19 +47,13 @@ __global__ void k_sort_keys(const float* coord, long long n, float res, SortBox 
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// merge_sort_limit = 0 -> always onesweep.  Batches of a training iteration are 2^12..2^22 items: the stock
-// geometry (16 Ki items per workgroup) would put 2^18 items on 16 of the 256 CUs, so small batches get
-// 1 Ki-item workgroups; 8 radix bits per pass.
-using onesweep_small = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 4>, rocprim::kernel_config<256, 4>, 8>, 0>;
-using onesweep_large = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                  rocprim::default_config, 0>;
-
-template <typename K, typename Cfg>
+// ONE radix-sort instantiation (64-bit keys, rocPRIM's default configuration).  Rounds 1-2 carried four (32- / 64-bit keys x a
+// small-batch and a large-batch onesweep geometry): 3.5 MB of code object for a function the hot path no longer calls — a
+// batch is ordered by the counting sort of shine_plan.hip, ~2x faster than any radix sort at these sizes.
+template <typename K>
 static hipError_t run_sort(void* tmp, size_t& tmp_bytes, K* k0, K* k1, int* v0, int* v1, size_t n, unsigned end_bit,
                            hipStream_t st) {
-  return rocprim::radix_sort_pairs<Cfg>(tmp, tmp_bytes, k0, k1, v0, v1, n, 0u, end_bit, st);
+  return rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, n, 0u, end_bit, st);
 }
 
 template <typename K>
@@ -67,12 +61,8 @@ static int sort_impl(const float* coord, long long n, float res, const SortBox& 
                      void* workspace, size_t* workspace_bytes, hipStream_t st) {
   const unsigned end_bit = (unsigned)(box.bx + box.by + box.bz);
   const size_t cnt = (size_t)(n > 0 ? n : 1);
-  const bool small = n <= (1ll << 20);
   size_t tmp_bytes = 0;
-  SHINE_HIP_CHECK(small ? (run_sort<K, onesweep_small>(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, cnt,
-                                                       end_bit, st))
-                        : (run_sort<K, onesweep_large>(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, cnt,
-                                                       end_bit, st)));
+  SHINE_HIP_CHECK(run_sort<K>(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, cnt, end_bit, st));
   const size_t kb = align256(cnt * sizeof(K)), vb = align256(cnt * 4);
   const size_t need = 2 * kb + vb + align256(tmp_bytes);
   if (!workspace) {
@@ -88,9 +78,7 @@ static int sort_impl(const float* coord, long long n, float res, const SortBox& 
   void* tmp = w + 2 * kb + vb;
   hipLaunchKernelGGL((k_sort_keys<K>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, coord, n, res, box, k0, v0);
   SHINE_HIP_CHECK(hipGetLastError());
-  SHINE_HIP_CHECK(small ? (run_sort<K, onesweep_small>(tmp, tmp_bytes, k0, k1, v0, (int*)perm_out, (size_t)n, end_bit, st))
-                        : (run_sort<K, onesweep_large>(tmp, tmp_bytes, k0, k1, v0, (int*)perm_out, (size_t)n, end_bit,
-                                                       st)));
+  SHINE_HIP_CHECK(run_sort<K>(tmp, tmp_bytes, k0, k1, v0, (int*)perm_out, (size_t)n, end_bit, st));
   return SHINE_OK;
 }
 
@@ -114,7 +102,5 @@ extern "C" int shine_morton_sort(const shine_step_config* cfg, const float* coor
   box.bmin = box.bx < box.by ? (box.bx < box.bz ? box.bx : box.bz) : (box.by < box.bz ? box.by : box.bz);
   const float res = (float)(1u << ml);
   hipStream_t st = (hipStream_t)stream;
-  if (box.bx + box.by + box.bz <= 32)
-    return sort_impl<unsigned int>(coord, n, res, box, perm_out, workspace, workspace_bytes, st);
   return sort_impl<unsigned long long>(coord, n, res, box, perm_out, workspace, workspace_bytes, st);
 }

@@ -1,6 +1,6 @@
-// shine_step_common.hpp — what the fused-step kernels (shine_step_v1.hip: 32-point tiles; shine_step_v2.hip: 16-point
-// tiles) share: the kernel argument block, the layout of the per-workgroup partial vector that k_reduce_partials adds
-// up, and a few wave-level device helpers.
+// shine_step_common.hpp — what the fused-step kernels (shine_step_v3.hip; check/shine_step_v5.hip) and their support kernels
+// (shine_step_support.hip) share: the kernel argument block, the layout of the per-workgroup partial vector that
+// k_reduce_partials adds up, and a few wave-level device helpers.
 #pragma once
 #include "shine_internal.hpp"
 
@@ -12,9 +12,6 @@ constexpr int PART_TRASH = SHINE_MLP_PARAMS;                     // + s*8 + q
 constexpr int PART_FLOATS = PART_TRASH + SHINE_MAX_LEVELS * 8;   // 1441
 constexpr int PART_LOSS = 1444;   // float index of double[3] {bce sum, count, eikonal sum} (8-B aligned)
 constexpr int PART_STRIDE = 1456;
-// MFMAs issued per 32-point tile (v_mfma_f32_32x32x2_f32): forward 4 + 16, backward 16 + 16, weight grads 16 + 16;
-// the eikonal build replaces the backward pair by the closed-form chain 16 + 16 + 4 + 16 (checked against the ISA)
-constexpr int MFMA_PER_TILE_BCE = 84, MFMA_PER_TILE_EIK = 104;
 
 // what the hot loop needs per level, nothing else (SGPR budget)
 struct V1Level {
@@ -57,7 +54,8 @@ struct V1Args {
   int pool_mode;  // 1: coord/label/weight/slots are a node-ordered POOL indexed by perm[i] (sorted sample indices,
                   //    shine_sample_sorted); pred / grad_x are written at the batch position i.  0: a batch.
   int ablate;  // debug only (kernel_variant >> 8): 1 no feature atomics, 2 no weight-grad phase, 4 no scatter phase,
-               // 8 no row gathers, 16 no probe (every point misses), 32 skip the partial-sum reduction launch
+               // 8 no row gathers, 16 no probe (every point misses), 32 skip the partial-sum reduction launch,
+               // 64 deterministic accumulation: one wave of one workgroup walks the whole stream (tests)
   float sigma;
   float inv_n;
   float weight_e;
@@ -88,26 +86,20 @@ __device__ __forceinline__ Axis axis_weight_rt(bool poly, float x, float res) {
   return poly ? axis_weight<true>(x, res, res * 0.5f) : axis_weight<false>(x, res, res * 0.5f);
 }
 
-// launch geometry of the 16-point-tile kernel (shine_step_v2.hip)
+// launch geometry of a 16-point-tile kernel
 struct V2Geometry {
   long long waves, chunk, blocks, tiles;
-  int wg_waves;  // waves per workgroup: 16 (one workgroup per CU) or 4 (small batches)
+  int wg_waves;  // waves per workgroup
 };
-V2Geometry v2_geometry(long long n);
-long long v2_lds_bytes(int wg_waves);
 V2Geometry v3_geometry(long long n);  // shine_step_v3.hip: tiles dealt evenly to every resident wave slot
 long long v3_lds_bytes(int wg_waves);
 V2Geometry v5_geometry(long long n, bool eik);  // shine_step_v5.hip: 16-wave workgroups of 4 role-specialised pipelines
 long long v5_lds_bytes(bool eik);
-// true when the 16-point-tile kernel serves this configuration (and is the faster one): see shine_api.hip
-bool v2_serves(const shine_step_config* cfg);
-bool v3_serves(const shine_step_config* cfg, bool planned);
-bool v5_serves(const shine_step_config* cfg, bool planned, long long n);
 
 // measurement aid (shine_debug_set_profile_buffer): per-wave phase cycle counters or null
 extern long long* g_prof_buffer;
 
-// second stage of a fused step (shine_step_v1.hip): add `nblocks` per-workgroup partial vectors [PART_STRIDE floats each]
+// second stage of a fused step (shine_step_support.hip): add `nblocks` per-workgroup partial vectors [PART_STRIDE floats each]
 // into the gradient tensors / loss, re-zero the trash rows (set_zero, model/feature_octree.py:78-81)
 __global__ void k_reduce_partials(V1Args a, int nblocks);
 __global__ void k_mark_touched(V1Args a);

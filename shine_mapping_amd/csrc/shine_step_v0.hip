@@ -493,6 +493,10 @@ extern "C" int shine_forward(const shine_tables* t, const shine_step_config* cfg
   return SHINE_OK;
 }
 
+#ifndef SHINE_V0_TRAIN  // 1 in the check library (libshine_check.so): the lane-per-point kernel as the on-device cross-check of
+#define SHINE_V0_TRAIN 0  // the fused step and the step for trees with more than 4 featured levels; the product library
+#endif                    // instantiates the forward forms only (shine_forward)
+#if SHINE_V0_TRAIN
 extern "C" int shine_train_step_v0(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                                    const float* sdf_label, const float* weight, const int32_t* perm,
                                    const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,
@@ -544,3 +548,4 @@ extern "C" int shine_train_step_v0(const shine_tables* t, const shine_step_confi
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }
+#endif

@@ -5,24 +5,31 @@
 //   loss     sdf_bce_loss                  utils/loss.py:17-24
 //   backward cur_loss.backward()           shine_batch.py:208-209 (closed form, SURVEY.md §8a math contract)
 //
-// Same algorithm, staging layout and outputs as shine_step_v2.hip.  What the round-2 measurements said about v2
-// (profiles/r02_*): ~1100 VALU + ~600 scalar instructions per 16-point tile next to 68 MFMAs, and — the hardware fact that
-// decides the design — exact-fp32 MFMA and the VALU work of another wave do NOT overlap on a SIMD
-// (tools/ubench/mfma_valu_overlap.hip; SQ_VALU_MFMA_COEXEC_CYCLES = 0): the decoder's matrix work and every vector
+// One wave walks a 16-point tile of the node-ordered stream through every phase.  What the round-2 measurements decided
+// (profiles/r02_*): ~1100 VALU + ~600 scalar instructions per tile next to 68 MFMAs in the predecessor (lane = point x corner
+// pair), and — the hardware fact behind the design — exact-fp32 MFMA and the VALU work of another wave do NOT overlap on a
+// SIMD (tools/ubench/mfma_valu_overlap.hip; SQ_VALU_MFMA_COEXEC_CYCLES = 0): the decoder's matrix work and every vector
 // instruction queue for one fp32 datapath.  So this kernel removes instructions and trades waves for registers:
-//   * query: lane (pt, g) owns LEVEL g of point pt (v2: a corner pair of every level).  The per-level work — hash slot,
-//     node-run masks, smooth-step weights, offsets — is done ONCE per wave instruction instead of once per level; one
-//     slot / eight ids per lane; the node-run masks of all four levels come out of ONE 64-bit ballot; the run carry is a
-//     DPP row broadcast.  Each lane gathers the eight 32-B corner rows of its level (sixteen 16-B loads, four corners in
-//     flight at a time) and sums them with its eight weights; a reduce-scatter over g (v_permlane32_swap /
-//     v_permlane16_swap, gfx950) leaves features (2g, 2g+1) of the point in lane g — the B operand of layer 1, as in v2.
-//     Measured: 1084 -> 744 VALU instructions per tile (SQ_INSTS_VALU);
+//   * query: lane (pt, g) owns LEVEL g of point pt.  The per-level work — hash slot, node-run masks, smooth-step weights,
+//     offsets — is done ONCE per wave instruction instead of once per level; one slot / eight ids per lane; the node-run
+//     masks of all four levels come out of ONE 64-bit ballot; the run carry is a DPP row broadcast.  Each lane gathers the
+//     eight 32-B corner rows of its level (sixteen 16-B loads, four corners in flight at a time) and sums them with its
+//     eight weights; a reduce-scatter over g (v_permlane32_swap / v_permlane16_swap, gfx950) leaves features (2g, 2g+1) of
+//     the point in lane g — the B operand of layer 1.  Measured: 1084 -> 744 VALU instructions per tile (SQ_INSTS_VALU);
+//   * decoder: exact-fp32 v_mfma_f32_16x16x4_f32 chains whose accumulators ARE the next B operands (the k-order of each
+//     product is permuted to the accumulator row order of the previous one); weight grads through [32][20] LDS transposes
+//     into MFMA accumulators that live in registers for the whole kernel;
 //   * loss: hardware transcendentals (v_exp_f32 / v_rcp_f32 / v_log_f32) instead of libm forms: ~25 VALU, not ~190;
 //   * 8 waves per CU (2 per SIMD, <= 256 VGPRs) instead of 12: 69 vs 74.5 us — more waves do not help this kernel;
-//   * eikonal build (EIK): the closed-form chain of shine_step_v1.hip on 16-point tiles, 240 VGPRs, no spills;
-//   * decoder / weight grads / scatter / flush: as in v2 (the scatter prefetches its LDS operands one level ahead).
-// Planned or pool batches only (the hash slots come with the batch); a batch without a plan runs on k_step_v2 / v1, or is
-// planned first by the Python layer (StepOptions.auto_plan_min).
+//   * eikonal build (EIK): the closed-form chain of SURVEY.md §8a on the same tiles, 240 VGPRs, no spills;
+//   * scatter: lane = (corner, feature), run-length walk, one 64-lane atomic per node run; the staged operands of level
+//     s + 1 are requested before level s is walked;
+//   * flush: one partial vector per workgroup, added up by k_reduce_partials (shine_step_support.hip).
+// Round 3 (profiles/r03_ab_experiments.txt): role-specialised waves (check/shine_step_v5.hip), a prefix-sum scatter, interleaved
+// and claimed tile chunks were all built and measured against this kernel — none is faster; the slowest waves are the ones whose
+// tile range holds 4-6 x the mean number of node runs (tools/run_stats.py).
+// Planned or pool batches only (the hash slots come with the batch): the Python layer plans every batch that arrives without
+// an order (shine_plan_batch), the C entry point refuses one.
 #include "shine_tile16.hpp"
 
 namespace shine {
@@ -43,6 +50,9 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 #endif
 #ifndef SHINE_V3_PREDSCAT  // measurement builds only: branch-free run-length scatter (see phase 6)
 #define SHINE_V3_PREDSCAT 0
+#endif
+#ifndef SHINE_V3_PROFBUILD  // 1: also instantiate the kernels with per-wave phase cycle counters (AB_PROF of tools/ab_build.py)
+#define SHINE_V3_PROFBUILD 0
 #endif
 #ifndef SHINE_V3_CH  // measurement builds: > 0 = the stream is cut into chunks of this many tiles dealt round-robin to ALL waves of
 #define SHINE_V3_CH 0  // the launch (node runs restart at chunk borders); 0 = one contiguous range per wave
@@ -197,8 +207,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     const long long nt = t1 - t0;
     constexpr int HW = WAVES / 2;
     const long long cut = (WAVES >= 8 && nt >= 4 * WAVES) ? (nt * OLD_SHARE) >> 8 : nt / 2;  // tiles of waves [0, HW)
-    const long long lo = wv < HW ? (wv * cut) / HW : cut + ((wv - HW) * (nt - cut)) / HW;
-    const long long hi = wv < HW ? ((wv + 1) * cut) / HW : cut + ((wv - HW + 1) * (nt - cut)) / HW;
+    long long lo = wv < HW ? (wv * cut) / HW : cut + ((wv - HW) * (nt - cut)) / HW;
+    long long hi = wv < HW ? ((wv + 1) * cut) / HW : cut + ((wv - HW + 1) * (nt - cut)) / HW;
+    if (a.ablate & 64) {  // deterministic accumulation (tests): ONE wave of the one-workgroup launch walks the whole stream,
+      lo = wv == 0 ? 0 : nt;  // so every feature-grad atomic is issued — and applied — in stream order
+      hi = nt;
+    }
     begin = V3_TP * (t0 + lo);
     end_t = V3_TP * (t0 + hi);
   }
@@ -960,11 +974,13 @@ long long v3_lds_bytes(int wg_waves) {
 template <int L, bool EIK>
 static void launch_v3(const V1Args& a, const V2Geometry& g, hipStream_t st) {
   const dim3 grid((unsigned)g.blocks);
+#if SHINE_V3_PROFBUILD  // measurement builds only (tools/mk_variant.py -DSHINE_V3_PROFBUILD=1): the per-wave phase counters
   if (a.prof) {
     if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, EIK, true>), grid, dim3(V3_BIG * 64), 0, st, a);
     else hipLaunchKernelGGL((k_step_v3<L, 4, EIK, true>), grid, dim3(256), 0, st, a);
     return;
   }
+#endif
   if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, EIK, false>), grid, dim3(V3_BIG * 64), 0, st, a);
   else hipLaunchKernelGGL((k_step_v3<L, 4, EIK, false>), grid, dim3(256), 0, st, a);
 }
@@ -980,7 +996,7 @@ extern "C" int shine_selftest_permlane(const float* x, const float* y, float* o3
   return SHINE_OK;
 }
 
-// same contract as shine_train_step_v1 (shine_step_v1.hip); planned / pool batches, needs the workspace
+// the fused step behind shine_train_step (include/shine_hip.h): planned / pool batches, needs the workspace
 extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                                    const float* sdf_label, const float* weight, const int32_t* perm,
                                    const int32_t* slots, const int64_t* n_surf, int64_t n, const float* const* feats,
@@ -994,7 +1010,12 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
                           grad_x_out, grad_feats, grad_mlp, loss_parts, touched);
   if (rc != SHINE_OK) return rc;
   if (n == 0) return SHINE_OK;
-  const V2Geometry g = v3_geometry(n);
+  V2Geometry g = v3_geometry(n);
+  if (a.ablate & 64) {  // kernel_variant bit 0x4000: the deterministic (single-wave) launch of the test suite
+    g.blocks = 1;
+    g.wg_waves = 4;
+    g.waves = 4;
+  }
   a.tiles = g.tiles;
   a.waves_total = g.waves;
   a.prof = g_prof_buffer;

@@ -29,13 +29,12 @@ class StepOptions:
     ekional_loss_on: bool = False     # (sic) config key of the reference
     weight_e: float = 0.1
     loss_weight_on: bool = False      # BCEWithLogitsLoss(weight=|weight|), utils/loss.py:18-19 (False in all shipped yamls)
-    auto_plan_min: int = 65536        # a batch handed over WITHOUT an order / plan (the reference's get_batch) of at least
-                                      # this many points is planned first (shine_plan_batch: node order + hash slots, 3
-                                      # small launches) and runs on the planned-batch kernel; 0 switches it off
     n_global: Optional[int] = None    # global batch size under data parallelism (defaults to local N)
     decoder_grad_on: Optional[bool] = None  # default: any decoder parameter requires grad (freeze_model, tools.py:188)
-    kernel_variant: int = 0           # 0 auto; 1 the simple v0 kernel (on-device cross-check); 2 / 3 force the 32- /
-                                      # 16-point-tile MFMA kernel
+    deterministic: bool = False       # tests: ONE wave walks the whole batch, so the fp32 atomics of the feature-grad scatter are
+                                      # applied in stream order and two runs agree to the bit (hundreds of times slower)
+    kernel_variant: int = 0           # 0 the fused step; tests / tools: 1 the lane-per-point reference kernel, 5 the
+                                      # role-specialised experimental kernel (both in libshine_check.so)
 
 
 def eik_needs_count(opts) -> bool:
@@ -144,10 +143,13 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
     coord = octree._check_coord(coord.detach())
     n = idx.numel() if pool_mode else coord.shape[0]
     dev = coord.device
-    if (not pool_mode and perm is None and slots is None and opts.auto_plan_min and n >= opts.auto_plan_min
-            and (int(opts.kernel_variant) & 0xff) in (0, 4) and octree.featured_level_num <= 4):
-        # an unordered batch: neighbouring lanes hit unrelated nodes.  Measured (tools/unordered_bench.py, whole call): 2^18
-        # points x 4 levels 320 -> 143 us, 2^20 x 3 with the eikonal term 889 -> 447 us; break-even at 32-64 k points
+    variant = int(opts.kernel_variant) & 0xff
+    if not pool_mode and slots is None and variant != 1 and octree.featured_level_num <= 4:
+        # a batch without a plan (what the reference's get_batch hands over): neighbouring lanes would hit unrelated nodes and
+        # the fused kernel takes the hash slots from the plan — order it by octree node and look the slots up first
+        # (shine_plan_batch: 3 small launches; measured at 2^18 points x 4 levels 320 -> 143 us for the whole call against
+        # in-kernel probing of the unordered batch, tools/unordered_bench.py).  A caller's own `perm` without slots (e.g.
+        # dp.morton_order) is replaced by the plan's node order: the step does not depend on the visiting order.
         from .dp import plan_batch
 
         perm, slots = plan_batch(octree, coord)
@@ -169,7 +171,8 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         sigma=float(opts.sigma), weight_e=float(opts.weight_e), eikonal_on=1 if eik else 0,
         reduction_sum=1 if opts.loss_reduction == "sum" else 0, decoder_grad_on=1 if dec_grad else 0,
         sorted_input=2 if pool_mode else (0 if perm is None else 1), n_global=n_global,
-        kernel_variant=int(opts.kernel_variant), loss_weight_on=1 if opts.loss_weight_on else 0,
+        kernel_variant=int(opts.kernel_variant) | (0x4000 if getattr(opts, "deterministic", False) else 0),
+        loss_weight_on=1 if opts.loss_weight_on else 0,
         inv_n=(1.0 if opts.loss_reduction == "sum" else 1.0 / max(n_global, 1)),
     )
     if eik and n_surf is None:
@@ -187,8 +190,11 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
                                                     and slots.numel() == n * octree.featured_level_num):
         raise ValueError("slots must come with perm from dp.plan_batch: CUDA int32 [N, L]")
     ws = _workspace(dev, cfg)
+    # the product library serves kernel_variant 0 / 4 on <= 4 levels; the reference kernel (1), the experimental kernel (5)
+    # and deeper trees need the check library (tests / tools)
+    library = _lib.check_lib() if (variant in (1, 5) or octree.featured_level_num > 4) else _lib.lib()
     _lib.check(
-        _lib.lib().shine_train_step(
+        library.shine_train_step(
             t.handle, C.byref(cfg), coord.data_ptr(), sdf_label.data_ptr(),
             weight.data_ptr() if weight is not None else None,
             perm.data_ptr() if perm is not None else None,

@@ -83,3 +83,18 @@ def oracle_from_product(octree, dec, cfg):
     mlp = so.OracleDecoder(ocfg)
     mlp.load_state_dict({k: v.detach().cpu() for k, v in dec.state_dict().items()})
     return ocfg, oct_, mlp
+
+
+def feat_grads_of_the_fused_terms(fx):
+    """Feature grads of a fixture WITHOUT the regulariser term, from the CPU oracle (fp32, the reference's op sequence).
+
+    The fixtures of the incremental configuration were recorded with the regulariser in the loss.  Its gradient cancels
+    exactly in exact arithmetic (features_last_frame is an attached clone of the Parameter, model/feature_octree.py:160), but
+    in fp32 the reference adds and subtracts lambda_forget = 1e4 times the importance and keeps ~1e-4..3e-4 (of max-abs) of
+    rounding noise in its recorded grads.  The HIP path computes the fused terms only, so it is held to THIS clean value at
+    the contract's 1e-4, and to the recorded grads at 1e-4 + the recorded grads' own distance from the clean value."""
+    from oracle import shine_oracle as so
+
+    ocfg, oct_, mlp = oracle_from_golden(fx)
+    out = so.train_step(oct_, mlp, fx["coord"], fx["sdf_label"], fx["weight"], ocfg, regularize=False)
+    return out["feat_grads"]

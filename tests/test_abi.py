@@ -104,3 +104,25 @@ def test_dropin_registers_the_reference_import_paths():
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_product_library_holds_the_fused_step_only_and_the_check_library_the_rest():
+    """the product library ships ONE fused-step kernel generation.  The lane-per-point reference kernel
+    (kernel_variant 1) and the experimental role-specialised kernel (5) live in libshine_check.so, which tests / tools load
+    explicitly; the product's dispatcher refuses those variants (and unplanned batches) instead of silently falling back."""
+    from shine_mapping_amd import _lib, build
+
+    build.build(verbose=False)
+    prod, chk = ctypes.CDLL(build.LIB), ctypes.CDLL(build.CHECK_LIB)
+    assert hasattr(prod, "shine_train_step_v3") and not hasattr(prod, "shine_train_step_v0") and not hasattr(prod, "shine_train_step_v5")
+    assert hasattr(chk, "shine_train_step_v0") and hasattr(chk, "shine_train_step_v5") and hasattr(chk, "shine_train_step_v3")
+    for gone in ("shine_train_step_v1", "shine_train_step_v2"):
+        assert not hasattr(prod, gone) and not hasattr(chk, gone)
+    cfg = _lib.StepConfig()
+    cfg.n_levels, cfg.max_level = 3, 12
+    lib = _lib.lib()
+    for variant, word in ((1, b"check library"), (5, b"check library"), (0, b"plan")):
+        cfg.kernel_variant = variant
+        rc = lib.shine_train_step(None, ctypes.byref(cfg), None, None, None, None, None, None, 16, None, None, None, None,
+                                  None, None, None, None, None, None, 0, None)
+        assert rc == -1 and word in lib.shine_error_string(rc), (variant, lib.shine_error_string(rc))

@@ -8,7 +8,7 @@ gradient tensors <= 1e-4 of the tensor's max-abs (fp32 atomics reorder the sums)
 import pytest
 import torch
 
-from conftest import load_golden, oracle_from_golden, product_from_golden
+from conftest import feat_grads_of_the_fused_terms, load_golden, oracle_from_golden, product_from_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -84,10 +84,12 @@ def test_fused_train_step_matches_reference(golden):
     if "eikonal" in ref["parts"]:
         expect = expect + golden["cfg"]["weight_e"] * ref["parts"]["eikonal"].double()
     assert abs(float(loss) - float(expect)) <= TOL * max(1.0, abs(float(expect)))
-    # with the regulariser the reference's recorded grads carry ~1e-4 of cancellation noise (see test_oracle)
-    gtol = 3e-4 if golden["regularize"] else TOL
-    for k, r in enumerate(ref["feat_grads"]):
-        assert rel_err(octree.hier_features[k].grad, r) <= gtol, "feature grad level %d" % k
+    # with the regulariser the reference's RECORDED grads carry ~1e-4 of cancellation noise of their own: hold the HIP path to
+    # the clean fused-term grads at TOL, and to the recorded ones at TOL + their distance from the clean value
+    clean = feat_grads_of_the_fused_terms(golden) if golden["regularize"] else ref["feat_grads"]
+    for k, (r, c) in enumerate(zip(ref["feat_grads"], clean)):
+        assert rel_err(octree.hier_features[k].grad, c) <= TOL, "feature grad level %d" % k
+        assert rel_err(octree.hier_features[k].grad, r) <= TOL + rel_err(r, c), "feature grad level %d (recorded)" % k
     for k, (p, r) in enumerate(zip(dec.fused_params(), ref["mlp_grads"])):
         assert rel_err(p.grad, r) <= TOL, "decoder grad %d" % k
 
@@ -213,26 +215,10 @@ def test_morton_sort_is_a_permutation_in_key_order_and_step_is_order_invariant()
         assert rel_err(octree.hier_features[k].grad, r) <= TOL
 
 
-def test_mfma_lane_maps_on_hardware():
-    """D = A.B through one v_mfma_f32_32x32x2_f32 with the operand/accumulator maps the fused kernel assumes
-    (asymmetric random A and B so a transposed read or write cannot pass)."""
-    from shine_mapping_amd import _lib
-
-    g = torch.Generator().manual_seed(0)
-    A = torch.randn(32, 2, generator=g)
-    B = torch.randn(2, 32, generator=g)
-    d = torch.zeros(32, 32, device="cuda")
-    Ad, Bd = A.cuda(), B.cuda()
-    _lib.check(_lib.lib().shine_selftest_mfma(Ad.data_ptr(), Bd.data_ptr(), d.data_ptr(),
-                                              torch.cuda.current_stream().cuda_stream), "shine_selftest_mfma")
-    torch.cuda.synchronize()
-    assert torch.allclose(d.cpu(), A @ B, atol=1e-6)
-
-
 @pytest.mark.parametrize("levels,n", [(3, 1 << 14), (4, 1 << 18)])
-def test_v1_against_v0_at_scale_and_grad_checksum(levels, n):
-    """BASELINE-size batch (2^18 points, 4 levels): the MFMA/run-length kernel vs the simple v0 kernel on the same
-    device inputs, plus a size-independent property: per level, the column sums of the feature-grad table
+def test_fused_step_against_the_reference_kernel_at_scale_and_grad_checksum(levels, n):
+    """BASELINE-size batch (2^18 points, 4 levels): the fused MFMA / run-length step (the batch is planned automatically) vs
+    the lane-per-point reference kernel of the check library on the same device inputs, plus a size-independent property: per level, the column sums of the feature-grad table
     (trash row included) equal sum_p d loss/d f_p up to rounding, because the 8 corner weights sum to 1 — so
     every level must report the SAME column sums ("checksum of checksums")."""
     from shine_mapping_amd import StepOptions, dp, fused_train_step, synth
@@ -308,9 +294,12 @@ def test_tier_a_drop_in_loop_matches_reference(golden):
     assert abs(float(cur_loss.detach()) - float(ref["loss"])) <= TOL * max(1.0, abs(float(ref["loss"])))
     if eik:
         assert rel_err(g, ref["g"]) <= TOL
-    gtol = 3e-4 if golden["regularize"] else TOL
-    for k, r in enumerate(ref["feat_grads"]):
-        assert rel_err(octree.hier_features[k].grad, r) <= gtol, "feature grad level %d" % k
+    # This loop runs the regulariser too (torch ops on the attached clone, like the reference): its gradient cancels only up to
+    # fp32 rounding of terms lambda_forget = 1e4 times larger than what remains — on BOTH sides.  The budget is the contract's
+    # TOL plus twice the recorded grads' own distance from the clean fused-term grads (the reference's noise and ours).
+    clean = feat_grads_of_the_fused_terms(golden) if golden["regularize"] else ref["feat_grads"]
+    for k, (r, cg) in enumerate(zip(ref["feat_grads"], clean)):
+        assert rel_err(octree.hier_features[k].grad, r) <= TOL + 2 * rel_err(r, cg), "feature grad level %d" % k
     for k, (p, r) in enumerate(zip(dec.fused_params(), ref["mlp_grads"])):
         assert rel_err(p.grad, r) <= TOL, "decoder grad %d" % k
 
@@ -911,9 +900,11 @@ def test_graphed_iteration_matches_eager_loop(mode):
             octree._reg_grad_on = [True] * cfg.tree_level_feat  # exercise the regulariser's gradient path too
         opt = setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())
         octree._require_tables(with_ranks=True)
+        # canonical: the samples of a node in pool-index order (the plan leaves them in atomic-retirement order, which differs
+        # from one build of the pool to the next — the same indices would then draw different samples in the two loops)
         pool = SortedPool(octree, fx["coord"].cuda().repeat(8, 1), fx["sdf_label"].cuda().repeat(8),
-                          fx["weight"].cuda().repeat(8), seed=5)
-        opts = StepOptions(sigma=fx["sigma"], loss_reduction="sum" if incremental else "mean")
+                          fx["weight"].cuda().repeat(8), seed=5, canonical=True)
+        opts = StepOptions(sigma=fx["sigma"], loss_reduction="sum" if incremental else "mean", deterministic=True)
         return cfg, octree, dec, opt, pool, opts
 
     # eager reference loop (host-side stream ids 0..K-1, host-side step count)
@@ -942,17 +933,19 @@ def test_graphed_iteration_matches_eager_loop(mode):
     assert all(torch.equal(a, b) for a, b in zip(seen, eager_idx[1:])), "replays must draw the eager loop's batches"
     assert not torch.equal(seen[0], seen[1])
     assert opt2.steps_taken() == K and float(loss) == float(loss)
-    # Parameters are NOT compared element-wise: Adam's first steps move an element by lr * sign(g), and for elements whose
-    # gradient is a near-cancelling sum the sign is decided by the order of the atomics — two runs of the SAME eager loop
-    # differ by 0.1 of max-abs after one step (the reference on CUDA has the same property).  What must agree: the
-    # well-conditioned decoder weights and the loss both models reach on a common probe batch.
+    # Both loops run the step in its DETERMINISTIC mode (StepOptions.deterministic: one wave walks the batch, the feature-grad
+    # atomics are applied in stream order), so graph replay and eager launches must produce the same parameters — not "within
+    # the noise of the atomics' order" (Adam's first steps move an element by lr * sign(g), and a near-cancelling gradient sum
+    # takes its sign from that order: without the mode two runs of the SAME loop differ by 0.02-0.05 of max-abs).
     for a, b in zip(eager_mlp, dec2.fused_params()):
-        assert rel_err(b.detach(), a) <= 0.1  # (observed 0.02-0.05 between runs of the same loop: atomics order + Adam's sign)
+        assert rel_err(b.detach(), a) <= 1e-6
+    for a, b in zip(eager_feats, octree2.hier_features):
+        assert rel_err(b.detach(), a) <= 1e-6
     probe = eager_idx[0]
-    opts_probe = StepOptions(sigma=opts.sigma, loss_reduction=opts.loss_reduction)
+    opts_probe = StepOptions(sigma=opts.sigma, loss_reduction=opts.loss_reduction, deterministic=True)
     l1, _, _ = fused_train_step(octree, dec, None, None, None, opts_probe, pool=pool, idx=probe)
     l2, _, _ = fused_train_step(octree2, dec2, None, None, None, opts_probe, pool=pool2, idx=probe)
-    assert abs(float(l1) - float(l2)) <= 0.05 * abs(float(l1))
+    assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l1))
     # growth invalidates the captured pointers
     octree2.update(torch.tensor([[0.31, 0.27, -0.11], [0.33, 0.27, -0.11]]).cuda())
     with pytest.raises(RuntimeError, match="GraphedIteration"):

@@ -51,7 +51,7 @@ for kind, pts, lv in CASES:
     res = {}
     for rep in range(4):
         for name, h in zip(paths, handles):
-            _lib._lib = h
+            _lib._lib = _lib._check = h
             o.kernel_variant = 0x2000 | kvar[name]
             for _ in range(5):
                 fused_train_step(octree, dec, None, None, None, o, n_surf=ns, pool=sp, idx=idx)
@@ -66,7 +66,7 @@ for kind, pts, lv in CASES:
     o1 = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=cfg.ekional_loss_on, weight_e=cfg.weight_e)
     ref = None
     for name, h in zip(paths, handles):
-        _lib._lib = h
+        _lib._lib = _lib._check = h
         o1.kernel_variant = kvar[name]
         for p in params:
             p.grad.zero_()
@@ -83,7 +83,7 @@ for kind, pts, lv in CASES:
         buf = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
         names = ["setup", "query", "dec fwd", "loss+dec bwd", "scatter", "wgrad", "flush", "block wait"]
         for name, h in zip(paths, handles):
-            _lib._lib = h
+            _lib._lib = _lib._check = h
             o.kernel_variant = 0x2000 | kvar[name]
             h.shine_debug_set_profile_buffer(buf.data_ptr())
             buf.zero_()

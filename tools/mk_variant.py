@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Build a VARIANT of libshine_hip.so for an in-process A/B on the GPU box (tools/ab_build.py):
 
-    python tools/mk_variant.py NAME [-DMACRO=1 ...] [--src shine_step_v2.hip ...]
+    python tools/mk_variant.py NAME [-DMACRO=1 ...] [shine_step_v3.hip ...]
 
-recompiles the named sources (default: the two fused-step kernels) with the extra flags, links them with the other
-objects of the current build (shine_mapping_amd/build/*.o) and writes tools/ab/lib_NAME.so (git-ignored; it travels
-with the gpurun snapshot)."""
+recompiles the named sources (default: shine_step_v3.hip; files of csrc/check/ by their bare name) with the extra flags,
+links them with the other objects of the current build (shine_mapping_amd/build/*.o) and writes tools/ab/lib_NAME.so
+(git-ignored; it travels with the gpurun snapshot)."""
 import os
 import subprocess
 import sys
@@ -16,16 +16,23 @@ from shine_mapping_amd import build as b  # noqa: E402
 
 name = sys.argv[1]
 flags = [a for a in sys.argv[2:] if a.startswith("-")]
-srcs = [a for a in sys.argv[2:] if a.endswith(".hip")] or ["shine_step_v2.hip", "shine_step_v1.hip"]
+srcs = [a for a in sys.argv[2:] if a.endswith(".hip")] or ["shine_step_v3.hip"]
 b.build(verbose=False)
 out_dir = os.path.join(ROOT, "tools", "ab")
 os.makedirs(out_dir, exist_ok=True)
+# a variant has the composition of the CHECK library (product objects + csrc/check/*.hip + the training build of
+# shine_step_v0.hip), so kernel_variant 1 / 5 work against it too
+jobs = [(os.path.join(b.CSRC, f), os.path.join(b.OBJDIR, f.replace(".hip", ".o")), [], f) for f in b.sources()
+        if f != "shine_step_v0.hip"]
+jobs += [(os.path.join(b.CHECK_DIR, f), os.path.join(b.OBJDIR, "check_" + f.replace(".hip", ".o")), [], f)
+         for f in sorted(os.listdir(b.CHECK_DIR)) if f.endswith(".hip")]
+jobs.append((os.path.join(b.CSRC, "shine_step_v0.hip"), os.path.join(b.OBJDIR, "check_shine_step_v0_train.o"),
+             ["-DSHINE_V0_TRAIN=1"], "shine_step_v0.hip"))
 objs = []
-for src in b.sources():
-    obj = os.path.join(b.OBJDIR, src.replace(".hip", ".o"))
-    if src in srcs:
-        obj = os.path.join(out_dir, "%s_%s.o" % (name, src.replace(".hip", "")))
-        subprocess.check_call([b.HIPCC] + b.FLAGS + flags + ["-c", os.path.join(b.CSRC, src), "-o", obj])
+for path, obj, extra, fname in jobs:
+    if fname in srcs:
+        obj = os.path.join(out_dir, "%s_%s.o" % (name, fname.replace(".hip", "")))
+        subprocess.check_call([b.HIPCC] + b.FLAGS + extra + flags + ["-c", path, "-o", obj])
     objs.append(obj)
 lib = os.path.join(out_dir, "lib_%s.so" % name)
 subprocess.check_call([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)

@@ -18,7 +18,9 @@ lib_path, script = os.path.abspath(sys.argv[1]), sys.argv[2]
 if not os.path.isfile(lib_path):
     raise SystemExit("no such library: %s" % lib_path)
 _lib.LIB_PATH = lib_path
+_lib.CHECK_LIB_PATH = lib_path  # a variant has the check library's composition (tools/mk_variant.py)
 _lib._lib = None
+_lib._check = None
 print("[run_with_lib] %s" % lib_path, file=sys.stderr)
 if script == "-m":  # python tools/run_with_lib.py LIB -m pytest tests -m gpu -k regul
     sys.argv = sys.argv[3:]

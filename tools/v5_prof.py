@@ -17,7 +17,7 @@ h = C.CDLL(os.path.abspath(lib))
 for name, (res, args) in _lib._SIGNATURES.items():
     fn = getattr(h, name)
     fn.restype, fn.argtypes = res, args
-_lib._lib = h
+_lib._lib = _lib._check = h
 PTS = {"maicity": 1 << 18, "kitti": 1 << 20}
 for case in cases:
     kind, lv = case.split(":")
