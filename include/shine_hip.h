@@ -115,7 +115,9 @@ int shine_query_indices(const shine_tables* t, const shine_step_config* cfg, con
  *      feats: host array of L device pointers (top-down), rows: host array of L row counts
  *      (without the trash row).  mlp: 6 device pointers W1,b1,W2,b2,w3,b3 (host array).
  *      Any of feat_out [N,8], pred_out [N], idx_out (as above), grad_x_out [N,3]
- *      (= d pred / d coord * sigma, utils/tools.py:175-185) may be NULL. ---------------------- */
+ *      (= d pred / d coord * sigma, utils/tools.py:175-185) may be NULL.
+ *      Like query_feature (set_zero, :78-81,238) the call re-zeroes the trash row feats[s][rows[s]] of every level —
+ *      the one write through the `feats` pointers. ------------------------------------------------------------- */
 int shine_forward(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,
                   const float* const* feats, const int64_t* rows, const float* const* mlp, float* feat_out,
                   float* pred_out, int64_t* const* idx_out, float* grad_x_out, void* stream);
@@ -147,6 +149,18 @@ int shine_mlp_backward(const float* feat, const float* grad_pred, int64_t n, con
                        float* grad_feat_out, float* const* grad_mlp, void* stream);
 int shine_mlp_backward_backward(const float* feat, const float* grad_pred, const float* gg_feat, int64_t n,
                                 const float* const* mlp, float* grad_gpred_out, float* const* grad_mlp, void* stream);
+
+/* ---- Tier A, fused: backward of { FeatureOctree.query_feature (model/feature_octree.py:237-244) -> Decoder.sdf
+ *      (model/decoder.py:49-63) } for a given grad_pred [N] = d loss / d pred — what autograd derives for
+ *      cur_loss.backward() (shine_batch.py:208-209) through those two calls when the driver is unchanged: decoder
+ *      backward, decoder weight grads and the interpolation backward with the run-merged scatter in ONE fused launch
+ *      (+ the partial-sum reduction).  The batch must be planned (perm, slots: shine_plan_batch); grad_pred is indexed like
+ *      the batch.  grad_feats[s] [rows_s+1, 8] and grad_mlp[6] (NULL entries / cfg->decoder_grad_on = 0: skipped) are
+ *      ACCUMULATED INTO.  No loss options: the loss is the caller's (any torch code). ------------------------------------ */
+int shine_interp_sdf_backward(const shine_tables* t, const shine_step_config* cfg, const float* coord, const int32_t* perm,
+                              const int32_t* slots, const float* grad_pred, int64_t n, const float* const* feats,
+                              const int64_t* rows, const float* const* mlp, float* const* grad_feats,
+                              float* const* grad_mlp, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- fused training step: query + decode + sdf_bce_loss (utils/loss.py:17-24) [+ eikonal
  *      (shine_batch.py:182-185)] + the whole backward (shine_batch.py:208-209) in one pass.

@@ -71,6 +71,11 @@ _SIGNATURES = {
         [_P, C.POINTER(StepConfig), _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64),
          C.POINTER(_P), _P, _P, C.POINTER(_P), C.POINTER(_P), _P, C.POINTER(_P), _P, C.c_size_t, _P],
     ),
+    "shine_interp_sdf_backward": (
+        C.c_int,
+        [_P, C.POINTER(StepConfig), _P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P),
+         C.POINTER(_P), C.POINTER(_P), _P, C.c_size_t, _P],
+    ),
     "shine_regularize": (
         C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                   C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_float, _P, _P]),

@@ -1,9 +1,14 @@
-"""Tier A: FeatureOctree.query_feature as a twice-differentiable torch.autograd.Function.
+"""The autograd nodes behind the reference's class surface.
 
-The reference builds the interpolation out of ~30 torch ops per level and lets autograd differentiate it,
-twice when the eikonal term is on (get_gradient(create_graph=True), utils/tools.py:175-185).  Here forward,
-backward and backward-of-backward are one HIP kernel each (shine_forward / shine_interp_backward /
-shine_interp_backward_backward); the Decoder stays a torch composite, so the reference drivers run unchanged.
+Tier A (strict drop-in): the reference builds the interpolation out of ~30 torch ops per level and lets
+autograd differentiate it, twice when the eikonal term is on (get_gradient(create_graph=True), utils/tools.py:175-185).
+Here `FeatureOctree.query_feature` is OctreeInterp and `Decoder.sdf` is FusedMLP: forward, backward and
+backward-of-backward are one HIP kernel each.  When the drivers' usual sequence `feature = octree.query_feature(coord);
+pred = geo_mlp.sdf(feature)` (shine_batch.py:123-124) reaches `sdf` with the feature tensor untouched and no gradient is
+wanted for `coord`, the two calls collapse into ONE node, FusedInterpSdf, whose backward is one fused launch (the Tier-B
+kernel fed with autograd's d loss / d pred) — the split nodes remain the fallback for everything else.
+
+Tier B: ShineTrainStep — the whole iteration (query, decode, loss, backward) as one node.
 """
 from __future__ import annotations
 
@@ -128,10 +133,11 @@ class FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, *mlp):
         f = _f32c(feat)
+        w = [_f32c(p) for p in mlp]  # alive across the launch: a temporary's block could be handed out again under it
         n = f.shape[0]
         pred = torch.empty(n, dtype=torch.float32, device=f.device)
         _lib.check(
-            _lib.lib().shine_mlp_forward(f.data_ptr(), n, _lib.ptr_array([_f32c(p).data_ptr() for p in mlp]),
+            _lib.lib().shine_mlp_forward(f.data_ptr(), n, _lib.ptr_array([p.data_ptr() for p in w]),
                                          pred.data_ptr(), _stream()),
             "shine_mlp_forward",
         )
@@ -157,6 +163,7 @@ class FusedMLPBackward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, feat, want_feat, want_w, *mlp):
         f, gc = _f32c(feat), _f32c(g)
+        w = [_f32c(p) for p in mlp]
         n = f.shape[0]
         dev = f.device
         grad_feat = torch.empty((n, 8), dtype=torch.float32, device=dev) if want_feat else None
@@ -164,7 +171,7 @@ class FusedMLPBackward(torch.autograd.Function):
             if want_w else None
         _lib.check(
             _lib.lib().shine_mlp_backward(
-                f.data_ptr(), gc.data_ptr(), n, _lib.ptr_array([_f32c(p).data_ptr() for p in mlp]),
+                f.data_ptr(), gc.data_ptr(), n, _lib.ptr_array([p.data_ptr() for p in w]),
                 grad_feat.data_ptr() if want_feat else None,
                 _lib.ptr_array([t.data_ptr() for t in gw]) if want_w else None, _stream(),
             ),
@@ -191,13 +198,14 @@ class FusedMLPBackward(torch.autograd.Function):
         if not (need_g or need_w):
             return none
         f, gc, r = _f32c(feat), _f32c(g), _f32c(gg_feat)
+        w = [_f32c(p) for p in mlp]
         n = f.shape[0]
         grad_g = torch.empty(n, dtype=torch.float32, device=f.device) if need_g else None
         gw = [torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in mlp] \
             if need_w else None
         _lib.check(
             _lib.lib().shine_mlp_backward_backward(
-                f.data_ptr(), gc.data_ptr(), r.data_ptr(), n, _lib.ptr_array([_f32c(p).data_ptr() for p in mlp]),
+                f.data_ptr(), gc.data_ptr(), r.data_ptr(), n, _lib.ptr_array([p.data_ptr() for p in w]),
                 grad_g.data_ptr() if need_g else None,
                 _lib.ptr_array([t.data_ptr() for t in gw]) if need_w else None, _stream(),
             ),
@@ -207,6 +215,93 @@ class FusedMLPBackward(torch.autograd.Function):
             else (None,) * len(mlp)
         # inputs: g, feat, want_feat, want_w, *mlp   (relu masks are piecewise constant: nothing flows to feat)
         return (grad_g, None, None, None) + grads
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Tier A, fused across the query_feature -> sdf boundary
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class FeatureSource:
+    """What FeatureOctree.query_feature remembers about the tensor it returned (attached as `feature._shine_src`): enough for
+    Decoder.sdf to recognise "the untouched output of query_feature" and run the fused node instead of the split ones."""
+
+    __slots__ = ("octree", "coord", "version", "epoch")
+
+    def __init__(self, octree, coord, feature):
+        self.octree, self.coord = octree, coord
+        self.version = feature._version
+        self.epoch = octree._tables_epoch
+
+    def fusable(self, feature) -> bool:
+        return (feature._version == self.version and self.octree._tables_epoch == self.epoch
+                and not self.coord.requires_grad and self.octree.featured_level_num <= 4
+                and feature.dim() == 2 and feature.shape[0] == self.coord.shape[0] and feature.shape[0] > 0)
+
+
+class FusedInterpSdf(torch.autograd.Function):
+    """pred = Decoder.sdf(FeatureOctree.query_feature(coord)) as ONE node (shine_batch.py:123-124 with the drivers unchanged).
+
+    forward: the decoder forward on the features query_feature already computed (shine_mlp_forward).  backward(g): the batch
+    is planned (shine_plan_batch: node order + hash slots) and ONE fused launch (shine_interp_sdf_backward: the Tier-B
+    kernel with d loss / d pred = g) produces every gradient — decoder backward, decoder weight grads, interpolation
+    backward with one atomic per node run — into views of one freshly zeroed flat buffer, which autograd adopts as `.grad`
+    (no per-table zeros_like, no index_put).  No gradient for coord (Decoder.sdf only picks this node when coord does not
+    ask for one) and no double backward: the eikonal configurations stay on the split nodes."""
+
+    @staticmethod
+    def forward(ctx, feat_values, coord, octree, *params):
+        L = octree.featured_level_num
+        mlp = [_f32c(p) for p in params[L:]]  # kept alive across the launch (a temporary's block could be re-used under it)
+        f = _f32c(feat_values)
+        n = f.shape[0]
+        pred = torch.empty(n, dtype=torch.float32, device=f.device)
+        _lib.check(_lib.lib().shine_mlp_forward(f.data_ptr(), n, _lib.ptr_array([p.data_ptr() for p in mlp]), pred.data_ptr(),
+                                                _stream()), "shine_mlp_forward")
+        ctx.octree = octree
+        ctx.save_for_backward(coord, *params)
+        return pred
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .dp import plan_batch
+        from .ops import _workspace
+
+        coord, *params = ctx.saved_tensors
+        octree = ctx.octree
+        L = octree.featured_level_num
+        feats, mlp = params[:L], params[L:]
+        need_f = [bool(x) for x in ctx.needs_input_grad[3:3 + L]]
+        need_m = any(ctx.needs_input_grad[3 + L:])
+        t = octree._require_tables(with_ranks=True)
+        c = octree._check_coord(coord.detach())
+        n = c.shape[0]
+        dev = c.device
+        g = _f32c(g)
+        perm, slots = plan_batch(octree, c)
+        sizes = [p.numel() if nf else 0 for p, nf in zip(feats, need_f)] + [p.numel() if need_m else 0 for p in mlp]
+        flat = torch.zeros((sum(sizes) + 3) // 4 * 4, dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for p, sz in zip(params, sizes):
+            views.append(flat[off:off + sz].view_as(p) if sz else None)
+            off += sz
+        mlp_c = [_f32c(p) for p in mlp]
+        feats_c = [_f32c(p) for p in feats]
+        cfg = octree.step_config(sorted_input=1, decoder_grad_on=1 if need_m else 0)
+        ws = _workspace(dev, cfg)
+        _lib.check(
+            _lib.lib().shine_interp_sdf_backward(
+                t.handle, C.byref(cfg), c.data_ptr(), perm.data_ptr(), slots.data_ptr(), g.data_ptr(), n,
+                _lib.ptr_array([f.data_ptr() for f in feats_c]), octree.row_counts(),
+                _lib.ptr_array([p.data_ptr() for p in mlp_c]),
+                _lib.ptr_array([v.data_ptr() if v is not None else None for v in views[:L]]),
+                _lib.ptr_array([v.data_ptr() if v is not None else None for v in views[L:]]) if need_m else None,
+                ws.data_ptr(), ws.numel(), _stream(),
+            ),
+            "shine_interp_sdf_backward",
+        )
+        return (None, None, None) + tuple(views)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -35,6 +35,8 @@ struct V1Args {
   const int* perm;
   const int* slots;  // [n][L] hash slots per point IN VISITING ORDER (shine_plan_batch), or null: probe in-kernel
   const long long* n_surf;
+  const float* ext_delta;  // Tier A backward (shine_interp_sdf_backward): d loss / d pred per point, indexed like pred;
+                           // the kernel then skips its own loss and backpropagates this instead
   const float* mlp[6];
   float* pred;
   float* grad_x;

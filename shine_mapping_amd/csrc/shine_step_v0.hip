@@ -57,6 +57,10 @@ __global__ __launch_bounds__(256) void k_step_v0(StepArgs a) {
   __shared__ float s_stage[TRAIN ? 4 * 64 * ST : 1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   load_mlp_to_lds(a, s_mlp, tid, 256);
+  // FeatureOctree.set_zero (model/feature_octree.py:78-81, called at the top of query_feature): the trash row of every
+  // level is re-zeroed here — nothing in this kernel reads it (a miss contributes nothing), so there is no ordering to keep
+  if (!TRAIN && blockIdx.x == 0 && tid < a.n_levels * F)
+    const_cast<float*>(a.ls.lv[tid / F].feat)[a.ls.lv[tid / F].rows * F + (tid % F)] = 0.f;
   __syncthreads();
   float* st = s_stage + (TRAIN ? wv * 64 * ST : 0);
   const int L = a.n_levels;

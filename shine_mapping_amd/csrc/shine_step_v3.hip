@@ -64,8 +64,12 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 #define SHINE_V3_ABL 0  // phase, 8 no row gathers; the product build compiles none of it
 #endif
 
-template <int L, int WAVES, bool EIK, bool PROF>
+// EXT: the backward half of Tier A's fused node (autograd_ops.FusedInterpSdf): d loss / d pred comes from autograd
+// (a.ext_delta) instead of the kernel's own BCE — query, decoder forward, decoder backward, weight grads and scatter are the
+// same code.
+template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_v3(V1Args a) {
+  static_assert(!(EXT && EIK), "the external-delta build backpropagates one scalar per point (no eikonal chain)");
   static_assert(!(EIK && SHINE_V3_DEDUP), "the eikonal build gathers directly");
   constexpr int NT = WAVES * 64;
   __shared__ float s_opA[V3_OPTOTAL];
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     }
     yp += __shfl_xor(yp, 16, 64);
     const float y = yp + __shfl_xor(yp, 32, 64) + b3;
-    if (valid && g == 0 && a.pred) __builtin_nontemporal_store(y, a.pred + po);
+    if (!EXT && valid && g == 0 && a.pred) __builtin_nontemporal_store(y, a.pred + po);
     __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
     SHINE_STAMP(2)  // decoder forward
 
@@ -518,7 +522,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     // BCEWithLogits(y, z) = max(y, 0) - y z + log1p(e), e = exp(-|y|); sigmoid(y) = 1 / (1 + e) or e / (1 + e) shares e.
     // Hardware transcendentals (v_exp_f32, v_rcp_f32, v_log_f32: ~1 ulp) — errors ~1e-7, the contract is 1e-4.
     float delta = 0.f;
-    {
+    if (EXT) {
+      if (valid) delta = a.ext_delta[po];
+    } else {
       const float zt = fast_sigmoid(label * inv_sigma);
       const float e = __builtin_amdgcn_exp2f(-1.44269504088896f * fabsf(y));
       const float r = __builtin_amdgcn_rcpf(1.0f + e);
@@ -985,6 +991,13 @@ static void launch_v3(const V1Args& a, const V2Geometry& g, hipStream_t st) {
   else hipLaunchKernelGGL((k_step_v3<L, 4, EIK, false>), grid, dim3(256), 0, st, a);
 }
 
+template <int L>
+static void launch_v3_ext(const V1Args& a, const V2Geometry& g, hipStream_t st) {
+  const dim3 grid((unsigned)g.blocks);
+  if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, false, false, true>), grid, dim3(V3_BIG * 64), 0, st, a);
+  else hipLaunchKernelGGL((k_step_v3<L, 4, false, false, true>), grid, dim3(256), 0, st, a);
+}
+
 }  // namespace shine
 
 using namespace shine;
@@ -1048,5 +1061,47 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
     hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks);
     SHINE_HIP_CHECK(hipGetLastError());
   }
+  return SHINE_OK;
+}
+
+// Tier A, fused: backward of {FeatureOctree.query_feature -> Decoder.sdf} (model/feature_octree.py:237-244,
+// model/decoder.py:49-63) for a given d loss / d pred — what autograd derives for cur_loss.backward()
+// (shine_batch.py:208-209) through those two calls, as ONE fused launch (+ the partial-sum reduction): decoder backward,
+// decoder weight grads, interpolation backward with the run-merged scatter.  Planned batch (perm, slots from
+// shine_plan_batch); grad_pred is indexed like the batch.  grad_feats / grad_mlp are ACCUMULATED INTO.
+extern "C" int shine_interp_sdf_backward(const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                                         const int32_t* perm, const int32_t* slots, const float* grad_pred, int64_t n,
+                                         const float* const* feats, const int64_t* rows, const float* const* mlp,
+                                         float* const* grad_feats, float* const* grad_mlp, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (!cfg || !perm || !slots || !grad_pred)
+    return set_error(SHINE_E_INVALID, "shine_interp_sdf_backward: needs a planned batch (perm, slots) and grad_pred");
+  if (cfg->eikonal_on || cfg->loss_weight_on || cfg->sorted_input == 2)
+    return set_error(SHINE_E_INVALID, "shine_interp_sdf_backward: a plain planned batch, no loss options (the loss is the caller's)");
+  V1Args a = {};
+  // (coord doubles as the label pointer: the external-delta build never reads labels)
+  int rc = fill_step_args(&a, t, cfg, coord, coord, nullptr, perm, slots, nullptr, n, feats, rows, mlp, nullptr, nullptr,
+                          grad_feats, grad_mlp, nullptr, nullptr);
+  if (rc != SHINE_OK) return rc;
+  if (n == 0) return SHINE_OK;
+  a.ext_delta = grad_pred;
+  a.inv_n = 1.0f;
+  const V2Geometry g = v3_geometry(n);
+  a.tiles = g.tiles;
+  a.waves_total = g.waves;
+  const size_t need = (size_t)g.blocks * PART_STRIDE * sizeof(float);
+  if (!workspace || workspace_bytes < need)
+    return set_error(SHINE_E_INVALID, "shine_interp_sdf_backward: workspace too small (shine_train_step_workspace_bytes)");
+  a.partials = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  switch (cfg->n_levels) {
+    case 1: launch_v3_ext<1>(a, g, st); break;
+    case 2: launch_v3_ext<2>(a, g, st); break;
+    case 3: launch_v3_ext<3>(a, g, st); break;
+    default: launch_v3_ext<4>(a, g, st); break;
+  }
+  SHINE_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks);
+  SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }

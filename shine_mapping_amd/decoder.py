@@ -40,9 +40,16 @@ class Decoder(nn.Module):
 
     # model/decoder.py:49-63
     def sdf(self, sum_features):
-        if self.fusable and sum_features.is_cuda and sum_features.dtype == torch.float32 and sum_features.dim() == 2:
-            from .autograd_ops import FusedMLP
+        if (self.fusable and sum_features.is_cuda and sum_features.dtype == torch.float32 and sum_features.dim() == 2
+                and self._params_on(sum_features.device)):
+            from .autograd_ops import FusedInterpSdf, FusedMLP
 
+            src = getattr(sum_features, "_shine_src", None)
+            if src is not None and torch.is_grad_enabled() and sum_features.requires_grad and src.fusable(sum_features):
+                # the untouched output of FeatureOctree.query_feature (shine_batch.py:123-124): interpolation + decoder as
+                # ONE autograd node whose backward is one fused launch
+                return FusedInterpSdf.apply(sum_features.detach(), src.coord, src.octree, *src.octree.feature_list(),
+                                            *self.fused_params())
             return FusedMLP.apply(sum_features, *self.fused_params())
         h = sum_features  # other shapes / devices: the reference's composite
         for l in self.layers:
@@ -71,6 +78,11 @@ class Decoder(nn.Module):
         return torch.argmax(self.sem_label_prob(sum_features), dim=1)
 
     # ---- fused-path plumbing
+    def _params_on(self, device) -> bool:
+        """the HIP decoder reads the six tensors in place: CUDA float32 contiguous on the input's device, or the composite runs"""
+        return all(p.is_cuda and p.device == device and p.dtype == torch.float32 and p.is_contiguous()
+                   for p in self.fused_params())
+
     def fused_params(self):
         """W1,b1,W2,b2,w3,b3 in the order libshine_hip expects."""
         if not self.fusable:

@@ -502,8 +502,14 @@ class FeatureOctree(nn.Module):
         """`faster` (get_indices_fast, :267-286) is a CPU-side dedup trick; on the GPU both paths are the same."""
         from .ops import octree_interp  # late import: ops imports this module's types
 
-        self.set_zero()
-        return octree_interp(self, coord)
+        # set_zero (:238) happens inside the forward kernel (shine_forward re-zeroes the trash rows): L python index ops and L
+        # fill launches less per query
+        feat = octree_interp(self, coord)
+        if feat.requires_grad:  # lets Decoder.sdf fuse the two calls into one autograd node (autograd_ops.FusedInterpSdf)
+            from .autograd_ops import FeatureSource
+
+            feat._shine_src = FeatureSource(self, coord, feat)
+        return feat
 
     # ------------------------------------------------------------------ :246-255
     def cal_regularization(self):

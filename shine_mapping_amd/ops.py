@@ -73,8 +73,7 @@ def forward_sdf(octree, decoder, coord, want_feat=False, want_indices=False, wan
     idx = None
     if want_indices:
         idx = [torch.empty((n, 8), dtype=torch.int64, device=dev) for _ in range(octree.featured_level_num)]
-    octree.set_zero()
-    cfg = octree.step_config(sigma=float(sigma))
+    cfg = octree.step_config(sigma=float(sigma))  # (set_zero: the forward kernel re-zeroes the trash rows)
     mlp = [p.detach() for p in decoder.fused_params()]
     _lib.check(
         _lib.lib().shine_forward(

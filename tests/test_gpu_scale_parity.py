@@ -314,6 +314,52 @@ def test_train_step_is_an_autograd_node(golden):
     assert not l3.requires_grad and abs_err(p3, ref["pred"]) <= TOL
 
 
+@pytest.mark.parametrize("name", ["maicity_bce_L3", "maicity_bce_L4", "ncd_reg_L3"])
+def test_tier_a_fuses_query_feature_and_sdf_into_one_node(name):
+    """The drivers' sequence `feature = octree.query_feature(coord); pred = geo_mlp.sdf(feature)` (shine_batch.py:123-124),
+    unchanged: when `sdf` receives the untouched output of `query_feature` (and coord wants no gradient) the two calls are
+    ONE autograd node whose backward is one fused launch (shine_interp_sdf_backward).  Same gradients as the split nodes,
+    which remain the fallback as soon as the feature tensor was modified or replaced."""
+    from shine_mapping_amd import sdf_bce_loss
+
+    fx = load_golden(name)
+    coord, label = fx["coord"].cuda(), fx["sdf_label"].cuda()
+    red = fx["cfg"].get("loss_reduction", "mean")
+    got = {}
+    for mode in ("fused", "modified in place", "replaced"):
+        cfg, octree, dec = product_from_golden(fx)
+        feature = octree.query_feature(coord)
+        assert getattr(feature, "_shine_src", None) is not None
+        if mode == "modified in place":
+            feature.mul_(1.0)
+        elif mode == "replaced":
+            feature = feature * 1.0
+        pred = dec.sdf(feature)
+        node = type(pred.grad_fn).__name__
+        assert ("FusedInterpSdf" in node) == (mode == "fused"), (mode, node)
+        loss = sdf_bce_loss(pred, label, fx["sigma"], None, False, red)
+        loss.backward()
+        torch.cuda.synchronize()
+        got[mode] = (pred.detach().clone(), [p.grad.clone() for p in list(octree.hier_features) + dec.fused_params()])
+        assert all(float(p[-1].abs().max()) == 0.0 for p in octree.hier_features)  # set_zero
+    for mode in ("modified in place", "replaced"):
+        assert torch.equal(got["fused"][0], got[mode][0])
+        for a, b in zip(got["fused"][1], got[mode][1]):
+            assert rel_err(a, b) <= TOL, mode
+    # and the recorded reference gradients (the fused terms' grads for the incremental fixture: conftest)
+    ref = fx["out"]
+    clean = feat_grads_of_the_fused_terms(fx) if fx["regularize"] else ref["feat_grads"]
+    for a, r in zip(got["fused"][1], list(clean) + list(ref["mlp_grads"])):
+        assert rel_err(a, r) <= TOL
+    # a coord that wants a gradient (eikonal configurations) keeps the split, twice-differentiable nodes
+    cfg, octree, dec = product_from_golden(fx)
+    c2 = coord.clone().requires_grad_(True)
+    pred = dec.sdf(octree.query_feature(c2))
+    assert "FusedInterpSdf" not in type(pred.grad_fn).__name__
+    g = torch.autograd.grad(pred.sum(), c2, create_graph=True)[0]
+    assert g.requires_grad
+
+
 def test_tier_a_loop_runs_no_torch_gemm():
     """The strict drop-in tier (query_feature -> sdf -> get_gradient -> sdf_bce_loss + eikonal -> backward on OUR classes)
     lands on HIP kernels end to end: the kernel trace of one iteration holds shine:: kernels for the query, the decoder
