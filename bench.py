@@ -148,7 +148,10 @@ def cpu_baseline(wl, seconds=12.0, n=4096, max_iters=400):
     # winner.  (One iteration per candidate let a single slow iteration pick the wrong count: the r02 figure moved 2x
     # between boxes.)
     calib = {}
-    for threads in sorted({host_cores, min(host_cores, 32), min(host_cores, 8), 1}, reverse=True):
+    # (all cores only on small hosts: on the 256-core GPU box one iteration at 256 threads takes ~10 s — four of them were
+    # 40 s of every run for a candidate that never wins)
+    cands = {min(host_cores, 32), min(host_cores, 8), 1} | ({host_cores} if host_cores <= 64 else set())
+    for threads in sorted(cands, reverse=True):
         torch.set_num_threads(threads)
         one_iteration()  # warm-up at this thread count
         calib[threads] = statistics.median(one_iteration()[0] for _ in range(3))
@@ -169,7 +172,7 @@ def cpu_baseline(wl, seconds=12.0, n=4096, max_iters=400):
         "sample": "%d whole iterations (query+decode+loss+backward+Adam step, the reference's timing(s)/total) of N=%d "
                   "(reference batch size) from the same pool/octree; oracle/shine_oracle.py train_step + "
                   "torch.optim.Adam(betas=(0.9,0.99), eps=1e-15) on the reference's groups, torch %s CPU, thread count = "
-                  "best median of 3 iterations over {all,32,8,1}" % (it, n, torch.__version__),
+                  "best median of 3 iterations over {32,8,1} (+ all cores on hosts of <= 64)" % (it, n, torch.__version__),
     }
 
 

@@ -67,6 +67,13 @@ typedef struct shine_step_config {
   int32_t sort_bits[3];    /* bits per axis that cover the box; 0 = whole cube (tree_level_world bits)     */
   int32_t loss_weight_on;  /* 1: BCEWithLogitsLoss(weight=|weight|) (utils/loss.py:18-19, shine_batch.py:172-174):
                               every sample's BCE term is multiplied by |weight[i]| (the reduction still divides by N) */
+  /* Iteration hooks of shine_train_step (all optional, NULL = off): scalar housekeeping of the calls that FOLLOW the step in
+   * an iteration rides on the step's reduction launch instead of costing launches of its own — at the reference's batch
+   * size (4096) an iteration is a chain of ~8 small launches and each one costs its run time plus ~2 us of dependency gap. */
+  int64_t* adam_state;     /* the shine_adam_step_dev state of the optimiser step that follows: the step counts it and derives
+                              the bias corrections; pass zero_grad | 2 to that shine_adam_step_dev call */
+  float adam_beta1, adam_beta2;
+  double* zero_f64;        /* one device double cleared by the step (shine_regularize's accumulator: out_zeroed = 1 there) */
 } shine_step_config;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -210,12 +217,14 @@ int shine_morton_sort(const shine_step_config* cfg, const float* coord, int64_t 
  *      shine_regularize = FeatureOctree.cal_regularization (model/feature_octree.py:246-255) on the rows flagged by the
  *      last shine_train_step: *reg_out = sum importance*(F - F_last)^2 (unweighted; overwritten), and, for levels with
  *      grad_on[s] != 0, grad_feats[s] += 2*lambda*importance*(F - F_last).  grad_on[s] = 0 is the reference's
- *      attached-clone quirk (:160): value only.  Clears the flags.
+ *      attached-clone quirk (:160): value only.  Clears the flags.  out_zeroed != 0: *reg_out was already cleared (by the
+ *      step's reduction launch, cfg->zero_f64) — no memset launch here.
  *      shine_importance_accumulate = the per-chunk epilogue of cal_feature_importance (utils/incre_learning.py:36-40):
  *      importance += |grad|, grad = 0, importance[trash row] = 0, for one level ([rows+1, 8] tensors). ------------- */
 int shine_regularize(int32_t n_levels, const float* const* feats, const float* const* feats_last,
                      const float* const* importance, float* const* grad_feats, unsigned char* const* touched,
-                     const int64_t* rows, const int32_t* grad_on, float lambda_forget, double* reg_out, void* stream);
+                     const int64_t* rows, const int32_t* grad_on, float lambda_forget, double* reg_out,
+                     int32_t out_zeroed, void* stream);
 int shine_importance_accumulate(float* importance, float* grad, int64_t rows, void* stream);
 /*      shine_importance_sweep = the whole of cal_feature_importance's chunk loop (utils/incre_learning.py:27-40) in one
  *      call.  coord / sdf_label / weight (or NULL) / slots: a node-ordered pool as for pool-mode shine_train_step
@@ -301,7 +310,10 @@ int shine_query_points(const shine_tables* t, const shine_step_config* cfg, cons
  *      graph: the scalars live in device memory and the kernels advance them, so ONE captured iteration
  *      {draw, shine_train_step, [shine_regularize], Adam} can be replayed for every iteration of a frame.
  *      stream_state: device uint64[2] = {stream id (read, then +1 by the launch), 0};  step_state: device int64[8] =
- *      {optimiser steps taken so far (this launch performs step [0]+1 and stores it), scratch, 6 reserved (zeros)};  lr_dev: device float[n_tensors]
+ *      {optimiser steps taken so far (this launch performs step [0]+1 and stores it), the two bias corrections (floats),
+ *      beta1^t and beta2^t as doubles (running products; 0 = derive them with pow once), 4 reserved};  zero_grad: bit 0 =
+ *      clear the grads in the same pass, bit 1 = the state was already advanced for this step by shine_train_step
+ *      (cfg->adam_state): no preparation launch;  lr_dev: device float[n_tensors]
  *      (step_lr_decay, utils/tools.py:135-155, becomes a small device copy outside the graph). --------------------- */
 int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t seed, uint64_t* stream_state, int32_t* idx_out,
                             void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
@@ -309,7 +321,7 @@ int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* g
                         float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const float* weight_decay,
                         float beta1, float beta2, float eps, int64_t* step_state, int32_t zero_grad, void* stream);
 
-/* ---- measurement aid (tools/ablate.py): per-wave phase cycle counters of the fused kernel.  buffer = device
+/* ---- measurement aid (tools/ab_build.py AB_PROF): per-wave phase cycle counters of the fused kernel.  buffer = device
  *      int64 [waves][8] (setup, query, decoder forward, loss+backward, scatter, weight grads, flush, block wait) that
  *      the next 4-level shine_train_step launches fill through s_memtime stamps; NULL switches it off again.
  *      The stamped build is a separate template instantiation: the product kernel carries no profiling code. -------- */

@@ -37,6 +37,10 @@ class StepConfig(C.Structure):
         ("sort_origin", C.c_int32 * 3),
         ("sort_bits", C.c_int32 * 3),
         ("loss_weight_on", C.c_int32),
+        ("adam_state", C.c_void_p),   # iteration hooks (include/shine_hip.h): optional device pointers
+        ("adam_beta1", C.c_float),
+        ("adam_beta2", C.c_float),
+        ("zero_f64", C.c_void_p),
     ]
 
 
@@ -78,7 +82,7 @@ _SIGNATURES = {
     ),
     "shine_regularize": (
         C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
-                  C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_float, _P, _P]),
+                  C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_float, _P, C.c_int32, _P]),
     "shine_importance_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
     "shine_importance_sweep": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P,
                                          C.c_size_t, _P]),

@@ -30,14 +30,10 @@ struct AdamArgs {
   float b1, b2, eps, bc1, bc2_sqrt;  // bc1 = 1 - b1^t ; bc2_sqrt = sqrt(1 - b2^t)
   int zero_grad;
   // graph-replayable form (shine_adam_step_dev): step counter and learning rates live in device memory
-  long long* step_state;  // int64[8]: [0] = steps taken so far (k_adam_prep makes it [0]+1), [1] = the two bias corrections
-                          // (floats); [2..4] are used by the SHINE_ADAM_FUSED_PREP measurement build only
+  long long* step_state;  // int64[8]: [0] = steps taken so far, [1] = the two bias corrections (floats), [2] / [3] = beta^t as
+                          // doubles (adam_advance, shine_internal.hpp)
   const float* lr_dev;    // [n_seg] or null
 };
-
-#ifndef SHINE_ADAM_FUSED_PREP  // measurement builds only (see k_adam)
-#define SHINE_ADAM_FUSED_PREP 0
-#endif
 
 struct AdamScalars {
   float b1, b2, eps, bc1, bc2_sqrt;
@@ -50,50 +46,14 @@ __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, co
   p -= (lr / a.bc1) * (m / denom);
 }
 
-// graph-replayable form: one thread counts the step and derives the bias corrections in double, like the host path
-// (a double pow per workgroup inside k_adam cost 100+ us)
-__global__ void k_adam_prep(long long* step_state, float b1, float b2) {
-  const long long t = step_state[0] + 1;
-  step_state[0] = t;
-  float* bc = reinterpret_cast<float*>(step_state + 1);
-  bc[0] = (float)(1.0 - pow((double)b1, (double)t));
-  bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
-}
+// graph-replayable form: one thread counts the step and derives the bias corrections (adam_advance, shine_internal.hpp) —
+// unless the fused step that precedes the optimiser in the iteration already did (cfg->adam_state): then there is no launch
+__global__ void k_adam_prep(long long* step_state, float b1, float b2) { adam_advance(step_state, b1, b2); }
 
 __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
   __shared__ float s_lr[ADAM_MAX_SEG];
   // (the kernel argument itself is never written: a modified by-value struct would be copied to scratch memory)
   AdamScalars sc = {a.b1, a.b2, a.eps, a.bc1, a.bc2_sqrt};
-#if SHINE_ADAM_FUSED_PREP
-  // measurement variant (tools/mk_variant.py -DSHINE_ADAM_FUSED_PREP=1 shine_adam.hip): no k_adam_prep launch.  The state
-  // carries beta^t as running products (doubles at step_state[2], [3]; 0 = not initialised: one pow), every workgroup
-  // derives the bias corrections of step t + 1 from them, and the LAST workgroup to finish (ticket at step_state[4])
-  // stores the new products and counts the step — every workgroup has read the old state by then.
-  __shared__ float s_bc[2];
-  __shared__ double s_q[2];
-  __shared__ long long s_t;
-  if (a.step_state) {
-    if (threadIdx.x == 0) {
-      const long long t_old = a.step_state[0];
-      const double* prod = reinterpret_cast<const double*>(a.step_state + 2);
-      double p1 = prod[0], p2 = prod[1];
-      if (p1 == 0.0 || p2 == 0.0) {
-        p1 = pow((double)a.b1, (double)t_old);
-        p2 = pow((double)a.b2, (double)t_old);
-      }
-      const double q1 = p1 * (double)a.b1, q2 = p2 * (double)a.b2;
-      s_bc[0] = (float)(1.0 - q1);
-      s_bc[1] = (float)sqrt(1.0 - q2);
-      s_q[0] = q1;
-      s_q[1] = q2;
-      s_t = t_old + 1;
-    }
-    if (threadIdx.x < a.n_seg) s_lr[threadIdx.x] = a.lr_dev ? a.lr_dev[threadIdx.x] : a.seg[threadIdx.x].lr;
-    __syncthreads();
-    sc.bc1 = s_bc[0];
-    sc.bc2_sqrt = s_bc[1];
-  }
-#else
   if (a.step_state) {  // wave-uniform: k_adam_prep counted the step and left the two bias corrections in step_state[1]
     const float* bc = reinterpret_cast<const float*>(a.step_state + 1);
     sc.bc1 = bc[0];
@@ -101,7 +61,6 @@ __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
     if (threadIdx.x < a.n_seg) s_lr[threadIdx.x] = a.lr_dev ? a.lr_dev[threadIdx.x] : a.seg[threadIdx.x].lr;
     __syncthreads();
   }
-#endif
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long long)gridDim.x * 256) {
     int s = 0;
     while (s + 1 < a.n_seg && i >= a.seg[s + 1].start) ++s;
@@ -130,23 +89,6 @@ __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
       }
     }
   }
-#if SHINE_ADAM_FUSED_PREP
-  if (a.step_state) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
-      unsigned long long* ticket = reinterpret_cast<unsigned long long*>(a.step_state + 4);
-      if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull) {
-        *ticket = 0ull;
-        double* prod = reinterpret_cast<double*>(a.step_state + 2);
-        prod[0] = s_q[0];
-        prod[1] = s_q[1];
-        __threadfence();
-        a.step_state[0] = s_t;
-      }
-    }
-  }
-#endif
 }
 
 }  // namespace shine
@@ -182,13 +124,14 @@ static int adam_impl(int32_t n_tensors, float* const* params, float* const* grad
   a.eps = eps;
   a.bc1 = step_state ? 1.f : (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2_sqrt = step_state ? 1.f : (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  a.zero_grad = zero_grad;
+  a.zero_grad = zero_grad & 1;
   a.step_state = step_state;
   a.lr_dev = lr_dev;
   if (start == 0) return SHINE_OK;
   long long blocks = (start + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (step_state && !SHINE_ADAM_FUSED_PREP) hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, beta1, beta2);
+  if (step_state && !(zero_grad & 2))  // (bit 1: the fused step of this iteration advanced the state already)
+    hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, beta1, beta2);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;

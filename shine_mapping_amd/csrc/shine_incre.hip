@@ -102,7 +102,7 @@ using namespace shine;
 extern "C" int shine_regularize(int32_t n_levels, const float* const* feats, const float* const* feats_last,
                                 const float* const* importance, float* const* grad_feats,
                                 unsigned char* const* touched, const int64_t* rows, const int32_t* grad_on,
-                                float lambda_forget, double* reg_out, void* stream) {
+                                float lambda_forget, double* reg_out, int32_t out_zeroed, void* stream) {
   if (n_levels < 1 || n_levels > SHINE_MAX_LEVELS || !feats || !feats_last || !importance || !touched || !rows ||
       !reg_out)
     return set_error(SHINE_E_INVALID, "shine_regularize: null argument");
@@ -127,7 +127,7 @@ extern "C" int shine_regularize(int32_t n_levels, const float* const* feats, con
     a.start[s + 1] = a.start[s] + rows[s];  // the trash row is excluded: its importance is reset to 0 (incre_learning.py:40)
   }
   hipStream_t st = (hipStream_t)stream;
-  SHINE_HIP_CHECK(hipMemsetAsync(reg_out, 0, sizeof(double), st));
+  if (!out_zeroed) SHINE_HIP_CHECK(hipMemsetAsync(reg_out, 0, sizeof(double), st));
   const long long total = a.start[n_levels];  // rows
   if (total == 0) return SHINE_OK;
   long long blocks = (total + 255) / 256;

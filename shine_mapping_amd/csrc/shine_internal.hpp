@@ -43,6 +43,28 @@ struct GrowScratch {
   unsigned long long* new_corners[SHINE_MAX_LEVELS] = {}; // [n_added] lexicographic = id order
 };
 
+// One optimiser step counted in a shine_adam_step_dev state (int64[8]: [0] steps taken, [1] the two bias corrections as
+// floats, [2] / [3] beta1^t / beta2^t as doubles).  The powers are RUNNING PRODUCTS — one multiply per step; a double pow()
+// is ~10 k cycles of one thread — and 0 means "not initialised": derived with pow once.  Called by ONE thread per step:
+// k_adam_prep (shine_adam.hip) or the step's reduction launch (k_reduce_partials, cfg->adam_state).
+__device__ inline void adam_advance(long long* state, float b1, float b2) {
+  const long long t = state[0] + 1;
+  state[0] = t;
+  double* pr = reinterpret_cast<double*>(state + 2);
+  double p1 = pr[0], p2 = pr[1];
+  if (p1 == 0.0 || p2 == 0.0) {
+    p1 = pow((double)b1, (double)(t - 1));
+    p2 = pow((double)b2, (double)(t - 1));
+  }
+  p1 *= (double)b1;
+  p2 *= (double)b2;
+  pr[0] = p1;
+  pr[1] = p2;
+  float* bc = reinterpret_cast<float*>(state + 1);
+  bc[0] = (float)(1.0 - p1);
+  bc[1] = (float)sqrt(1.0 - p2);
+}
+
 int set_error(int code, const char* msg);
 int set_hip_error(hipError_t e, const char* what);
 

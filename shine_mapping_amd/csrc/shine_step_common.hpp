@@ -43,6 +43,9 @@ struct V1Args {
   float* grad_mlp[6];
   double* loss_parts;
   float* partials;
+  long long* adam_state;  // iteration hooks (cfg->adam_state / zero_f64): housekeeping of the calls that follow the step,
+  double* zero_f64;       // done by one thread of the reduction launch
+  float adam_b1, adam_b2;
   long long* prof;  // debug: per-wave phase cycle counters [waves][8] (shine_debug_set_profile_buffer) or null
   long long n;
   long long chunk;
@@ -165,6 +168,10 @@ inline int fill_step_args(V1Args* a, const shine_tables* t, const shine_step_con
   a->sigma = cfg->sigma;
   a->inv_n = (float)cfg->inv_n;
   a->weight_e = cfg->weight_e;
+  a->adam_state = reinterpret_cast<long long*>(cfg->adam_state);
+  a->adam_b1 = cfg->adam_beta1;
+  a->adam_b2 = cfg->adam_beta2;
+  a->zero_f64 = cfg->zero_f64;
   return SHINE_OK;
 }
 

@@ -139,6 +139,13 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
     const int sl = threadIdx.x / F, q = threadIdx.x % F;
     if (a.feat_rw[sl]) a.feat_rw[sl][a.rows[sl] * F + q] = 0.f;
   }
+  // iteration hooks (include/shine_hip.h, shine_step_config): scalar housekeeping of the launches that FOLLOW the step rides
+  // here — the optimiser's step count + bias corrections, the regulariser's accumulator — one thread each, in a block that
+  // has little else to do
+  if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x == 0 && a.adam_state) adam_advance(a.adam_state, a.adam_b1, a.adam_b2);
+    if (threadIdx.x == 64 && a.zero_f64) *a.zero_f64 = 0.0;
+  }
 }
 
 // D[16x16] = A[16x4] . B[4x16] through one v_mfma_f32_16x16x4_f32: pins the operand / accumulator lane maps

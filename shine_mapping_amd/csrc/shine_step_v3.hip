@@ -45,9 +45,6 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 #ifndef SHINE_V3_DEDUP
 #define SHINE_V3_DEDUP 0
 #endif
-#ifndef SHINE_V3_MARK  // measurement builds only: touched-row flags set by the scatter instead of k_mark_touched
-#define SHINE_V3_MARK 0
-#endif
 #ifndef SHINE_V3_PREDSCAT  // measurement builds only: branch-free run-length scatter (see phase 6)
 #define SHINE_V3_PREDSCAT 0
 #endif
@@ -67,7 +64,11 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 // EXT: the backward half of Tier A's fused node (autograd_ops.FusedInterpSdf): d loss / d pred comes from autograd
 // (a.ext_delta) instead of the kernel's own BCE — query, decoder forward, decoder backward, weight grads and scatter are the
 // same code.
-template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false>
+// MARK: the touched-row flags (for shine_regularize) are set by the scatter at the run start of every hit node instead of by a
+// k_mark_touched launch in front of the step — a build of its own, because the flag code costs the kernel ~10 % at 2^18
+// points even when there are no flags to set (profiles/r03_ab_experiments.txt block 3), and pays at the incremental
+// configuration's 4096 points, where the extra launch is half the step (ncd-incre 172 -> 179 frames/s).
+template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_v3(V1Args a) {
   static_assert(!(EXT && EIK), "the external-delta build backpropagates one scalar per point (no eikonal chain)");
   static_assert(!(EIK && SHINE_V3_DEDUP), "the eikonal build gathers directly");
@@ -819,8 +820,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
             i32x16 iv;
 #pragma unroll
             for (int p2 = 0; p2 < V3_TP; ++p2) wv[p2] = wr[p2], dv[p2] = dfr[p2], iv[p2] = idr[p2];
-            scatter_level_prefix<!(SHINE_V3_ABL & 1)>(wv, iv, dv, cm, hm, sq, gbase, SHINE_V3_MARK ? a.touched[s] : nullptr, rid, rhit,
-                                                      racc);
+            scatter_level_prefix<!(SHINE_V3_ABL & 1)>(wv, iv, dv, cm, hm, sq, gbase, MARK ? a.touched[s] : nullptr, rid, rhit, racc);
           }
 #elif SHINE_V3_PREDSCAT
           // measurement variant (tools/mk_variant.py -DSHINE_V3_PREDSCAT=1): the walk without branches — the run-start
@@ -854,11 +854,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
               racc = 0.f;
               rid = (idr[p2] << 3) | sq;  // float offset of this lane's (corner row, feature)
               rhit = (int)((hm >> p2) & 1u);
-#if SHINE_V3_MARK
-              // measurement variant: the touched-row flags (unique(hierarchical_indices) without -1, for shine_regularize)
-              // are set here, at the run start of every hit node, by one lane per corner — no k_mark_touched launch
-              if (rhit && a.touched[s] && sq == 0) a.touched[s][idr[p2]] = 1;
-#endif
+              // the touched-row flags (unique(hierarchical_indices) without -1, for shine_regularize) are set here, at the run
+              // start of every hit node, by one lane per corner
+              if (MARK && rhit && a.touched[s] && sq == 0) a.touched[s][idr[p2]] = 1;
             }
             racc = fmaf(wr[p2], dfr[p2], racc);  // misses and padding lanes staged w = 0
           }
@@ -992,6 +990,13 @@ static void launch_v3(const V1Args& a, const V2Geometry& g, hipStream_t st) {
 }
 
 template <int L>
+static void launch_v3_mark(const V1Args& a, const V2Geometry& g, hipStream_t st) {  // BCE build that sets the touched-row flags
+  const dim3 grid((unsigned)g.blocks);
+  if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, false, false, false, true>), grid, dim3(V3_BIG * 64), 0, st, a);
+  else hipLaunchKernelGGL((k_step_v3<L, 4, false, false, false, true>), grid, dim3(256), 0, st, a);
+}
+
+template <int L>
 static void launch_v3_ext(const V1Args& a, const V2Geometry& g, hipStream_t st) {
   const dim3 grid((unsigned)g.blocks);
   if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, false, false, true>), grid, dim3(V3_BIG * 64), 0, st, a);
@@ -1037,11 +1042,22 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
     return set_error(SHINE_E_INVALID, "shine_train_step_v3: workspace too small (shine_train_step_workspace_bytes)");
   a.partials = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  if (touched && !SHINE_V3_MARK) {
+  // touched-row flags: set by the scatter of the MARK build (BCE steps whose every level has a gradient table: a level
+  // without one is not walked), by a marking pass in front of the step otherwise
+  bool mark_in_kernel = touched && !cfg->eikonal_on && !a.prof;
+  for (int s = 0; s < cfg->n_levels; ++s) mark_in_kernel = mark_in_kernel && a.lv[s].grad != nullptr;
+  if (touched && !mark_in_kernel) {
     hipLaunchKernelGGL(k_mark_touched, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     SHINE_HIP_CHECK(hipGetLastError());
   }
-  if (cfg->eikonal_on) {
+  if (mark_in_kernel) {
+    switch (cfg->n_levels) {
+      case 1: launch_v3_mark<1>(a, g, st); break;
+      case 2: launch_v3_mark<2>(a, g, st); break;
+      case 3: launch_v3_mark<3>(a, g, st); break;
+      default: launch_v3_mark<4>(a, g, st); break;
+    }
+  } else if (cfg->eikonal_on) {
     switch (cfg->n_levels) {
       case 1: launch_v3<1, true>(a, g, st); break;
       case 2: launch_v3<2, true>(a, g, st); break;

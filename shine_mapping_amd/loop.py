@@ -33,14 +33,26 @@ def _capture(fn):
     if side is None:
         side = _CAPTURE_STREAM[dev] = torch.cuda.Stream()
     g = torch.cuda.CUDAGraph()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        g.capture_begin()
-        try:
-            out = fn()
-        finally:
-            g.capture_end()
-    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize(dev)  # nothing of the eager warm-up (non-blocking copies, allocator activity) straddles the capture
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    out, err = None, None
+    try:
+        with torch.cuda.stream(side):
+            g.capture_begin()
+            try:
+                out = fn()
+            except BaseException as e:  # keep the ORIGINAL error: ending a broken capture may raise one of its own
+                err = e
+            try:
+                g.capture_end()
+            except BaseException as e2:
+                if err is None:
+                    err = e2
+    finally:
+        main.wait_stream(side)  # the main stream re-joins the side stream on every path
+    if err is not None:
+        raise err
     return g, out
 
 
@@ -54,6 +66,8 @@ class GraphedIteration:
         self._idx = torch.empty(self.n, dtype=torch.int32, device=pool.coord.device)
         self._nsurf = torch.zeros((), dtype=torch.int64, device=pool.coord.device)
         self.loss = self.reg = None
+        self._reg_out = torch.zeros(1, dtype=torch.float64, device=pool.coord.device) if self.regularize else None
+        self._hooked = None  # StepOptions with the iteration hooks (made once the optimiser has its device state)
         self._body()  # eager warm-up: allocates workspaces, optimiser state and device counters outside the capture
         self.graph, (self.loss, self.reg) = _capture(self._body)
         # `unroll` iterations in ONE graph: at the reference's batch size an iteration is ~8 small launches, and a graph
@@ -76,10 +90,25 @@ class GraphedIteration:
         if self.opts.ekional_loss_on:
             self._nsurf.copy_((self.pool.weight[idx.long()] > 0).sum())
             n_surf = self._nsurf
-        loss, _, _ = fused_train_step(self.octree, self.decoder, None, None, None, self.opts, n_surf=n_surf, pool=self.pool,
+        # Iteration hooks: the step's reduction launch also counts the optimiser step (+ bias corrections) and clears the
+        # regulariser's accumulator, so neither costs a launch of its own (an iteration at N = 4096 is a chain of small
+        # launches: each one removed saves its run time and ~2 us of dependency gap).  The optimiser's device state exists
+        # after its first graph-safe step — the eager warm-up call below runs unhooked and creates it.
+        state = self.opt.device_state() if hasattr(self.opt, "device_state") else None
+        hooked = state is not None
+        if hooked and (self._hooked is None or self._hooked.adam_state is not state):
+            import copy
+
+            self._hooked = copy.copy(self.opts)
+            self._hooked.adam_state, self._hooked.adam_betas = state, tuple(self.opt.betas)
+            self._hooked.zero_f64 = self._reg_out
+        opts = self._hooked if hooked else self.opts
+        loss, _, _ = fused_train_step(self.octree, self.decoder, None, None, None, opts, n_surf=n_surf, pool=self.pool,
                                       idx=idx, touched=self.touched)
-        reg = fused_regularization(self.octree, self.lambda_forget, self.touched) if self.regularize else None
-        self.opt.step(zero_grad=True, graph_safe=True)
+        reg = None
+        if self.regularize:
+            reg = fused_regularization(self.octree, self.lambda_forget, self.touched, out=self._reg_out, out_zeroed=hooked)
+        self.opt.step(zero_grad=True, graph_safe=True, advanced=hooked)
         return loss, reg
 
     def __call__(self):

@@ -33,6 +33,10 @@ class StepOptions:
     decoder_grad_on: Optional[bool] = None  # default: any decoder parameter requires grad (freeze_model, tools.py:188)
     deterministic: bool = False       # tests: ONE wave walks the whole batch, so the fp32 atomics of the feature-grad scatter are
                                       # applied in stream order and two runs agree to the bit (hundreds of times slower)
+    # iteration hooks (loop.GraphedIteration): housekeeping of the calls that follow the step rides on its reduction launch
+    adam_state: Optional[torch.Tensor] = None   # FusedAdam's device step state: the step counts the optimiser step
+    adam_betas: tuple = (0.9, 0.99)
+    zero_f64: Optional[torch.Tensor] = None     # one float64 element cleared by the step (the regulariser's accumulator)
     kernel_variant: int = 0           # 0 the fused step; tests / tools: 1 the lane-per-point reference kernel, 5 the
                                       # role-specialised experimental kernel (both in libshine_check.so)
 
@@ -174,6 +178,11 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         loss_weight_on=1 if opts.loss_weight_on else 0,
         inv_n=(1.0 if opts.loss_reduction == "sum" else 1.0 / max(n_global, 1)),
     )
+    if opts.adam_state is not None:
+        cfg.adam_state = opts.adam_state.data_ptr()
+        cfg.adam_beta1, cfg.adam_beta2 = float(opts.adam_betas[0]), float(opts.adam_betas[1])
+    if opts.zero_f64 is not None:
+        cfg.zero_f64 = opts.zero_f64.data_ptr()
     if eik and n_surf is None:
         n_surf = (weight > 0).sum()  # stays on the device; under DP the caller all-reduces it first
     pred = torch.empty(n, dtype=torch.float32, device=dev)
@@ -250,12 +259,14 @@ _WORKSPACE = {}
 
 
 def _workspace(dev, cfg):
-    """Scratch for the fused step (per-workgroup partial sums), one buffer per device for the life of the process.
+    """Scratch for the fused step (per-workgroup partial sums): one buffer per (device, stream), for the life of the process.
 
-    It is allocated ONCE at the size of the largest launch geometry (the workgroup count is capped at one per CU, so
-    the bound is ~1.5 MB) and never replaced: a captured HIP graph (loop.GraphedIteration, bench.py) bakes its address
-    in, so swapping it for a bigger one later would leave the graph writing into freed memory."""
-    key = str(dev)
+    It is allocated ONCE at the size of the largest launch geometry (the workgroup count is capped, so the bound is ~3 MB)
+    and never replaced: a captured HIP graph (loop.GraphedIteration, bench.py) bakes its address in, so swapping it for a
+    bigger one later would leave the graph writing into freed memory.  Per STREAM, because the partial sums of a step live
+    in it between the step's two launches: two steps in flight on different streams (a graph replaying on its capture
+    stream next to eager launches, two models in one process) must not share them."""
+    key = (str(dev), int(_stream() or 0))
     ws = _WORKSPACE.get(key)
     if ws is None:
         nbytes = int(_lib.lib().shine_train_step_workspace_bytes(C.byref(cfg), -1))  # bound for any batch size
@@ -271,7 +282,7 @@ def _dummy_mlp(dev):
     return _DUMMY[key]
 
 
-def fused_regularization(octree, lambda_forget: float, touched):
+def fused_regularization(octree, lambda_forget: float, touched, out=None, out_zeroed=False):
     """FeatureOctree.cal_regularization (model/feature_octree.py:246-255) on the rows the last fused step touched.
 
     Returns the UNWEIGHTED regulariser as a 0-dim float64 device tensor and adds lambda * d(reg)/dF into the feature
@@ -280,7 +291,9 @@ def fused_regularization(octree, lambda_forget: float, touched):
     import ctypes as _C
 
     L = octree.featured_level_num
-    out = torch.empty(1, dtype=torch.float64, device=octree.feature_list()[0].device)
+    if out is None:
+        out = torch.empty(1, dtype=torch.float64, device=octree.feature_list()[0].device)
+        out_zeroed = False
     feats = octree.feature_list()
     last = [t.detach().contiguous() for t in octree.features_last_frame]
     imp = [t.contiguous() for t in octree.importance_weight]
@@ -291,7 +304,7 @@ def fused_regularization(octree, lambda_forget: float, touched):
             L, _lib.ptr_array([t.data_ptr() for t in feats]), _lib.ptr_array([t.data_ptr() for t in last]),
             _lib.ptr_array([t.data_ptr() for t in imp]), _lib.ptr_array([g.data_ptr() for g in grads]),
             _lib.ptr_array([t.data_ptr() for t in touched]), octree.row_counts(), grad_on, float(lambda_forget),
-            out.data_ptr(), _stream(),
+            out.data_ptr(), 1 if out_zeroed else 0, _stream(),
         ),
         "shine_regularize",
     )

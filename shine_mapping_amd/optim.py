@@ -8,6 +8,7 @@ FusedAdam takes the same param_groups (so step_lr_decay, utils/tools.py:135-155,
 in the same pass.  Numerics follow torch.optim.Adam (tests compare the two on the GPU).
 """
 import ctypes as C
+import struct
 
 import torch
 
@@ -64,10 +65,25 @@ class FusedAdam:
         return int(self._dev[0][0].item()) if self._dev is not None else self.step_count
 
     @torch.no_grad()
-    def step(self, zero_grad=False, graph_safe=False):
+    def device_state(self):
+        """The device-side step state of graph-replayable steps (int64[8]; None before the first such step): hand it to the
+        fused step (StepOptions.adam_state) and the step's reduction launch advances it — then call step(..., advanced=True)."""
+        return None if self._dev is None else self._dev[0]
+
+    def _make_dev_state(self, dev):
+        """[0] steps taken, [1] bias corrections (floats, written by the advance), [2] / [3] beta1^t / beta2^t as doubles"""
+        def bits(x):
+            return struct.unpack("<q", struct.pack("<d", x))[0]
+
+        t = self.step_count
+        return torch.tensor([t, 0, bits(float(self.betas[0]) ** t), bits(float(self.betas[1]) ** t), 0, 0, 0, 0],
+                            dtype=torch.int64, device=dev)
+
+    def step(self, zero_grad=False, graph_safe=False, advanced=False):
         """`graph_safe`: step counter and learning rates are read from device memory (shine_adam_step_dev), so a captured
         HIP graph of this call performs step t, t+1, ... on successive replays.  Do not mix with eager steps afterwards
-        without reading steps_taken()."""
+        without reading steps_taken().  `advanced`: the fused step of this iteration already counted the step in
+        device_state() (StepOptions.adam_state): no preparation launch."""
         ts = self._tensors()
         if not ts:
             return
@@ -78,10 +94,22 @@ class FusedAdam:
                 raise NotImplementedError("graph-replayable FusedAdam steps need all tensors to have the same age "
                                           "(a parameter that started receiving grads later: use eager steps)")
             dev = ts[0][0].device
-            if self._dev is None or self._dev[1].numel() != n:
+            if self._dev is not None and self._dev[1].numel() != n:
+                # the set of tensors that receive grads changed while the device-side counter was live (e.g. the decoder was
+                # frozen / unfrozen): fold the steps the graph took back into the host counters before the state is re-made,
+                # or the bias correction would silently restart from the stale host count
+                taken = self.steps_taken()
+                for p in list(self._age):
+                    self._age[p] += taken - self.step_count
+                self.step_count = taken
+                self._dev = None
+                ages = [self._age.get(t[0], 0) for t in ts]
+                if len(set(ages)) != 1 or ages[0] != self.step_count:
+                    raise NotImplementedError("graph-replayable FusedAdam steps need all tensors to have the same age "
+                                              "(a parameter that started receiving grads later: use eager steps)")
+            if self._dev is None:
                 # int64[8]: [0] steps taken, [1] the step's bias corrections; the rest is reserved (zeros)
-                self._dev = (torch.tensor([self.step_count, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int64, device=dev),
-                             torch.tensor([t[3] for t in ts], dtype=torch.float32, device=dev))
+                self._dev = (self._make_dev_state(dev), torch.tensor([t[3] for t in ts], dtype=torch.float32, device=dev))
             for p, m, v, _, _ in ts:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
                     raise ValueError("FusedAdam needs contiguous CUDA float32 parameters and grads")
@@ -91,8 +119,8 @@ class FusedAdam:
                     n, _lib.ptr_array([t[0].data_ptr() for t in ts]), _lib.ptr_array([t[0].grad.data_ptr() for t in ts]),
                     _lib.ptr_array([t[1].data_ptr() for t in ts]), _lib.ptr_array([t[2].data_ptr() for t in ts]),
                     _lib.i64_array([t[0].numel() for t in ts]), self._dev[1].data_ptr(), wd, float(self.betas[0]),
-                    float(self.betas[1]), float(self.eps), self._dev[0].data_ptr(), 1 if zero_grad else 0,
-                    _lib.current_stream_handle(),
+                    float(self.betas[1]), float(self.eps), self._dev[0].data_ptr(),
+                    (1 if zero_grad else 0) | (2 if advanced else 0), _lib.current_stream_handle(),
                 ),
                 "shine_adam_step_dev",
             )
