@@ -54,9 +54,11 @@ PEAK_CLOCK_GHZ = 2.4
 N_SIMD = 1024
 MFMA16_CYCLES = 32.0       # v_mfma_f32_16x16x4_f32 issue interval per SIMD (guide, per-instruction constants)
 # fp32-datapath cycles of one plain VALU wave-instruction.  The guide's SIMD-32 figure is 2; tools/ubench/mfma_valu_overlap
-# measures 2.3 with two waves per SIMD issuing independent v_fma_f32 (mode 4: 512 k instructions per SIMD in 0.545 ms at the
-# 2.165 GHz mode 0 implies) — profiles/r03_ubench_calibration.txt re-derives it with the PMC formula below.
-VALU_CYCLES = 2.3
+# (profiles/r03_ubench_calibration.txt) measures 5.0 for ONE wave per SIMD issuing independent v_fma_f32 (mode 5) and 2.52
+# per instruction per SIMD with two waves (mode 6) — the best sustained rate seen; the packed v_pk_fma_f32 modes 1/4 that
+# round 2 quoted as "VALU 2.3" are two FMAs per lane.  MFMA + VALU from different waves do not overlap (mode 7: 2.34 M
+# cycles = 1.06 M MFMA + 1.28 M VALU).  The roof uses the best case, 2.5.
+VALU_CYCLES = 2.5
 
 WORKLOADS = {
     "maicity": dict(preset="maicity", points=1 << 18, levels=4, frames=60, azimuths=450),
@@ -532,15 +534,30 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
     if flags is not None:
         for f in flags:
             f.zero_()
-    idx_buf = torch.empty(points, dtype=torch.int32, device=dev)
+    # Two index buffers: the sorted draw of step i + 1 runs on a side stream UNDER the fused kernel of step i (it is two small
+    # launches that would otherwise sit in front of every step), so a step is {clear grads, fused step, reduction, [exchange]}
+    # with the next batch's draw in its shadow.  Every step still draws its own fresh batch (the sampler's stream id lives in
+    # device memory and advances with every draw).  --no-pipeline: draw, then step, on one stream.
+    idx_bufs = [torch.empty(points, dtype=torch.int32, device=dev) for _ in range(2)]
+    pipelined = not args.no_pipeline
+    side = torch.cuda.Stream(device=dev) if pipelined else None
 
-    def step_body():
-        """global sorted draw (+ clear grads in the same pass) -> fused step on this rank's slice (-> exchange).  The
-        draw's stream id lives in device memory (graph_safe), so every replay of the captured body draws a FRESH batch."""
+    def draw_into(buf, zero=None):
         # this rank's contiguous slice of the ONE global sorted draw (same seed / draw count on every rank): only the
         # slice's indices are generated (shine_sample_sorted_slice), so the draw does not grow with the world size
-        idx = spool.draw(points, out=idx_buf, zero=reducer.flat, graph_safe=True, n_global=n_global,
-                         slice_begin=rank * points)
+        return spool.draw(points, out=buf, zero=zero, graph_safe=True, n_global=n_global, slice_begin=rank * points)
+
+    def step_body(k=0):
+        """[draw of the NEXT batch on the side stream] clear grads -> fused step on this rank's slice (-> exchange)"""
+        main = torch.cuda.current_stream()
+        if pipelined:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                draw_into(idx_bufs[k ^ 1])
+            reducer.flat.zero_()  # opt.zero_grad(): one fill of the flat gradient bucket
+            idx = idx_bufs[k]
+        else:
+            idx = draw_into(idx_bufs[0], zero=reducer.flat)  # (the draw's first pass also clears the bucket)
         n_surf = None
         if opts.ekional_loss_on:  # global surface count: local count + an 8-byte all-reduce
             n_surf = (spool.weight[idx.long()] > 0).sum()
@@ -554,7 +571,12 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
                 reducer.all_reduce_touched(flags)
             else:
                 reducer.all_reduce_grads()
+        if pipelined:
+            main.wait_stream(side)
         return loss
+
+    if pipelined:
+        draw_into(idx_bufs[0])  # prime: the batch of the first step
 
     def barrier():
         if dist is not None:
@@ -565,26 +587,36 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
     # and replayed (launch-bound inner loops belong in hipGraphs).  With the dense exchange the RCCL all-reduce is
     # captured with it; the touched-row exchange reads a row count on the host and stays eager.
     launch = "eager"
-    graph, graph_loss = None, None
+    graphs, graph_loss = [], []
+    parity = [0]
     if not args.no_graph and not (use_dist and exchange == "touched"):
         try:
-            for _ in range(3):
-                step_body()  # warm caches / allocate workspaces / RCCL channels outside capture
+            for _ in range(4):
+                step_body(parity[0])  # warm caches / allocate workspaces / RCCL channels outside capture
+                parity[0] ^= 1
             barrier()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                graph_loss = step_body()
-            launch = "hipgraph, fresh batch per replay" + (" (all-reduce captured)" if use_dist else "")
+            for k in ((0, 1) if pipelined else (0,)):  # pipelined: one graph per buffer parity, replayed alternately
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    graph_loss.append(step_body(k))
+                graphs.append(g_)
+            parity[0] = 0
+            if pipelined:
+                draw_into(idx_bufs[0])  # (the captures ran nothing: re-prime the first buffer)
+            launch = "hipgraph, fresh batch per replay" + (", next draw under the step" if pipelined else "") + (
+                " (all-reduce captured)" if use_dist else "")
         except Exception as e:  # capture not possible on this stack: measure eagerly and say so
             print("graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
-            graph, graph_loss, launch = None, None, "eager"
+            graphs, graph_loss, launch = [], [], "eager"
             torch.cuda.synchronize()
 
     def step():
-        if graph is not None:
-            graph.replay()
-            return graph_loss
-        return step_body()
+        k = parity[0]
+        parity[0] ^= 1 if pipelined else 0
+        if graphs:
+            graphs[k].replay()
+            return graph_loss[k]
+        return step_body(k)
 
     loss = None
     for _ in range(warmup):
@@ -719,6 +751,8 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default invocation: skip the abbreviated kitti / ncd-incre legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="draw a step's batch in front of the step instead of under the previous step's fused kernel")
     ap.add_argument("--exchange", default="auto", choices=["auto", "dense", "touched"],
                     help="data-parallel gradient exchange: one flat all-reduce of the dense grads, or only the rows the "
                          "global batch touched (auto: touched when the dense bucket exceeds 64 MB)")

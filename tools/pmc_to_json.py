@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--meta", nargs="*", default=[])
     ap.add_argument("--command", default="")
     ap.add_argument("--lib", default=None, help="library whose kernel code is hashed into the record (default: the in-tree .so)")
-    ap.add_argument("--valu-cycles", type=float, default=2.3,
+    ap.add_argument("--valu-cycles", type=float, default=2.5,
                     help="fp32-datapath cycles per plain VALU wave-instruction (profiles/r03_ubench_calibration.txt)")
     ap.add_argument("dirs", nargs="+")
     a = ap.parse_args()
