@@ -534,12 +534,12 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
     if flags is not None:
         for f in flags:
             f.zero_()
-    # Two index buffers: the sorted draw of step i + 1 runs on a side stream UNDER the fused kernel of step i (it is two small
-    # launches that would otherwise sit in front of every step), so a step is {clear grads, fused step, reduction, [exchange]}
-    # with the next batch's draw in its shadow.  Every step still draws its own fresh batch (the sampler's stream id lives in
-    # device memory and advances with every draw).  --no-pipeline: draw, then step, on one stream.
+    # Default: draw, then step, on one stream.  --pipeline: two index buffers, the sorted draw of step i + 1 on a forked stream
+    # UNDER the fused kernel of step i (measured SLOWER: the fork/join of a two-branch HIP graph costs more than the two small
+    # launches it hides — profiles/r03_ab_experiments.txt block 9).  Either way every step draws its own fresh batch (the
+    # sampler's stream id lives in device memory and advances with every draw).
     idx_bufs = [torch.empty(points, dtype=torch.int32, device=dev) for _ in range(2)]
-    pipelined = not args.no_pipeline
+    pipelined = bool(args.pipeline)
     side = torch.cuda.Stream(device=dev) if pipelined else None
 
     def draw_into(buf, zero=None):
@@ -751,8 +751,9 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default invocation: skip the abbreviated kitti / ncd-incre legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="draw a step's batch in front of the step instead of under the previous step's fused kernel")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="draw the NEXT step's batch on a forked stream under the fused kernel (two alternating graphs); "
+                         "measured slower than the in-line draw (profiles/r03_ab_experiments.txt block 9), off by default")
     ap.add_argument("--exchange", default="auto", choices=["auto", "dense", "touched"],
                     help="data-parallel gradient exchange: one flat all-reduce of the dense grads, or only the rows the "
                          "global batch touched (auto: touched when the dense bucket exceeds 64 MB)")
