@@ -74,6 +74,11 @@ typedef struct shine_step_config {
                               the bias corrections; pass zero_grad | 2 to that shine_adam_step_dev call */
   float adam_beta1, adam_beta2;
   double* zero_f64;        /* one device double cleared by the step (shine_regularize's accumulator: out_zeroed = 1 there) */
+  void* clear_ptr;         /* ride-along clear: clear_bytes of device memory (16-byte aligned and sized) zero-filled BY the step */
+  size_t clear_bytes;      /* kernel, a slice per wave and tile, i.e. under its compute instead of in a launch of its own.  Meant
+                              for the gradient bucket of the NEXT step when the grads are double-buffered (the step accumulates
+                              into one bucket while the other, already consumed by the optimiser / exchange, is cleared).  Must
+                              not overlap anything the step reads or accumulates into. */
 } shine_step_config;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -277,7 +282,7 @@ int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t st
 /* the same draw for ONE data-parallel rank: only draws [slice_begin, slice_begin + slice_n) of the global sorted batch of
  * n draws are written (idx_out [slice_n]); every rank passes the same (seed, stream id) and its own slice, so the ranks'
  * slices are the contiguous parts of one i.i.d. batch at 1/world of the writing cost.  stream_state: device
- * uint64[2] (graph-replayable, as shine_sample_sorted_dev) or NULL to use stream_id. */
+ * uint64[4] (graph-replayable, as shine_sample_sorted_dev) or NULL to use stream_id. */
 int shine_sample_sorted_slice(int64_t pool_size, int64_t n, int64_t slice_begin, int64_t slice_n, uint64_t seed,
                               uint64_t stream_id, uint64_t* stream_state, int32_t* idx_out, void* zero_ptr,
                               size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
@@ -309,7 +314,8 @@ int shine_query_points(const shine_tables* t, const shine_step_config* cfg, cons
 /* ---- graph-replayable forms of the two calls whose per-iteration scalars are otherwise baked into a captured HIP
  *      graph: the scalars live in device memory and the kernels advance them, so ONE captured iteration
  *      {draw, shine_train_step, [shine_regularize], Adam} can be replayed for every iteration of a frame.
- *      stream_state: device uint64[2] = {stream id (read, then +1 by the launch), 0};  step_state: device int64[8] =
+ *      stream_state: device uint64[4] = {stream id (read, then +1 by the launches), 0, 0, 0} ([1], [2] are the library's: a
+ *      block counter and a shadow of the id, through which two launches advance it without atomics);  step_state: device int64[8] =
  *      {optimiser steps taken so far (this launch performs step [0]+1 and stores it), the two bias corrections (floats),
  *      beta1^t and beta2^t as doubles (running products; 0 = derive them with pow once), 4 reserved};  zero_grad: bit 0 =
  *      clear the grads in the same pass, bit 1 = the state was already advanced for this step by shine_train_step

@@ -43,12 +43,19 @@ __device__ __forceinline__ double block_sum_256(double v, double* s_red) {
   return t;
 }
 
-// stream_dev != nullptr: the stream id is read from device memory (graph-replayable form, shine_sample_sorted_dev)
+// stream_dev != nullptr: the stream id is read from device memory (graph-replayable form, shine_sample_sorted_dev):
+// uint64[4] = {A = stream id, block counter of the one-launch form, B = shadow of A, reserved}.  The two-launch form advances
+// the id without atomics: pass 1 reads A and its block 0 stores B = A + 1 (nothing in pass 1 reads B); pass 2 reads B - 1
+// and its block 0 stores A = B (nothing in pass 2 reads A) — the kernel boundaries order it.  (A "last block done" counter
+// costs one fenced same-address atomic per block: 22-40 ns each, serialised — 41 us for the 1025 blocks of a 2^20 draw.)
 __global__ __launch_bounds__(256) void k_sample_pass1(double* block_sum, long long n1, unsigned long long seed,
                                                       unsigned long long stream, const unsigned long long* stream_dev,
                                                       float4* zero_ptr, long long zero_n16) {
   __shared__ double s_red[4];
-  if (stream_dev) stream = stream_dev[0];
+  if (stream_dev) {
+    stream = stream_dev[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<unsigned long long*>(stream_dev)[2] = stream + 1ull;
+  }
   const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
   // ride-along clear of the gradient bucket (opt.zero_grad for the fused step), as in shine_plan_batch
   for (long long z = g; z < zero_n16; z += (long long)gridDim.x * 256) zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -70,7 +77,10 @@ __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, i
                                                       long long cnt) {
   __shared__ double s_red[4];
   __shared__ double s_wave_pre[4];
-  if (stream_dev) stream = stream_dev[0];
+  if (stream_dev) {
+    stream = stream_dev[2] - 1ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) stream_dev[0] = stream + 1ull;
+  }
   // prefix of the blocks in front of this one, and the grand total (nblocks is a few hundred)
   double before = 0.0, total = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 256) {
@@ -106,17 +116,6 @@ __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, i
     if (k0 + j < n && k0 + j >= lo && k0 + j < lo + cnt) {
       long long v = (long long)((s / total) * (double)pool);
       idx[k0 + j - lo] = (int)(v < 0 ? 0 : (v >= pool ? pool - 1 : v));
-    }
-  }
-  if (stream_dev) {  // the last block to finish advances the stream for the next replay (every block has read it by then)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
-      if (atomicAdd(&stream_dev[1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
-        stream_dev[1] = 0ull;
-        __threadfence();
-        atomicAdd(&stream_dev[0], 1ull);
-      }
     }
   }
 }
@@ -181,12 +180,13 @@ __global__ __launch_bounds__(256) void k_sample_fused(int nblocks, long long n, 
       idx[k0 + j] = (int)(v < 0 ? 0 : (v >= pool ? pool - 1 : v));
     }
   }
-  if (stream_dev) {  // as in pass 2: the last block to finish advances the stream id
+  if (stream_dev) {  // the last block to finish advances the stream id (<= 16 blocks: the counter costs < 1 us here)
     __syncthreads();
     if (threadIdx.x == 0) {
       __threadfence();
       if (atomicAdd(&stream_dev[1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
         stream_dev[1] = 0ull;
+        stream_dev[2] = stream + 1ull;  // (keeps the shadow of the two-launch form in step)
         __threadfence();
         atomicAdd(&stream_dev[0], 1ull);
       }

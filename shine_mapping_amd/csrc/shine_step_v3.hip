@@ -45,9 +45,6 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 #ifndef SHINE_V3_DEDUP
 #define SHINE_V3_DEDUP 0
 #endif
-#ifndef SHINE_V3_PREDSCAT  // measurement builds only: branch-free run-length scatter (see phase 6)
-#define SHINE_V3_PREDSCAT 0
-#endif
 #ifndef SHINE_V3_PROFBUILD  // 1: also instantiate the kernels with per-wave phase cycle counters (AB_PROF of tools/ab_build.py)
 #define SHINE_V3_PROFBUILD 0
 #endif
@@ -245,6 +242,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   const long long second = begin + V3_TP;
 #endif
 
+  // ride-along clear (cfg->clear_ptr: the next step's gradient bucket when the grads are double-buffered): this wave's
+  // contiguous share of the buffer, `zq` 1-KB rows of it per tile, so the stores trickle out under the tiles' compute
+  // instead of filling a launch of their own (13 MB: ~6 us, 72 MB: ~40 us in front of every step otherwise)
+  long long zc = 0, ze = 0;
+  int zq = 0;
+  if (a.clear_n16 > 0) {
+    const long long wtot = (long long)gridDim.x * WAVES;
+    const long long per = (a.clear_n16 + wtot - 1) / wtot;
+    zc = (long long)__builtin_amdgcn_readfirstlane((int)wave_g) * per;
+    ze = zc + per < a.clear_n16 ? zc + per : a.clear_n16;
+#if SHINE_V3_CH > 0
+    const long long my_tiles = njobs;
+#else
+    const long long my_tiles = end > begin ? (end - begin + V3_TP - 1) / V3_TP : 0;
+#endif
+    zq = my_tiles > 0 ? (int)((per + 64 * my_tiles - 1) / (64 * my_tiles)) : 0;
+    zq = __builtin_amdgcn_readfirstlane(zq);
+  }
+
   // software prefetch of the {perm -> coord, label, slot} chain, index two tiles ahead (as in v1 / v2)
   long long np = 0;
   float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, nlabel = 0.f, nweight = 0.f;
@@ -272,6 +288,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   for (long long base = begin; base < end; base += V3_TP) {
 #endif
     asm volatile("" : "+v"(lane_o));  // opaque per tile (see above)
+    for (int u = 0; u < zq; ++u, zc += 64)  // this tile's slice of the ride-along clear
+      if (zc + lane < ze) a.clear_ptr[zc + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int o_pt = lane_o & 15, o_g = lane_o >> 4;
     int* const st_ids = U_ids + (8 * o_g) * V3_WP + o_pt;   // staging writes (level o_g): + c * V3_WP
     float* const st_w = U_w + (8 * o_g) * V3_WP + o_pt;
@@ -822,30 +840,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
             for (int p2 = 0; p2 < V3_TP; ++p2) wv[p2] = wr[p2], dv[p2] = dfr[p2], iv[p2] = idr[p2];
             scatter_level_prefix<!(SHINE_V3_ABL & 1)>(wv, iv, dv, cm, hm, sq, gbase, MARK ? a.touched[s] : nullptr, rid, rhit, racc);
           }
-#elif SHINE_V3_PREDSCAT
-          // measurement variant (tools/mk_variant.py -DSHINE_V3_PREDSCAT=1): the walk without branches — the run-start
-          // decision selects the exec mask of the atomic (SCC -> s_cselect_b64 exec) and the resets are v_cndmask
-          unsigned long long rmask = rhit ? ~0ull : 0ull;
-#pragma unroll
-          for (int p2 = 0; p2 < V3_TP; ++p2) {
-            const bool start = (cm >> p2) & 1u;
-            unsigned long long saved;
-            asm volatile(
-                "s_mov_b64 %[sv], exec\n\t"
-                "s_bitcmp1_b32 %[cm], %[bit]\n\t"
-                "s_cselect_b64 exec, %[rm], 0\n\t"
-                "global_atomic_add_f32 %[off], %[val], %[base]\n\t"
-                "s_mov_b64 exec, %[sv]"
-                : [sv] "=&s"(saved)
-                : [cm] "s"(cm), [bit] "n"(p2), [rm] "s"(rmask), [off] "v"((unsigned int)rid * 4u), [val] "v"(racc),
-                  [base] "s"(gbase)
-                : "scc", "memory");
-            racc = start ? 0.f : racc;
-            rid = start ? ((idr[p2] << 3) | sq) : rid;
-            rmask = start ? (((hm >> p2) & 1u) ? ~0ull : 0ull) : rmask;
-            racc = fmaf(wr[p2], dfr[p2], racc);
-          }
-          rhit = rmask != 0ull;
 #else
 #pragma unroll
           for (int p2 = 0; p2 < V3_TP; ++p2) {
@@ -870,6 +864,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     wave_lds_fence();
     SHINE_STAMP(4)  // scatter
   }
+
+  for (; zc < ze; zc += 64)  // ride-along clear: what the tile loop left (a wave without tiles: its whole share)
+    if (zc + lane < ze) a.clear_ptr[zc + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // ---- end of the wave's run: flush the open node runs
 #pragma unroll

@@ -36,7 +36,7 @@ class SortedPool:
         self.seed = int(seed)
         self.draws = 0
         self._ws = {}  # per batch size, never replaced: captured HIP graphs bake the address in
-        self._stream_state = None  # device uint64[2] for graph-replayable draws (loop.GraphedIteration)
+        self._stream_state = None  # device uint64[4] for graph-replayable draws (loop.GraphedIteration)
         self.rebuild(coord, sdf_label, weight)
 
     def rebuild(self, coord, sdf_label, weight):
@@ -81,7 +81,7 @@ class SortedPool:
             state = None
             if graph_safe:
                 if self._stream_state is None:
-                    self._stream_state = torch.tensor([self.draws, 0], dtype=torch.int64, device=dev)
+                    self._stream_state = torch.tensor([self.draws, 0, self.draws, 0], dtype=torch.int64, device=dev)
                 state = self._stream_state.data_ptr()
             _lib.check(lib.shine_sample_sorted_slice(self.size, nd, int(slice_begin), n, self.seed, self.draws, state,
                                                      idx.data_ptr(), zero.data_ptr() if zero is not None else None,
@@ -93,7 +93,7 @@ class SortedPool:
             return idx
         if graph_safe:
             if self._stream_state is None:
-                self._stream_state = torch.tensor([self.draws, 0], dtype=torch.int64, device=dev)
+                self._stream_state = torch.tensor([self.draws, 0, self.draws, 0], dtype=torch.int64, device=dev)
             _lib.check(lib.shine_sample_sorted_dev(self.size, n, self.seed, self._stream_state.data_ptr(), idx.data_ptr(),
                                                    zero.data_ptr() if zero is not None else None,
                                                    zero.numel() * zero.element_size() if zero is not None else 0,

@@ -14,6 +14,7 @@ BENCH="python $R/bench.py --workload $W --points $P --levels $L --no-cpu-baselin
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/p_trace_$TAG -o run -- $BENCH --steps 200 --warmup 10 > $OUT/bench_under_rocprof_$TAG.log 2>&1
 python $R/tools/prof_summary.py /tmp/p_trace_$TAG 30 > $OUT/kernel_stats_$TAG.txt 2>&1
+python $R/tools/timeline_gaps.py /tmp/p_trace_$TAG k_step_v3 20 > $OUT/timeline_$TAG.txt 2>&1
 DIRS=""
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -d /tmp/p_${C}_$TAG -o run -- $BENCH --steps 6 --warmup 2 --no-graph > $OUT/pmc_${C}_$TAG.log 2>&1
