@@ -522,11 +522,7 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
     params = list(octree.hier_features) + decoder.fused_params()
     for p in params:
         p.grad = torch.zeros_like(p)
-    # Double-buffered gradient bucket: the fused kernel of step i accumulates into one bucket while it clears the other under
-    # its own compute (StepOptions.clear) — opt.zero_grad() costs no launch and no exposed fill (13 MB: ~6 us, 72 MB: ~40 us
-    # in front of every step otherwise).  --single-bucket: one bucket, cleared by the draw's first pass.
-    twin = not args.single_bucket
-    reducer = shine_dp.TouchedRowReducer(list(octree.hier_features), decoder.fused_params(), dist, double_buffer=twin)
+    reducer = shine_dp.TouchedRowReducer(list(octree.hier_features), decoder.fused_params(), dist)
     exchange = args.exchange
     if exchange == "auto":
         exchange = "touched" if reducer.dense_bytes() > (64 << 20) else "dense"
@@ -551,33 +547,23 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
         # slice's indices are generated (shine_sample_sorted_slice), so the draw does not grow with the world size
         return spool.draw(points, out=buf, zero=zero, graph_safe=True, n_global=n_global, slice_begin=rank * points)
 
-    import copy
-
     def step_body(k=0):
-        """k = parity of the step (which gradient bucket it accumulates into / which index buffer it reads)
-        [--pipeline: draw of the NEXT batch on the side stream]  draw -> fused step on this rank's slice (-> exchange)"""
+        """[draw of the NEXT batch on the side stream] clear grads -> fused step on this rank's slice (-> exchange)"""
         main = torch.cuda.current_stream()
-        o = opts
-        if twin:
-            if reducer.swap() != k:
-                reducer.swap()
-            o = copy.copy(opts)
-            o.clear = reducer.spare  # the bucket of step i + 1, cleared by this step's kernel
         if pipelined:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 draw_into(idx_bufs[k ^ 1])
-            if not twin:
-                reducer.flat.zero_()  # opt.zero_grad(): one fill of the flat gradient bucket
+            reducer.flat.zero_()  # opt.zero_grad(): one fill of the flat gradient bucket
             idx = idx_bufs[k]
         else:
-            idx = draw_into(idx_bufs[0], zero=None if twin else reducer.flat)  # (one bucket: the draw's first pass clears it)
+            idx = draw_into(idx_bufs[0], zero=reducer.flat)  # (the draw's first pass also clears the bucket)
         n_surf = None
-        if o.ekional_loss_on:  # global surface count: local count + an 8-byte all-reduce
+        if opts.ekional_loss_on:  # global surface count: local count + an 8-byte all-reduce
             n_surf = (spool.weight[idx.long()] > 0).sum()
             if use_dist:
                 reducer.all_reduce_scalar(n_surf)
-        loss, pred, _ = fused_train_step(octree, decoder, None, None, None, o, n_surf=n_surf, pool=spool, idx=idx)
+        loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx)
         if use_dist:
             if exchange == "touched":
                 shine_dp.mark_touched(octree, spool, idx, flags)  # this rank's rows ...
@@ -609,7 +595,7 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
                 step_body(parity[0])  # warm caches / allocate workspaces / RCCL channels outside capture
                 parity[0] ^= 1
             barrier()
-            for k in ((0, 1) if (pipelined or twin) else (0,)):  # one graph per buffer parity, replayed alternately
+            for k in ((0, 1) if pipelined else (0,)):  # pipelined: one graph per buffer parity, replayed alternately
                 g_ = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_):
                     graph_loss.append(step_body(k))
@@ -618,7 +604,6 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
             if pipelined:
                 draw_into(idx_bufs[0])  # (the captures ran nothing: re-prime the first buffer)
             launch = "hipgraph, fresh batch per replay" + (", next draw under the step" if pipelined else "") + (
-                ", grads double-buffered (the step clears the next bucket)" if twin else "") + (
                 " (all-reduce captured)" if use_dist else "")
         except Exception as e:  # capture not possible on this stack: measure eagerly and say so
             print("graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
@@ -627,7 +612,7 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
 
     def step():
         k = parity[0]
-        parity[0] ^= 1 if (pipelined or twin) else 0
+        parity[0] ^= 1 if pipelined else 0
         if graphs:
             graphs[k].replay()
             return graph_loss[k]
@@ -766,9 +751,6 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default invocation: skip the abbreviated kitti / ncd-incre legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
-    ap.add_argument("--single-bucket", action="store_true",
-                    help="one gradient bucket cleared by the draw's first pass (default: two buckets, the fused kernel clears "
-                         "the next step's while it fills this step's)")
     ap.add_argument("--pipeline", action="store_true",
                     help="draw the NEXT step's batch on a forked stream under the fused kernel (two alternating graphs); "
                          "measured slower than the in-line draw (profiles/r03_ab_experiments.txt block 9), off by default")

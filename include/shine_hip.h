@@ -74,11 +74,6 @@ typedef struct shine_step_config {
                               the bias corrections; pass zero_grad | 2 to that shine_adam_step_dev call */
   float adam_beta1, adam_beta2;
   double* zero_f64;        /* one device double cleared by the step (shine_regularize's accumulator: out_zeroed = 1 there) */
-  void* clear_ptr;         /* ride-along clear: clear_bytes of device memory (16-byte aligned and sized) zero-filled BY the step */
-  size_t clear_bytes;      /* kernel, a slice per wave and tile, i.e. under its compute instead of in a launch of its own.  Meant
-                              for the gradient bucket of the NEXT step when the grads are double-buffered (the step accumulates
-                              into one bucket while the other, already consumed by the optimiser / exchange, is cleared).  Must
-                              not overlap anything the step reads or accumulates into. */
 } shine_step_config;
 
 /* ---- library ------------------------------------------------------------------------- */

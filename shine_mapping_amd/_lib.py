@@ -41,8 +41,6 @@ class StepConfig(C.Structure):
         ("adam_beta1", C.c_float),
         ("adam_beta2", C.c_float),
         ("zero_f64", C.c_void_p),
-        ("clear_ptr", C.c_void_p),
-        ("clear_bytes", C.c_size_t),
     ]
 
 

@@ -64,12 +64,6 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
                                 float* const* grad_feats, float* const* grad_mlp, double* loss_parts,
                                 unsigned char* const* touched, void* workspace, size_t workspace_bytes, void* stream) {
   if (!cfg) return shine::set_error(SHINE_E_INVALID, "shine_train_step: null config");
-  const int variant = cfg->kernel_variant & 0xff;
-  // the ride-along clear is part of the product kernel; an empty batch and the check library's kernels fill it here
-  if (cfg->clear_ptr && cfg->clear_bytes &&
-      (n == 0 || variant == 1 || variant == 5 || cfg->n_levels > shine::LCAP || !slots) &&
-      hipMemsetAsync(cfg->clear_ptr, 0, cfg->clear_bytes, (hipStream_t)stream) != hipSuccess)
-    return shine::set_error(SHINE_E_HIP, "hipMemsetAsync(clear_ptr)");
   if (n == 0) {  // empty batch: nothing to add to the grads, loss terms are zero
     if (loss_parts && hipMemsetAsync(loss_parts, 0, 4 * sizeof(double), (hipStream_t)stream) != hipSuccess)
       return shine::set_error(SHINE_E_HIP, "hipMemsetAsync(loss_parts)");
@@ -78,6 +72,7 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
   // kernel_variant (low byte): 0 the product kernel (shine_step_v3.hip: planned / pool batches, <= 4 featured levels — every
   // shipped yaml).  The check library adds 1 = the lane-per-point reference kernel (any batch, up to 8 levels; the
   // on-device cross-check of the tests) and 5 = the role-specialised experimental kernel (check/shine_step_v5.hip).
+  const int variant = cfg->kernel_variant & 0xff;
   if (variant == 5) {
     if (!shine_train_step_v5)
       return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 5 is part of the check library (libshine_check.so)");

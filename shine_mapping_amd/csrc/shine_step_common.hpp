@@ -46,8 +46,6 @@ struct V1Args {
   long long* adam_state;  // iteration hooks (cfg->adam_state / zero_f64): housekeeping of the calls that follow the step,
   double* zero_f64;       // done by one thread of the reduction launch
   float adam_b1, adam_b2;
-  float4* clear_ptr;      // ride-along clear (cfg->clear_ptr / clear_bytes): clear_n16 float4s zero-filled by the step kernel
-  long long clear_n16;
   long long* prof;  // debug: per-wave phase cycle counters [waves][8] (shine_debug_set_profile_buffer) or null
   long long n;
   long long chunk;
@@ -174,10 +172,6 @@ inline int fill_step_args(V1Args* a, const shine_tables* t, const shine_step_con
   a->adam_b1 = cfg->adam_beta1;
   a->adam_b2 = cfg->adam_beta2;
   a->zero_f64 = cfg->zero_f64;
-  if (cfg->clear_ptr && (((size_t)cfg->clear_ptr | cfg->clear_bytes) & 15))
-    return set_error(SHINE_E_INVALID, "shine_train_step: clear_ptr / clear_bytes must be 16-byte aligned and sized");
-  a->clear_ptr = reinterpret_cast<float4*>(cfg->clear_ptr);
-  a->clear_n16 = cfg->clear_ptr ? (long long)(cfg->clear_bytes / 16) : 0;
   return SHINE_OK;
 }
 

@@ -242,25 +242,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   const long long second = begin + V3_TP;
 #endif
 
-  // ride-along clear (cfg->clear_ptr: the next step's gradient bucket when the grads are double-buffered): this wave's
-  // contiguous share of the buffer, `zq` 1-KB rows of it per tile, so the stores trickle out under the tiles' compute
-  // instead of filling a launch of their own (13 MB: ~6 us, 72 MB: ~40 us in front of every step otherwise)
-  long long zc = 0, ze = 0;
-  int zq = 0;
-  if (a.clear_n16 > 0) {
-    const long long wtot = (long long)gridDim.x * WAVES;
-    const long long per = (a.clear_n16 + wtot - 1) / wtot;
-    zc = (long long)__builtin_amdgcn_readfirstlane((int)wave_g) * per;
-    ze = zc + per < a.clear_n16 ? zc + per : a.clear_n16;
-#if SHINE_V3_CH > 0
-    const long long my_tiles = njobs;
-#else
-    const long long my_tiles = end > begin ? (end - begin + V3_TP - 1) / V3_TP : 0;
-#endif
-    zq = my_tiles > 0 ? (int)((per + 64 * my_tiles - 1) / (64 * my_tiles)) : 0;
-    zq = __builtin_amdgcn_readfirstlane(zq);
-  }
-
   // software prefetch of the {perm -> coord, label, slot} chain, index two tiles ahead (as in v1 / v2)
   long long np = 0;
   float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, nlabel = 0.f, nweight = 0.f;
@@ -288,8 +269,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   for (long long base = begin; base < end; base += V3_TP) {
 #endif
     asm volatile("" : "+v"(lane_o));  // opaque per tile (see above)
-    for (int u = 0; u < zq; ++u, zc += 64)  // this tile's slice of the ride-along clear
-      if (zc + lane < ze) a.clear_ptr[zc + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int o_pt = lane_o & 15, o_g = lane_o >> 4;
     int* const st_ids = U_ids + (8 * o_g) * V3_WP + o_pt;   // staging writes (level o_g): + c * V3_WP
     float* const st_w = U_w + (8 * o_g) * V3_WP + o_pt;
@@ -864,9 +843,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     wave_lds_fence();
     SHINE_STAMP(4)  // scatter
   }
-
-  for (; zc < ze; zc += 64)  // ride-along clear: what the tile loop left (a wave without tiles: its whole share)
-    if (zc + lane < ze) a.clear_ptr[zc + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // ---- end of the wave's run: flush the open node runs
 #pragma unroll

@@ -17,24 +17,14 @@ from . import _lib
 
 
 class GradReducer:
-    """Flat-bucket gradient all-reduce.  `dist` is torch.distributed (backend nccl = RCCL on ROCm, gloo in CPU tests).
+    """Flat-bucket gradient all-reduce.  `dist` is torch.distributed (backend nccl = RCCL on ROCm, gloo in CPU tests)."""
 
-    double_buffer=True: TWO flat buckets.  `swap()` re-homes every .grad into the other one; the fused step accumulates into
-    the current bucket while it clears `spare` under its own compute (StepOptions.clear), so no launch — and no optimiser
-    pass — has to zero the grads in front of a step:
-
-        reducer.swap(); fused_train_step(..., opts(clear=reducer.spare)); reducer.all_reduce_grads(); opt.step()
-    """
-
-    def __init__(self, params, dist=None, group=None, double_buffer=False):
+    def __init__(self, params, dist=None, group=None):
         self.params = list(params)
         self.dist = dist
         self.group = group
-        self.double_buffer = bool(double_buffer)
         self._flat = None
         self._views = None
-        self._buckets = None  # [(padded, flat, views)] x (1 | 2)
-        self._cur = 0
 
     def _ensure_flat(self):
         """Re-home every .grad as a view into one flat buffer so the collective is a single large message
@@ -46,42 +36,18 @@ class GradReducer:
         if not stale:
             return
         dev = self.params[0].device
-        self._buckets = []
-        for b in range(2 if self.double_buffer else 1):
-            padded = torch.zeros((total + 3) // 4 * 4, dtype=torch.float32, device=dev)
-            flat = padded[:total]
-            views, off = [], 0
-            for p in self.params:
-                v = flat[off: off + p.numel()].view_as(p)
-                if b == 0 and p.grad is not None:
-                    v.copy_(p.grad)
-                views.append(v)
-                off += p.numel()
-            self._buckets.append((padded, flat, views))
-        self._cur = 0
-        self._home(0)
-
-    def _home(self, k):
-        self._cur = k
-        self._flat_padded, self._flat, self._views = self._buckets[k]
-        for p, v in zip(self.params, self._views):
+        padded = torch.zeros((total + 3) // 4 * 4, dtype=torch.float32, device=dev)
+        flat = padded[:total]
+        self._flat_padded = padded
+        views, off = [], 0
+        for p in self.params:
+            v = flat[off: off + p.numel()].view_as(p)
+            if p.grad is not None:
+                v.copy_(p.grad)
             p.grad = v
-
-    def swap(self):
-        """double_buffer: the grads move to the other bucket (which the previous step cleared); returns its index"""
-        self._ensure_flat()
-        if not self.double_buffer:
-            raise RuntimeError("GradReducer.swap() needs double_buffer=True")
-        self._home(self._cur ^ 1)
-        return self._cur
-
-    @property
-    def spare(self):
-        """double_buffer: the padded bucket the grads are NOT in (pass it as StepOptions.clear)"""
-        self._ensure_flat()
-        if not self.double_buffer:
-            raise RuntimeError("GradReducer.spare needs double_buffer=True")
-        return self._buckets[self._cur ^ 1][0]
+            views.append(v)
+            off += p.numel()
+        self._flat, self._views = flat, views
 
     @property
     def flat(self):
@@ -221,8 +187,8 @@ class TouchedRowReducer(GradReducer):
     the same code runs over gloo on CPU tensors in the tests.  `feature_params`: the L feature tables (top-down);
     `other_params`: the decoder tensors."""
 
-    def __init__(self, feature_params, other_params, dist=None, group=None, double_buffer=False):
-        super().__init__(list(feature_params) + list(other_params), dist, group, double_buffer=double_buffer)
+    def __init__(self, feature_params, other_params, dist=None, group=None):
+        super().__init__(list(feature_params) + list(other_params), dist, group)
         self.n_feat = len(list(feature_params))
         self.last_rows = 0      # rows exchanged by the last sparse reduce (all levels)
         self.last_bytes = 0     # message size of the last reduce

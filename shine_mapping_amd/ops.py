@@ -37,9 +37,6 @@ class StepOptions:
     adam_state: Optional[torch.Tensor] = None   # FusedAdam's device step state: the step counts the optimiser step
     adam_betas: tuple = (0.9, 0.99)
     zero_f64: Optional[torch.Tensor] = None     # one float64 element cleared by the step (the regulariser's accumulator)
-    clear: Optional[torch.Tensor] = None        # ride-along clear: a contiguous tensor (16-byte aligned and sized) zero-filled by
-                                                # the step kernel under its compute — the NEXT step's gradient bucket when the
-                                                # grads are double-buffered (dp.GradReducer(double_buffer=True).spare)
     kernel_variant: int = 0           # 0 the fused step; tests / tools: 1 the lane-per-point reference kernel, 5 the
                                       # role-specialised experimental kernel (both in libshine_check.so)
 
@@ -186,10 +183,6 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         cfg.adam_beta1, cfg.adam_beta2 = float(opts.adam_betas[0]), float(opts.adam_betas[1])
     if opts.zero_f64 is not None:
         cfg.zero_f64 = opts.zero_f64.data_ptr()
-    if opts.clear is not None:
-        if not opts.clear.is_contiguous() or opts.clear.device != dev:
-            raise ValueError("StepOptions.clear must be a contiguous tensor on the step's device")
-        cfg.clear_ptr, cfg.clear_bytes = opts.clear.data_ptr(), opts.clear.numel() * opts.clear.element_size()
     if eik and n_surf is None:
         n_surf = (weight > 0).sum()  # stays on the device; under DP the caller all-reduces it first
     pred = torch.empty(n, dtype=torch.float32, device=dev)

@@ -698,95 +698,3 @@ def test_unrolled_graph_replays_draw_the_same_batches_and_count_the_same_steps()
     many()
     torch.cuda.synchronize()
     assert torch.equal(one._idx, many._idx)  # and the next one
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 5])
-@pytest.mark.parametrize("n,eik,clear_floats", [(1, False, 4), (300, True, 1000004), (40000, False, 3000000),
-                                                (1 << 17, True, 64 * 1024 * 33 + 12)])
-def test_ride_along_clear_zeroes_the_spare_bucket_and_nothing_else(n, eik, clear_floats, variant):
-    """StepOptions.clear (cfg->clear_ptr): the step kernel zero-fills another buffer under its compute (the NEXT step's gradient
-    bucket when the grads are double-buffered).  The buffer must come back all-zero — every wave's share, the waves without
-    tiles, the ragged end — the guard words around it untouched, and the step's own results bit-identical to a step without
-    the hook in deterministic mode (the check library's kernels take the memset path of shine_train_step)."""
-    from shine_mapping_amd import Decoder, FeatureOctree, StepOptions, dp, fused_train_step, synth
-
-    cfg = synth.make_config("kitti" if eik else "maicity", device="cuda", tree_level_feat=3)
-    torch.manual_seed(3)
-    octree, dec = FeatureOctree(cfg), Decoder(cfg).cuda()
-    frames = list(synth.make_frames(cfg, frames=2, beams=16, azimuths=120, seed=9, device="cuda"))
-    for c, l, w in frames:
-        octree.update(c[w > 0])
-    pc, pl, pw = (torch.cat([f[k] for f in frames]) for k in range(3))
-    g = torch.Generator(device="cuda").manual_seed(n)
-    sel = torch.randint(0, pc.shape[0], (n,), generator=g, device="cuda")
-    c, l, w = pc[sel].contiguous(), pl[sel].contiguous(), pw[sel].contiguous()
-    w[0] = w[0].abs().clamp_min(1e-3)
-    perm, slots = dp.plan_batch(octree, c)
-    params = list(octree.hier_features) + dec.fused_params()
-
-    def run(clear, deterministic):
-        for p in params:
-            p.grad = torch.zeros_like(p)
-        o = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=eik, weight_e=cfg.weight_e, kernel_variant=variant,
-                        deterministic=deterministic and variant == 0, clear=clear)
-        loss, pred, _ = fused_train_step(octree, dec, c, l, w, o, perm=perm, slots=slots)
-        torch.cuda.synchronize()
-        return float(loss), pred.clone(), [p.grad.clone() for p in params]
-
-    guard = 8
-    for deterministic in ((True, False) if n <= 40000 else (False,)):
-        buf = torch.full((clear_floats + 2 * guard,), 7.0, device="cuda")
-        spare = buf[guard: guard + clear_floats]
-        got = run(spare, deterministic)
-        assert float(spare.abs().max()) == 0.0 and int((spare != 0).sum()) == 0
-        assert bool((buf[:guard] == 7.0).all()) and bool((buf[guard + clear_floats:] == 7.0).all())
-        if deterministic and variant == 0:
-            ref = run(None, True)
-            assert got[0] == ref[0] and torch.equal(got[1], ref[1])
-            assert all(torch.equal(a, b) for a, b in zip(got[2], ref[2]))
-    with pytest.raises((ValueError, RuntimeError)):
-        run(buf[1: 1 + 8], False)  # not 16-byte aligned
-
-
-@pytest.mark.gpu
-def test_double_buffered_grads_equal_an_explicit_zero_grad_loop():
-    """dp.GradReducer(double_buffer=True): K steps of {swap, fused step clearing the spare bucket} must see the gradients of K
-    steps of {zero the one bucket, fused step} — every step starts from a cleared bucket, whichever one it is."""
-    from shine_mapping_amd import StepOptions, dp, fused_train_step
-    from shine_mapping_amd.sampler import SortedPool
-    import copy
-
-    def make(twin):
-        fx = load_golden("maicity_bce_L3")
-        cfg, octree, dec = product_from_golden(fx)
-        dec = dec.cuda()
-        octree._require_tables(with_ranks=True)
-        pool = SortedPool(octree, fx["coord"].cuda().repeat(8, 1), fx["sdf_label"].cuda().repeat(8),
-                          fx["weight"].cuda().repeat(8), seed=5, canonical=True)
-        params = list(octree.hier_features) + dec.fused_params()
-        for p in params:
-            p.grad = torch.zeros_like(p)
-        red = dp.GradReducer(params, None, double_buffer=twin)
-        return octree, dec, pool, params, red, StepOptions(sigma=fx["sigma"], deterministic=True)
-
-    K, N = 5, 2048
-    o1, d1, p1, par1, r1, s1 = make(False)
-    want = []
-    for _ in range(K):
-        idx = p1.draw(N)
-        r1.zero_grads()
-        fused_train_step(o1, d1, None, None, None, s1, pool=p1, idx=idx)
-        want.append(r1.flat.clone())
-    o2, d2, p2, par2, r2, s2 = make(True)
-    seen = set()
-    for k in range(K):
-        idx = p2.draw(N)
-        seen.add(r2.swap())
-        o = copy.copy(s2)
-        o.clear = r2.spare
-        fused_train_step(o2, d2, None, None, None, o, pool=p2, idx=idx)
-        assert par2[0].grad.data_ptr() == r2.flat.data_ptr() and r2.spare.data_ptr() != r2.flat.data_ptr()
-        assert float(r2.spare.abs().max()) == 0.0
-        assert torch.equal(r2.flat, want[k]), "step %d" % k
-    assert seen == {0, 1}

@@ -53,32 +53,3 @@ def test_canonical_order_sorts_inside_nodes_only():
         shuffled[m] = base[m[torch.randperm(m.numel(), generator=g)]]
     assert not torch.equal(shuffled, base)
     assert torch.equal(shuffled[canonical_order(shuffled, slots)], p2)
-
-
-def test_double_buffered_grad_bucket_swaps_every_grad_between_two_flat_buffers():
-    """dp.GradReducer(double_buffer=True): .grad of every parameter is a view into ONE of two flat buckets; swap() re-homes
-    all of them into the other one (the fused step clears `spare` while it fills `flat`, StepOptions.clear)."""
-    from shine_mapping_amd import dp
-
-    params = [torch.nn.Parameter(torch.randn(5, 8)), torch.nn.Parameter(torch.randn(3)), torch.nn.Parameter(torch.randn(2, 2))]
-    for i, p in enumerate(params):
-        p.grad = torch.full_like(p, float(i + 1))
-    red = dp.GradReducer(params, None, double_buffer=True)
-    flat0 = red.flat
-    assert flat0.numel() % 4 == 0 and flat0.numel() >= 47
-    assert torch.equal(flat0[:40], torch.ones(40)) and torch.equal(flat0[40:43], torch.full((3,), 2.0))  # grads carried over
-    spare0 = red.spare
-    assert spare0.data_ptr() != flat0.data_ptr() and float(spare0.abs().max()) == 0.0
-    assert red.swap() == 1
-    assert red.flat.data_ptr() == spare0.data_ptr() and red.spare.data_ptr() == flat0.data_ptr()
-    off = 0
-    for p in params:  # every grad is now a view of the second bucket, at its flat offset
-        assert p.grad.data_ptr() == red.flat.data_ptr() + 4 * off and p.grad.shape == p.shape
-        off += p.numel()
-    params[1].grad.add_(5.0)
-    assert torch.equal(red.flat[40:43], torch.full((3,), 5.0))
-    assert red.swap() == 0 and params[0].grad.data_ptr() == flat0.data_ptr()
-    red.zero_grads()
-    assert float(flat0.abs().max()) == 0.0 and float(red.spare[40:43].min()) == 5.0
-    with pytest.raises(RuntimeError):
-        dp.GradReducer(params, None).swap()
