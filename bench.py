@@ -534,35 +534,24 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
     if flags is not None:
         for f in flags:
             f.zero_()
-    # Default: draw, then step, on one stream.  --pipeline: two index buffers, the sorted draw of step i + 1 on a forked stream
-    # UNDER the fused kernel of step i (measured SLOWER: the fork/join of a two-branch HIP graph costs more than the two small
-    # launches it hides — profiles/r03_ab_experiments.txt block 9).  Either way every step draws its own fresh batch (the
-    # sampler's stream id lives in device memory and advances with every draw).
-    idx_bufs = [torch.empty(points, dtype=torch.int32, device=dev) for _ in range(2)]
-    pipelined = bool(args.pipeline)
-    side = torch.cuda.Stream(device=dev) if pipelined else None
+    # One stream: draw -> fused step -> reduction (-> exchange).  Every step draws its own fresh batch (the sampler's stream id
+    # lives in device memory and advances with every draw).  (Drawing the next batch on a forked graph branch under the fused
+    # kernel was measured slower — profiles/r03_ab_experiments.txt block 9.)
+    idx_buf = torch.empty(points, dtype=torch.int32, device=dev)
+    surf_parts = spool.surf_parts_buffer(points) if opts.ekional_loss_on else None
 
-    def draw_into(buf, zero=None):
+    def step_body():
+        """draw (its first pass also clears the gradient bucket: opt.zero_grad()) -> fused step on this rank's slice (-> exchange)"""
         # this rank's contiguous slice of the ONE global sorted draw (same seed / draw count on every rank): only the
         # slice's indices are generated (shine_sample_sorted_slice), so the draw does not grow with the world size
-        return spool.draw(points, out=buf, zero=zero, graph_safe=True, n_global=n_global, slice_begin=rank * points)
-
-    def step_body(k=0):
-        """[draw of the NEXT batch on the side stream] clear grads -> fused step on this rank's slice (-> exchange)"""
-        main = torch.cuda.current_stream()
-        if pipelined:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                draw_into(idx_bufs[k ^ 1])
-            reducer.flat.zero_()  # opt.zero_grad(): one fill of the flat gradient bucket
-            idx = idx_bufs[k]
-        else:
-            idx = draw_into(idx_bufs[0], zero=reducer.flat)  # (the draw's first pass also clears the bucket)
-        n_surf = None
-        if opts.ekional_loss_on:  # global surface count: local count + an 8-byte all-reduce
-            n_surf = (spool.weight[idx.long()] > 0).sum()
-            if use_dist:
-                reducer.all_reduce_scalar(n_surf)
+        idx = spool.draw(points, out=idx_buf, zero=reducer.flat, graph_safe=True, n_global=n_global,
+                         slice_begin=rank * points, surf_parts=surf_parts)
+        # eikonal: the surface count of the batch comes out of the draw as per-block partial counts which the step's kernels
+        # add up (no launch of its own); data parallel: the global count = sum of the parts + an 8-byte all-reduce
+        n_surf = surf_parts
+        if surf_parts is not None and use_dist:
+            n_surf = surf_parts.sum()
+            reducer.all_reduce_scalar(n_surf)
         loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx)
         if use_dist:
             if exchange == "touched":
@@ -571,60 +560,63 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
                 reducer.all_reduce_touched(flags)
             else:
                 reducer.all_reduce_grads()
-        if pipelined:
-            main.wait_stream(side)
         return loss
-
-    if pipelined:
-        draw_into(idx_bufs[0])  # prime: the batch of the first step
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The loop body has no host sync and no allocation outside torch's allocator, so it is captured into ONE HIP graph
-    # and replayed (launch-bound inner loops belong in hipGraphs).  With the dense exchange the RCCL all-reduce is
-    # captured with it; the touched-row exchange reads a row count on the host and stays eager.
+    # The loop body has no host sync and no allocation outside torch's allocator, so it is captured into HIP graphs and
+    # replayed (launch-bound inner loops belong in hipGraphs): one graph of `--graph-steps` U consecutive steps — a replay
+    # costs ~9 us of idle GPU at its boundary whatever it holds, so K steps run as K // U replays of it plus K % U replays of
+    # a one-step graph; every step in either graph is the full body above with its own draw.  With the dense exchange the RCCL
+    # all-reduce is captured with it; the touched-row exchange reads a row count on the host and stays eager.
     launch = "eager"
-    graphs, graph_loss = [], []
-    parity = [0]
+    U = max(1, int(args.graph_steps))
+    graph_u = graph_1 = None
+    loss_u = loss_1 = None
     if not args.no_graph and not (use_dist and exchange == "touched"):
         try:
-            for _ in range(4):
-                step_body(parity[0])  # warm caches / allocate workspaces / RCCL channels outside capture
-                parity[0] ^= 1
+            for _ in range(3):
+                step_body()  # warm caches / allocate workspaces / RCCL channels outside capture
             barrier()
-            for k in ((0, 1) if pipelined else (0,)):  # pipelined: one graph per buffer parity, replayed alternately
-                g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_):
-                    graph_loss.append(step_body(k))
-                graphs.append(g_)
-            parity[0] = 0
-            if pipelined:
-                draw_into(idx_bufs[0])  # (the captures ran nothing: re-prime the first buffer)
-            launch = "hipgraph, fresh batch per replay" + (", next draw under the step" if pipelined else "") + (
-                " (all-reduce captured)" if use_dist else "")
+            graph_1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_1):
+                loss_1 = step_body()
+            if U > 1:
+                graph_u = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_u):
+                    for _ in range(U):
+                        loss_u = step_body()
+            launch = "hipgraph, %d step%s per replay, fresh batch per step%s" % (
+                U, "s" if U > 1 else "", " (all-reduce captured)" if use_dist else "")
         except Exception as e:  # capture not possible on this stack: measure eagerly and say so
             print("graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
-            graphs, graph_loss, launch = [], [], "eager"
+            graph_u = graph_1 = None
+            launch = "eager"
             torch.cuda.synchronize()
 
-    def step():
-        k = parity[0]
-        parity[0] ^= 1 if pipelined else 0
-        if graphs:
-            graphs[k].replay()
-            return graph_loss[k]
-        return step_body(k)
+    def run(k):
+        """exactly k steps -> the last step's loss"""
+        out = None
+        if graph_1 is None:
+            for _ in range(k):
+                out = step_body()
+            return out
+        q, r = divmod(k, U) if graph_u is not None else (0, k)
+        for _ in range(q):
+            graph_u.replay()
+            out = loss_u
+        for _ in range(r):
+            graph_1.replay()
+            out = loss_1
+        return out
 
-    loss = None
-    for _ in range(warmup):
-        step()
+    run(warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
+    loss = run(steps)
     barrier()
     dt_local = time.perf_counter() - t0
     dt, rank_ms = dt_local, None
@@ -751,9 +743,8 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default invocation: skip the abbreviated kitti / ncd-incre legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="draw the NEXT step's batch on a forked stream under the fused kernel (two alternating graphs); "
-                         "measured slower than the in-line draw (profiles/r03_ab_experiments.txt block 9), off by default")
+    ap.add_argument("--graph-steps", type=int, default=4,
+                    help="steps captured per HIP graph (K steps = K // U replays + K % U one-step replays)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "dense", "touched"],
                     help="data-parallel gradient exchange: one flat all-reduce of the dense grads, or only the rows the "
                          "global batch touched (auto: touched when the dense bucket exceeds 64 MB)")

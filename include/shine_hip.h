@@ -74,6 +74,8 @@ typedef struct shine_step_config {
                               the bias corrections; pass zero_grad | 2 to that shine_adam_step_dev call */
   float adam_beta1, adam_beta2;
   double* zero_f64;        /* one device double cleared by the step (shine_regularize's accumulator: out_zeroed = 1 there) */
+  int32_t n_surf_parts;    /* shine_train_step's n_surf points at this many (<= 64) int64 partial counts which the kernels add up
+                              (what shine_sample_sorted_* writes to surf_parts); 0 / 1 = one count */
 } shine_step_config;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -270,9 +272,15 @@ int shine_plan_batch(const shine_tables* t, const shine_step_config* cfg, const 
  *      the drawn batch is already ordered: pass idx_out as `perm` to shine_train_step with cfg->sorted_input = 2.
  *      idx_out [n] int32 ascending; (seed, stream_id) select the random stream (use the iteration number as
  *      stream_id).  zero_ptr/zero_bytes: optional 16-B aligned buffer cleared in the same pass (the gradient bucket).
- *      workspace == NULL returns the required bytes. ------------------------------------------------------------------ */
+ *      surf_parts (optional, with weight = the pool's weights [pool_size]): device int64[SHINE_SURF_PARTS]; the launches that
+ *      write the indices also count the draws (of the slice, for shine_sample_sorted_slice) with weight > 0 — the surface
+ *      samples the eikonal term averages over (shine_batch.py:183-185) — as 64 partial counts (overwritten): hand them to
+ *      shine_train_step as n_surf with cfg->n_surf_parts = SHINE_SURF_PARTS.  workspace == NULL returns the required
+ *      bytes. --------------------------------------------------------------------------------------------------------- */
+#define SHINE_SURF_PARTS 64
 int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,
-                        void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
+                        void* zero_ptr, size_t zero_bytes, const float* weight, int64_t* surf_parts, void* workspace,
+                        size_t* workspace_bytes, void* stream);
 
 /* the same draw for ONE data-parallel rank: only draws [slice_begin, slice_begin + slice_n) of the global sorted batch of
  * n draws are written (idx_out [slice_n]); every rank passes the same (seed, stream id) and its own slice, so the ranks'
@@ -280,7 +288,8 @@ int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t st
  * uint64[4] (graph-replayable, as shine_sample_sorted_dev) or NULL to use stream_id. */
 int shine_sample_sorted_slice(int64_t pool_size, int64_t n, int64_t slice_begin, int64_t slice_n, uint64_t seed,
                               uint64_t stream_id, uint64_t* stream_state, int32_t* idx_out, void* zero_ptr,
-                              size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
+                              size_t zero_bytes, const float* weight, int64_t* surf_parts, void* workspace,
+                              size_t* workspace_bytes, void* stream);
 
 /* ---- data-parallel exchange of the rows a step touched (the reference is single-GPU: no counterpart).
  *      flags[l]: uint8 [rows[l]] from shine_mark_touched (OR-reduced over the ranks), rows[l] = the level's row count
@@ -317,7 +326,8 @@ int shine_query_points(const shine_tables* t, const shine_step_config* cfg, cons
  *      (cfg->adam_state): no preparation launch;  lr_dev: device float[n_tensors]
  *      (step_lr_decay, utils/tools.py:135-155, becomes a small device copy outside the graph). --------------------- */
 int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t seed, uint64_t* stream_state, int32_t* idx_out,
-                            void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream);
+                            void* zero_ptr, size_t zero_bytes, const float* weight, int64_t* surf_parts, void* workspace,
+                            size_t* workspace_bytes, void* stream);
 int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const float* weight_decay,
                         float beta1, float beta2, float eps, int64_t* step_state, int32_t zero_grad, void* stream);

@@ -41,6 +41,7 @@ class StepConfig(C.Structure):
         ("adam_beta1", C.c_float),
         ("adam_beta2", C.c_float),
         ("zero_f64", C.c_void_p),
+        ("n_surf_parts", C.c_int32),
     ]
 
 
@@ -93,10 +94,10 @@ _SIGNATURES = {
     "shine_adam_step_dev": (
         C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
                   _P, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _P, C.c_int32, _P]),
-    "shine_sample_sorted_dev": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, _P, _P, _P, C.c_size_t, _P,
+    "shine_sample_sorted_dev": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, _P, _P, _P, C.c_size_t, _P, _P, _P,
                                           C.POINTER(C.c_size_t), _P]),
     "shine_sample_sorted_slice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, _P,
-                                            C.c_size_t, _P, C.POINTER(C.c_size_t), _P]),
+                                            C.c_size_t, _P, _P, _P, C.POINTER(C.c_size_t), _P]),
     "shine_touched_index": (C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, _P,
                                       C.POINTER(C.c_size_t), _P]),
     "shine_touched_pack": (C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
@@ -111,8 +112,8 @@ _SIGNATURES = {
     "shine_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
     "shine_selftest_permlane": (C.c_int, [_P, _P, _P, _P, _P]),
     "shine_debug_set_profile_buffer": (None, [_P]),
-    "shine_sample_sorted": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, C.c_size_t, _P,
-                                      C.POINTER(C.c_size_t), _P]),
+    "shine_sample_sorted": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, C.c_size_t, _P, _P,
+                                      _P, C.POINTER(C.c_size_t), _P]),
     "shine_tables_set_ranks": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, C.c_int64, _P]),
     "shine_plan_batch": (C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, _P, _P, _P, C.c_size_t, _P,
                                    C.POINTER(C.c_size_t), _P]),

@@ -43,6 +43,27 @@ __device__ __forceinline__ double block_sum_256(double v, double* s_red) {
   return t;
 }
 
+// Surface count of the batch (the eikonal term averages over the samples with weight > 0, shine_batch.py:183-185): the launch
+// that writes the indices also counts its draws with weight > 0 into surf_parts, int64[SHINE_SURF_PARTS = 64] partial counts
+// that the fused step adds up itself (one load per lane, cfg->n_surf_parts) — no launch of its own; in torch the same number
+// costs six launches (index, compare, sum, ...: 45 us at 2^20 draws).  Two-launch form: pass 1 clears the 64 parts, block j of
+// pass 2 adds its count to part j % 64 with one relaxed atomic (<= 16-fold contention per address for 2^20 draws; ONE shared
+// counter would serialise ~1000 same-address atomics, and one part per block would make every wave of the step read ~1000
+// words: 17 dependent round trips in its prologue, measured +13 us).  One-launch form (<= 16 blocks): block j stores part j.
+constexpr int SURF_PARTS = 64;
+
+__device__ __forceinline__ void block_count_256(int v, int* s_cnt, long long* surf_parts, int part, bool plain_store) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long c = (long long)(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+    if (plain_store) surf_parts[part] = c;
+    else __hip_atomic_fetch_add(surf_parts + part, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // stream_dev != nullptr: the stream id is read from device memory (graph-replayable form, shine_sample_sorted_dev):
 // uint64[4] = {A = stream id, block counter of the one-launch form, B = shadow of A, reserved}.  The two-launch form advances
 // the id without atomics: pass 1 reads A and its block 0 stores B = A + 1 (nothing in pass 1 reads B); pass 2 reads B - 1
@@ -50,8 +71,9 @@ __device__ __forceinline__ double block_sum_256(double v, double* s_red) {
 // costs one fenced same-address atomic per block: 22-40 ns each, serialised — 41 us for the 1025 blocks of a 2^20 draw.)
 __global__ __launch_bounds__(256) void k_sample_pass1(double* block_sum, long long n1, unsigned long long seed,
                                                       unsigned long long stream, const unsigned long long* stream_dev,
-                                                      float4* zero_ptr, long long zero_n16) {
+                                                      float4* zero_ptr, long long zero_n16, long long* surf_parts) {
   __shared__ double s_red[4];
+  if (surf_parts && blockIdx.x == 0 && threadIdx.x < SURF_PARTS) surf_parts[threadIdx.x] = 0;  // pass 2 adds to them
   if (stream_dev) {
     stream = stream_dev[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<unsigned long long*>(stream_dev)[2] = stream + 1ull;
@@ -74,9 +96,10 @@ __global__ __launch_bounds__(256) void k_sample_pass1(double* block_sum, long lo
 __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, int nblocks, long long n, long long pool,
                                                       unsigned long long seed, unsigned long long stream,
                                                       unsigned long long* stream_dev, int* idx, int blk0, long long lo,
-                                                      long long cnt) {
+                                                      long long cnt, const float* weight, long long* surf_parts) {
   __shared__ double s_red[4];
   __shared__ double s_wave_pre[4];
+  __shared__ int s_cnt[4];
   if (stream_dev) {
     stream = stream_dev[2] - 1ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) stream_dev[0] = stream + 1ull;
@@ -110,14 +133,18 @@ __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, i
   double wpre = 0.0;
   for (int w = 0; w < wv; ++w) wpre += s_wave_pre[w];
   double s = before + wpre + (inc - run);
+  int surf = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     s += e[j];
     if (k0 + j < n && k0 + j >= lo && k0 + j < lo + cnt) {
       long long v = (long long)((s / total) * (double)pool);
-      idx[k0 + j - lo] = (int)(v < 0 ? 0 : (v >= pool ? pool - 1 : v));
+      v = v < 0 ? 0 : (v >= pool ? pool - 1 : v);
+      idx[k0 + j - lo] = (int)v;
+      if (surf_parts) surf += weight[v] > 0.f ? 1 : 0;
     }
   }
+  if (surf_parts) block_count_256(surf, s_cnt, surf_parts, (blk0 + (int)blockIdx.x) & (SURF_PARTS - 1), false);
 }
 
 // Small draws (the reference's bs = 4096 is 5 blocks): ONE launch.  Every block first recomputes all the block sums
@@ -127,10 +154,12 @@ constexpr int FUSED_MAX_BLOCKS = 16;
 
 __global__ __launch_bounds__(256) void k_sample_fused(int nblocks, long long n, long long pool, unsigned long long seed,
                                                       unsigned long long stream, unsigned long long* stream_dev, int* idx,
-                                                      float4* zero_ptr, long long zero_n16) {
+                                                      float4* zero_ptr, long long zero_n16, const float* weight,
+                                                      long long* surf_parts) {
   __shared__ double s_red[4];
   __shared__ double s_wave_pre[4];
   __shared__ double s_bs[FUSED_MAX_BLOCKS];
+  __shared__ int s_cnt[4];
   if (stream_dev) stream = stream_dev[0];
   const long long n1 = n + 1;
   const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -172,13 +201,20 @@ __global__ __launch_bounds__(256) void k_sample_fused(int nblocks, long long n, 
   double wpre = 0.0;
   for (int w = 0; w < wv; ++w) wpre += s_wave_pre[w];
   double sacc = before + wpre + (inc - run);
+  int surf = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     sacc += e[j];
     if (k0 + j < n) {
       long long v = (long long)((sacc / total) * (double)pool);
-      idx[k0 + j] = (int)(v < 0 ? 0 : (v >= pool ? pool - 1 : v));
+      v = v < 0 ? 0 : (v >= pool ? pool - 1 : v);
+      idx[k0 + j] = (int)v;
+      if (surf_parts) surf += weight[v] > 0.f ? 1 : 0;
     }
+  }
+  if (surf_parts) {
+    block_count_256(surf, s_cnt, surf_parts, (int)blockIdx.x, true);
+    if (blockIdx.x == 0 && (int)threadIdx.x >= nblocks && threadIdx.x < SURF_PARTS) surf_parts[threadIdx.x] = 0;
   }
   if (stream_dev) {  // the last block to finish advances the stream id (<= 16 blocks: the counter costs < 1 us here)
     __syncthreads();
@@ -202,8 +238,8 @@ using namespace shine;
 
 static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id,
                               unsigned long long* stream_dev, int32_t* idx_out, void* zero_ptr, size_t zero_bytes,
-                              void* workspace, size_t* workspace_bytes, void* stream, int64_t slice_begin = 0,
-                              int64_t slice_n = -1) {
+                              const float* weight, int64_t* surf_parts, void* workspace, size_t* workspace_bytes,
+                              void* stream, int64_t slice_begin = 0, int64_t slice_n = -1) {
   if (slice_n < 0) slice_n = n - slice_begin;
   if (!workspace_bytes || n < 0 || pool_size < 1 || pool_size > 0x7fffffffll || slice_begin < 0 || slice_n < 0 ||
       slice_begin + slice_n > n)
@@ -219,29 +255,32 @@ static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint6
   if (*workspace_bytes < need) return set_error(SHINE_E_INVALID, "shine_sample_sorted: workspace too small");
   if (zero_ptr && (((size_t)zero_ptr | zero_bytes) & 15))
     return set_error(SHINE_E_INVALID, "shine_sample_sorted: zero buffer must be 16-byte aligned and sized");
+  // pass 2 over the blocks that hold the slice (an empty slice still runs one block: it advances the device stream id)
+  const long long b0 = slice_n > 0 ? slice_begin / SB : 0;
+  const long long b1 = slice_n > 0 ? (slice_begin + slice_n - 1) / SB : 0;
+  if (surf_parts && !weight) return set_error(SHINE_E_INVALID, "shine_sample_sorted: surf_parts needs the pool's weights");
   if (n == 0) {
     if (zero_ptr && zero_bytes) SHINE_HIP_CHECK(hipMemsetAsync(zero_ptr, 0, zero_bytes, st));
+    if (surf_parts) SHINE_HIP_CHECK(hipMemsetAsync(surf_parts, 0, (size_t)SURF_PARTS * 8, st));
     return SHINE_OK;
   }
   if (!idx_out) return set_error(SHINE_E_INVALID, "shine_sample_sorted: null output");
   if (nblocks <= FUSED_MAX_BLOCKS && slice_begin == 0 && slice_n == n) {
     hipLaunchKernelGGL(k_sample_fused, dim3((unsigned)nblocks), dim3(256), 0, st, (int)nblocks, (long long)n,
                        (long long)pool_size, (unsigned long long)seed, (unsigned long long)stream_id, stream_dev,
-                       (int*)idx_out, (float4*)zero_ptr, zero_ptr ? (long long)(zero_bytes / 16) : 0ll);
+                       (int*)idx_out, (float4*)zero_ptr, zero_ptr ? (long long)(zero_bytes / 16) : 0ll, weight,
+                       (long long*)surf_parts);
     SHINE_HIP_CHECK(hipGetLastError());
     return SHINE_OK;
   }
   double* bs = (double*)workspace;
   hipLaunchKernelGGL(k_sample_pass1, dim3((unsigned)nblocks), dim3(256), 0, st, bs, n1, (unsigned long long)seed,
                      (unsigned long long)stream_id, (const unsigned long long*)stream_dev, (float4*)zero_ptr,
-                     zero_ptr ? (long long)(zero_bytes / 16) : 0ll);
+                     zero_ptr ? (long long)(zero_bytes / 16) : 0ll, (long long*)surf_parts);
   SHINE_HIP_CHECK(hipGetLastError());
-  // pass 2 over the blocks that hold the slice (an empty slice still runs one block: it advances the device stream id)
-  const long long b0 = slice_n > 0 ? slice_begin / SB : 0;
-  const long long b1 = slice_n > 0 ? (slice_begin + slice_n - 1) / SB : 0;
   hipLaunchKernelGGL(k_sample_pass2, dim3((unsigned)(b1 - b0 + 1)), dim3(256), 0, st, bs, (int)nblocks, (long long)n,
                      (long long)pool_size, (unsigned long long)seed, (unsigned long long)stream_id, stream_dev,
-                     (int*)idx_out, (int)b0, (long long)slice_begin, (long long)slice_n);
+                     (int*)idx_out, (int)b0, (long long)slice_begin, (long long)slice_n, weight, (long long*)surf_parts);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }
@@ -251,22 +290,23 @@ static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint6
 // shine_sample_sorted_dev, or NULL to use stream_id.
 extern "C" int shine_sample_sorted_slice(int64_t pool_size, int64_t n, int64_t slice_begin, int64_t slice_n, uint64_t seed,
                                          uint64_t stream_id, uint64_t* stream_state, int32_t* idx_out, void* zero_ptr,
-                                         size_t zero_bytes, void* workspace, size_t* workspace_bytes, void* stream) {
+                                         size_t zero_bytes, const float* weight, int64_t* surf_parts, void* workspace,
+                                         size_t* workspace_bytes, void* stream) {
   return sample_sorted_impl(pool_size, n, seed, stream_id, (unsigned long long*)stream_state, idx_out, zero_ptr,
-                            zero_bytes, workspace, workspace_bytes, stream, slice_begin, slice_n);
+                            zero_bytes, weight, surf_parts, workspace, workspace_bytes, stream, slice_begin, slice_n);
 }
 
 extern "C" int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,
-                                   void* zero_ptr, size_t zero_bytes, void* workspace, size_t* workspace_bytes,
-                                   void* stream) {
-  return sample_sorted_impl(pool_size, n, seed, stream_id, nullptr, idx_out, zero_ptr, zero_bytes, workspace,
-                            workspace_bytes, stream);
+                                   void* zero_ptr, size_t zero_bytes, const float* weight, int64_t* surf_parts,
+                                   void* workspace, size_t* workspace_bytes, void* stream) {
+  return sample_sorted_impl(pool_size, n, seed, stream_id, nullptr, idx_out, zero_ptr, zero_bytes, weight, surf_parts,
+                            workspace, workspace_bytes, stream);
 }
 
 extern "C" int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t seed, uint64_t* stream_state,
-                                       int32_t* idx_out, void* zero_ptr, size_t zero_bytes, void* workspace,
-                                       size_t* workspace_bytes, void* stream) {
+                                       int32_t* idx_out, void* zero_ptr, size_t zero_bytes, const float* weight,
+                                       int64_t* surf_parts, void* workspace, size_t* workspace_bytes, void* stream) {
   if (workspace && !stream_state) return set_error(SHINE_E_INVALID, "shine_sample_sorted_dev: null stream_state");
   return sample_sorted_impl(pool_size, n, seed, 0, (unsigned long long*)stream_state, idx_out, zero_ptr, zero_bytes,
-                            workspace, workspace_bytes, stream);
+                            weight, surf_parts, workspace, workspace_bytes, stream);
 }

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void k_mark_touched(V1Args a) {
 __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks) {
   __shared__ float s_red[16][64];
   __shared__ double s_dred[16][3];
+  __shared__ long long s_ns;  // the batch's surface count (eikonal): the sum of the <= 64 parts of cfg->n_surf_parts
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
   const int L = a.n_levels;
@@ -111,6 +112,12 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
       d += reinterpret_cast<const double*>(a.partials + (long long)b * PART_STRIDE + PART_LOSS)[lane];
     s_dred[part][lane] = d;
   }
+  if (blockIdx.x == 0 && part == 15) {  // one wave adds up the surface-count parts: one load per lane
+    int c = (a.n_surf && lane < a.n_surf_parts && a.n_surf_parts > 1) ? (int)a.n_surf[lane] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) s_ns = a.n_surf ? (a.n_surf_parts > 1 ? (long long)c : *a.n_surf) : 0;
+  }
   __syncthreads();
   if (dst) {
     float tot = 0.f;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
       cs += s_dred[k][1];
       es += s_dred[k][2];
     }
-    const long long ns = a.n_surf ? *a.n_surf : 0;
+    const long long ns = s_ns;
     const double bce = a.reduction_sum ? ls : ls * (double)a.inv_n;
     const double eik = ns > 0 ? es * (double)(1.0f / (float)ns) : 0.0;
     a.loss_parts[0] = bce;

@@ -176,8 +176,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   for (int r = 0; r < (EIK ? 8 : 1); ++r) db2c[r] = db1c[r] = 0.f;
   float eik_acc = 0.f;
   float inv_nsurf = 0.f;
-  if (EIK) {
-    const long long ns = a.n_surf ? *a.n_surf : 0;
+  if (EIK) {  // the batch's surface count: one number, or the sampler's per-block parts (cfg->n_surf_parts) added up here
+    long long ns = 0;
+    if (a.n_surf) {
+      if (a.n_surf_parts <= 1) {
+        ns = *a.n_surf;
+      } else {
+        int c = lane < a.n_surf_parts ? (int)a.n_surf[lane] : 0;  // (<= 64 parts: one load per lane)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        ns = c;
+      }
+    }
     inv_nsurf = ns > 0 ? 1.0f / (float)ns : 0.f;
   }
   float db3 = 0.f;

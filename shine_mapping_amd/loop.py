@@ -64,7 +64,8 @@ class GraphedIteration:
         self.touched = touched_flags(octree) if self.regularize else None
         self._epoch = octree._tables_epoch
         self._idx = torch.empty(self.n, dtype=torch.int32, device=pool.coord.device)
-        self._nsurf = torch.zeros((), dtype=torch.int64, device=pool.coord.device)
+        # the eikonal term's surface count: per-block partial counts written by the draw itself, summed by the step's kernels
+        self._surf = pool.surf_parts_buffer(self.n) if opts.ekional_loss_on else None
         self.loss = self.reg = None
         self._reg_out = torch.zeros(1, dtype=torch.float64, device=pool.coord.device) if self.regularize else None
         self._hooked = None  # StepOptions with the iteration hooks (made once the optimiser has its device state)
@@ -85,11 +86,8 @@ class GraphedIteration:
             self.graph_k, (self.loss_k, self.reg_k) = _capture(body_k)
 
     def _body(self):
-        idx = self.pool.draw(self.n, out=self._idx, graph_safe=True)
-        n_surf = None
-        if self.opts.ekional_loss_on:
-            self._nsurf.copy_((self.pool.weight[idx.long()] > 0).sum())
-            n_surf = self._nsurf
+        idx = self.pool.draw(self.n, out=self._idx, graph_safe=True, surf_parts=self._surf)
+        n_surf = self._surf
         # Iteration hooks: the step's reduction launch also counts the optimiser step (+ bias corrections) and clears the
         # regulariser's accumulator, so neither costs a launch of its own (an iteration at N = 4096 is a chain of small
         # launches: each one removed saves its run time and ~2 us of dependency gap).  The optimiser's device state exists

@@ -185,6 +185,13 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         cfg.zero_f64 = opts.zero_f64.data_ptr()
     if eik and n_surf is None:
         n_surf = (weight > 0).sum()  # stays on the device; under DP the caller all-reduces it first
+    if eik and n_surf.numel() > 1:  # the sampler's per-block partial counts (SortedPool.draw(surf_parts=...))
+        if n_surf.dtype != torch.int64 or not n_surf.is_contiguous():
+            raise ValueError("n_surf parts must be a contiguous int64 tensor")
+        if (int(opts.kernel_variant) & 0xff) in (1, 5) or slots is None:
+            n_surf = n_surf.sum()  # the check library's kernels take one count
+        else:
+            cfg.n_surf_parts = int(n_surf.numel())
     pred = torch.empty(n, dtype=torch.float32, device=dev)
     gx = torch.empty((n, 3), dtype=torch.float32, device=dev) if (want_grad_x and eik) else None
     loss_parts = torch.empty(4, dtype=torch.float64, device=dev)  # overwritten by the step; set_zero is in-kernel

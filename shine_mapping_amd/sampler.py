@@ -24,6 +24,8 @@ def canonical_order(perm, slots):
     return torch.argsort(key)
 
 
+SURF_PARTS = 64  # include/shine_hip.h SHINE_SURF_PARTS
+
 class SortedPool:
     def __init__(self, octree, coord, sdf_label, weight, seed=42, canonical=False):
         """`canonical`: order the samples of one node by their original pool index.  The plan's counting sort places the
@@ -56,56 +58,62 @@ class SortedPool:
         for k in [k for k in self._ws if k[1] != self.size]:
             del self._ws[k]
 
-    def draw(self, n, out=None, zero=None, graph_safe=False, n_global=None, slice_begin=0):
+    def draw(self, n, out=None, zero=None, graph_safe=False, n_global=None, slice_begin=0, surf_parts=None):
         """n sorted i.i.d. uniform sample indices (int32, device).  `zero`: optional contiguous float tensor cleared in
         the same pass (the flat gradient bucket, i.e. opt.zero_grad()).  `graph_safe`: the stream id is read from (and
         advanced in) device memory, so a captured HIP graph of this call draws a fresh batch at every replay.
         Data parallel: `n_global` / `slice_begin` — this call returns draws [slice_begin, slice_begin + n) of ONE global
         sorted batch of n_global draws that every rank agrees on (same seed, same draw count): the rank's contiguous
-        slice of the node-ordered global batch without generating the other ranks' indices."""
+        slice of the node-ordered global batch without generating the other ranks' indices.
+        `surf_parts` (surf_parts_buffer()): the launches that write the indices also count the drawn samples with weight > 0
+        (the eikonal term's surface samples, shine_batch.py:183-185) into it, as 64 partial counts — pass the tensor to
+        fused_train_step as n_surf (the kernels add the parts up); in torch the count costs six launches."""
         dev = self.coord.device
         lib = _lib.lib()
         stream = _lib.current_stream_handle()
         sliced = n_global is not None and (int(n_global) != n or slice_begin)
         nd = int(n_global) if sliced else n  # the draw whose spacings pass 1 sums
         ws = self._ws.get((nd, self.size))
+        none13 = (None, None)
         if ws is None:
             need = C.c_size_t(0)
-            _lib.check(lib.shine_sample_sorted(self.size, nd, self.seed, 0, None, None, 0, None, C.byref(need), stream),
-                       "shine_sample_sorted")
+            _lib.check(lib.shine_sample_sorted(self.size, nd, self.seed, 0, None, None, 0, *none13, None, C.byref(need),
+                                               stream), "shine_sample_sorted")
             ws = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev), nd, int(need.value))
             self._ws[(nd, self.size)] = ws
         idx = out if out is not None else torch.empty(n, dtype=torch.int32, device=dev)
         need = C.c_size_t(ws[2])
-        if sliced:
-            state = None
-            if graph_safe:
-                if self._stream_state is None:
-                    self._stream_state = torch.tensor([self.draws, 0, self.draws, 0], dtype=torch.int64, device=dev)
-                state = self._stream_state.data_ptr()
-            _lib.check(lib.shine_sample_sorted_slice(self.size, nd, int(slice_begin), n, self.seed, self.draws, state,
-                                                     idx.data_ptr(), zero.data_ptr() if zero is not None else None,
-                                                     zero.numel() * zero.element_size() if zero is not None else 0,
-                                                     ws[0].data_ptr(), C.byref(need), stream),
-                       "shine_sample_sorted_slice")
-            if not graph_safe:
-                self.draws += 1
-            return idx
+        zero_args = (zero.data_ptr() if zero is not None else None,
+                     zero.numel() * zero.element_size() if zero is not None else 0)
+        surf_args = none13
+        if surf_parts is not None:
+            if (surf_parts.dtype != torch.int64 or not surf_parts.is_contiguous() or surf_parts.device != dev
+                    or surf_parts.numel() != SURF_PARTS):
+                raise ValueError("surf_parts must be a contiguous int64[%d] tensor on the pool's device "
+                                 "(surf_parts_buffer())" % SURF_PARTS)
+            surf_args = (self.weight.data_ptr(), surf_parts.data_ptr())
+        state = None
         if graph_safe:
             if self._stream_state is None:
                 self._stream_state = torch.tensor([self.draws, 0, self.draws, 0], dtype=torch.int64, device=dev)
-            _lib.check(lib.shine_sample_sorted_dev(self.size, n, self.seed, self._stream_state.data_ptr(), idx.data_ptr(),
-                                                   zero.data_ptr() if zero is not None else None,
-                                                   zero.numel() * zero.element_size() if zero is not None else 0,
-                                                   ws[0].data_ptr(), C.byref(need), stream),
-                       "shine_sample_sorted_dev")
-            return idx
-        _lib.check(lib.shine_sample_sorted(self.size, n, self.seed, self.draws, idx.data_ptr(),
-                                           zero.data_ptr() if zero is not None else None,
-                                           zero.numel() * zero.element_size() if zero is not None else 0,
-                                           ws[0].data_ptr(), C.byref(need), stream), "shine_sample_sorted")
-        self.draws += 1
+            state = self._stream_state.data_ptr()
+        if sliced:
+            _lib.check(lib.shine_sample_sorted_slice(self.size, nd, int(slice_begin), n, self.seed, self.draws, state,
+                                                     idx.data_ptr(), *zero_args, *surf_args, ws[0].data_ptr(),
+                                                     C.byref(need), stream), "shine_sample_sorted_slice")
+        elif graph_safe:
+            _lib.check(lib.shine_sample_sorted_dev(self.size, n, self.seed, state, idx.data_ptr(), *zero_args, *surf_args,
+                                                   ws[0].data_ptr(), C.byref(need), stream), "shine_sample_sorted_dev")
+        else:
+            _lib.check(lib.shine_sample_sorted(self.size, n, self.seed, self.draws, idx.data_ptr(), *zero_args, *surf_args,
+                                               ws[0].data_ptr(), C.byref(need), stream), "shine_sample_sorted")
+        if not graph_safe:
+            self.draws += 1
         return idx
+
+    def surf_parts_buffer(self, n=None):
+        """int64[64] buffer for draw(n, surf_parts=...): the partial surface counts of a batch (SHINE_SURF_PARTS)"""
+        return torch.zeros(SURF_PARTS, dtype=torch.int64, device=self.coord.device)
 
     def get_batch(self, idx):
         """(coord, sdf_label, weight) of a drawn batch, for code that wants the tensors (Tier A / debugging)."""

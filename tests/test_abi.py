@@ -62,12 +62,12 @@ def test_argument_checks_of_the_per_iteration_entry_points():
     C = ctypes
     need = C.c_size_t(0)
     # sampler: size query, then a slice that does not fit the draw / a pool that does not fit int32
-    assert lib.shine_sample_sorted(1000, 4096, 1, 0, None, None, 0, None, C.byref(need), None) == 0
+    assert lib.shine_sample_sorted(1000, 4096, 1, 0, None, None, 0, None, None, None, C.byref(need), None) == 0
     assert need.value >= 5 * 8  # one fp64 block sum per 1024 draws (+ the closing spacing)
-    assert lib.shine_sample_sorted_slice(1000, 4096, 4000, 200, 1, 0, None, None, None, 0, None, C.byref(need), None) == -1
-    assert lib.shine_sample_sorted_slice(1000, 4096, -1, 10, 1, 0, None, None, None, 0, None, C.byref(need), None) == -1
-    assert lib.shine_sample_sorted(1 << 40, 16, 1, 0, None, None, 0, None, C.byref(need), None) == -1
-    assert lib.shine_sample_sorted(1000, 16, 1, 0, None, None, 0, None, None, None) == -1
+    assert lib.shine_sample_sorted_slice(1000, 4096, 4000, 200, 1, 0, None, None, None, 0, None, None, None, C.byref(need), None) == -1
+    assert lib.shine_sample_sorted_slice(1000, 4096, -1, 10, 1, 0, None, None, None, 0, None, None, None, C.byref(need), None) == -1
+    assert lib.shine_sample_sorted(1 << 40, 16, 1, 0, None, None, 0, None, None, None, C.byref(need), None) == -1
+    assert lib.shine_sample_sorted(1000, 16, 1, 0, None, None, 0, None, None, None, None, None) == -1
     assert b"shine_sample_sorted" in lib.shine_last_error() if hasattr(lib, "shine_last_error") else True
     # importance sweep / regulariser: null handles and level counts
     assert lib.shine_importance_sweep(None, None, None, None, None, None, None, None, 0, None, None, None, None, None, None,

@@ -878,7 +878,7 @@ def test_device_node_ranks_equal_host_ranks():
 
 # ---------------------------------------------------------------------------------------------------------
 # graph-replayable iteration (loop.GraphedIteration): device-resident sampler stream id and Adam step count
-@pytest.mark.parametrize("mode", ["bce", "incremental"])
+@pytest.mark.parametrize("mode", ["bce", "incremental", "eikonal"])
 def test_graphed_iteration_matches_eager_loop(mode):
     """K iterations through ONE captured HIP graph == K eager iterations: same batches (the stream id advances on the
     device), same Adam bias corrections (the step count advances on the device), same parameters."""
@@ -892,7 +892,7 @@ def test_graphed_iteration_matches_eager_loop(mode):
     K, N = 12, 4096
 
     def make():
-        fx = load_golden("ncd_reg_L3" if incremental else "maicity_bce_L3")
+        fx = load_golden("ncd_reg_L3" if incremental else ("kitti_eik_L3" if mode == "eikonal" else "maicity_bce_L3"))
         cfg, octree, dec = product_from_golden(fx)
         dec = dec.cuda()
         cfg.lr, cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio, cfg.weight_decay = 0.01, True, 1e-15, 1.0, 1e-7
@@ -904,7 +904,9 @@ def test_graphed_iteration_matches_eager_loop(mode):
         # from one build of the pool to the next — the same indices would then draw different samples in the two loops)
         pool = SortedPool(octree, fx["coord"].cuda().repeat(8, 1), fx["sdf_label"].cuda().repeat(8),
                           fx["weight"].cuda().repeat(8), seed=5, canonical=True)
-        opts = StepOptions(sigma=fx["sigma"], loss_reduction="sum" if incremental else "mean", deterministic=True)
+        # eikonal: the graphed loop takes the surface count from the draw (per-block parts), the eager loop from torch
+        opts = StepOptions(sigma=fx["sigma"], loss_reduction="sum" if incremental else "mean", deterministic=True,
+                           ekional_loss_on=mode == "eikonal", weight_e=0.1)
         return cfg, octree, dec, opt, pool, opts
 
     # eager reference loop (host-side stream ids 0..K-1, host-side step count)
@@ -942,7 +944,8 @@ def test_graphed_iteration_matches_eager_loop(mode):
     for a, b in zip(eager_feats, octree2.hier_features):
         assert rel_err(b.detach(), a) <= 1e-6
     probe = eager_idx[0]
-    opts_probe = StepOptions(sigma=opts.sigma, loss_reduction=opts.loss_reduction, deterministic=True)
+    opts_probe = StepOptions(sigma=opts.sigma, loss_reduction=opts.loss_reduction, deterministic=True,
+                             ekional_loss_on=opts.ekional_loss_on, weight_e=opts.weight_e)
     l1, _, _ = fused_train_step(octree, dec, None, None, None, opts_probe, pool=pool, idx=probe)
     l2, _, _ = fused_train_step(octree2, dec2, None, None, None, opts_probe, pool=pool2, idx=probe)
     assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l1))

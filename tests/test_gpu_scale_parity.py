@@ -698,3 +698,85 @@ def test_unrolled_graph_replays_draw_the_same_batches_and_count_the_same_steps()
     many()
     torch.cuda.synchronize()
     assert torch.equal(one._idx, many._idx)  # and the next one
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 1000, 1024, 4096, 16 * 1024 + 5, (1 << 18) + 37])
+def test_the_draw_counts_its_surface_samples_per_block(n):
+    """SortedPool.draw(surf_parts=...): the launch that writes the indices also counts the drawn samples with weight > 0 (the
+    eikonal term's surface samples, shine_batch.py:183-185) as 64 partial counts (overwritten, whatever they held); the parts
+    of a rank's slice count the slice.  Every form of the draw (host stream id, device stream id, one launch / two)."""
+    from shine_mapping_amd.sampler import SortedPool
+
+    fx = load_golden("kitti_eik_L3")
+    cfg, octree, dec = product_from_golden(fx)
+    octree._require_tables(with_ranks=True)
+    sp = SortedPool(octree, fx["coord"].cuda().repeat(40, 1), fx["sdf_label"].cuda().repeat(40), fx["weight"].cuda().repeat(40),
+                    seed=3)
+    assert 0 < int((sp.weight > 0).sum()) < sp.size  # both kinds of sample in the pool
+    for graph_safe in (False, True, True):
+        parts = sp.surf_parts_buffer()
+        parts.fill_(-7)  # stale contents must not survive
+        plain = sp.draws
+        idx = sp.draw(n, graph_safe=graph_safe, surf_parts=parts)
+        torch.cuda.synchronize()
+        want = int((sp.weight[idx.long()] > 0).sum())
+        assert parts.numel() == 64 and int(parts.sum()) == want and int(parts.min()) >= 0
+        if not graph_safe:  # the same draw without the count: same indices
+            sp.draws = plain
+            assert torch.equal(sp.draw(n), idx)
+    # a data-parallel rank's slice
+    if n >= 4096:
+        lo, cnt = n // 3 + 5, n // 2
+        parts = sp.surf_parts_buffer()
+        parts.fill_(-7)
+        here = sp.draws
+        whole = sp.draw(n).clone()
+        sp.draws = here
+        sl = sp.draw(cnt, n_global=n, slice_begin=lo, surf_parts=parts)
+        torch.cuda.synchronize()
+        assert torch.equal(sl, whole[lo: lo + cnt])
+        assert int(parts.sum()) == int((sp.weight[sl.long()] > 0).sum())
+    with pytest.raises((RuntimeError, ValueError)):
+        sp.draw(n, surf_parts=torch.zeros(8, dtype=torch.int64, device="cuda"))  # not SHINE_SURF_PARTS entries
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [300, 40000, (1 << 17) + 11])
+def test_step_adds_up_the_surface_count_parts(n):
+    """shine_train_step with n_surf given as the sampler's partial counts (cfg->n_surf_parts) == the same step with the one
+    count: same 1 / n_surf in every wave and in the loss (pred and the loss terms to the bit in deterministic mode)."""
+    from shine_mapping_amd import StepOptions, fused_train_step
+    from shine_mapping_amd.sampler import SortedPool
+
+    fx = load_golden("kitti_eik_L3")
+    cfg, octree, dec = product_from_golden(fx)
+    dec = dec.cuda()
+    octree._require_tables(with_ranks=True)
+    sp = SortedPool(octree, fx["coord"].cuda().repeat(40, 1), fx["sdf_label"].cuda().repeat(40), fx["weight"].cuda().repeat(40),
+                    seed=3, canonical=True)
+    params = list(octree.hier_features) + dec.fused_params()
+    parts = sp.surf_parts_buffer()
+    idx = sp.draw(n, surf_parts=parts)
+    one = (sp.weight[idx.long()] > 0).sum()
+    assert int(one) > 0
+    det = n <= 40000
+    opts = StepOptions(sigma=fx["sigma"], ekional_loss_on=True, weight_e=0.1, deterministic=det)
+
+    def run(n_surf, variant=0):
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        o = StepOptions(**{**opts.__dict__, "kernel_variant": variant, "deterministic": det and variant == 0})
+        loss, pred, gx = fused_train_step(octree, dec, None, None, None, o, n_surf=n_surf, pool=sp, idx=idx, want_grad_x=True)
+        torch.cuda.synchronize()
+        return float(loss), pred.clone(), gx.clone(), [p.grad.clone() for p in params]
+
+    a, b = run(parts), run(one)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    if det:
+        assert a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+    else:
+        assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0])
+        assert all(rel_err(x, y) <= TOL for x, y in zip(a[3], b[3]))
+    c = run(parts, variant=5)  # the check library's kernel takes one count: the Python layer adds the parts up for it
+    assert abs_err(c[1], b[1]) <= TOL and abs(c[0] - b[0]) <= TOL * max(1.0, abs(b[0]))
