@@ -2,7 +2,7 @@
 """bench.py — trained SDF samples/s (fwd+bwd) of the fused SHINE hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload maicity|kitti|kitti-large|ncd-incre]
-                    [--points P] [--levels L] [--frames F] [--exchange dense|touched] ...
+                    [--points P] [--levels L] [--frames F] [--exchange gather|dense|touched] ...
 
 Workloads (synthetic, shine_mapping_amd/synth.py; BASELINE.json configs):
   maicity      config 2: MaiCity-like street, 2^18 points/iter, 4-level octree, BCE                     (default)
@@ -15,7 +15,8 @@ node-ordered pool (also clears the dense grads, i.e. opt.zero_grad) -> fused que
 (shine_batch.py:123-209 minus the optimiser) [-> gradient exchange under data parallelism].  For ncd-incre a step is
 one frame.  With N>1 ranks (torch.distributed.run, one process per GPU, RCCL): ONE global sorted draw (same seed
 everywhere), rank r takes the r-th contiguous slice of P points (weak scaling), global normalisers come from the common
-draw, and the grads are exchanged dense (one flat all-reduce) or as touched rows only (--exchange).
+draw, and the grads are exchanged (--exchange) by an all-gather of the rows every rank touched (default; checked against the
+dense all-reduce on a real step before anything is timed), dense (one flat all-reduce) or as the union of touched rows.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches this script under `torch.distributed.run` with N
 ranks on 127.0.0.1 (so `python bench.py --gpus 8` and the driver's explicit torchrun form run the same thing); fewer
@@ -522,96 +523,188 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
     params = list(octree.hier_features) + decoder.fused_params()
     for p in params:
         p.grad = torch.zeros_like(p)
-    reducer = shine_dp.TouchedRowReducer(list(octree.hier_features), decoder.fused_params(), dist)
-    exchange = args.exchange
-    if exchange == "auto":
-        exchange = "touched" if reducer.dense_bytes() > (64 << 20) else "dense"
     octree._require_tables(with_ranks=True)
     # ONE pool order and ONE random stream on every rank: the global draw is common knowledge
     # (canonical: the plan leaves the samples of one node in atomic-retirement order, which differs between processes)
     spool = SortedPool(octree, pool.coord, pool.sdf_label, pool.weight, seed=1000, canonical=use_dist)
-    flags = shine_dp.mark_touched(octree, spool, spool.draw(8)) if (use_dist and exchange == "touched") else None
-    if flags is not None:
-        for f in flags:
-            f.zero_()
-    # One stream: draw -> fused step -> reduction (-> exchange).  Every step draws its own fresh batch (the sampler's stream id
-    # lives in device memory and advances with every draw).  (Drawing the next batch on a forked graph branch under the fused
-    # kernel was measured slower — profiles/r03_ab_experiments.txt block 9.)
+    feats, dec_params = list(octree.hier_features), decoder.fused_params()
     idx_buf = torch.empty(points, dtype=torch.int32, device=dev)
     surf_parts = spool.surf_parts_buffer(points) if opts.ekional_loss_on else None
-
-    def step_body():
-        """draw (its first pass also clears the gradient bucket: opt.zero_grad()) -> fused step on this rank's slice (-> exchange)"""
-        # this rank's contiguous slice of the ONE global sorted draw (same seed / draw count on every rank): only the
-        # slice's indices are generated (shine_sample_sorted_slice), so the draw does not grow with the world size
-        idx = spool.draw(points, out=idx_buf, zero=reducer.flat, graph_safe=True, n_global=n_global,
-                         slice_begin=rank * points, surf_parts=surf_parts)
-        # eikonal: the surface count of the batch comes out of the draw as per-block partial counts which the step's kernels
-        # add up (no launch of its own); data parallel: the global count = sum of the parts + an 8-byte all-reduce
-        n_surf = surf_parts
-        if surf_parts is not None and use_dist:
-            n_surf = surf_parts.sum()
-            reducer.all_reduce_scalar(n_surf)
-        loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx)
-        if use_dist:
-            if exchange == "touched":
-                shine_dp.mark_touched(octree, spool, idx, flags)  # this rank's rows ...
-                reducer.or_reduce_flags(flags)                    # ... OR-ed into the global row set
-                reducer.all_reduce_touched(flags)
-            else:
-                reducer.all_reduce_grads()
-        return loss
+    U = max(1, int(args.graph_steps))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The loop body has no host sync and no allocation outside torch's allocator, so it is captured into HIP graphs and
-    # replayed (launch-bound inner loops belong in hipGraphs): one graph of `--graph-steps` U consecutive steps — a replay
-    # costs ~9 us of idle GPU at its boundary whatever it holds, so K steps run as K // U replays of it plus K % U replays of
-    # a one-step graph; every step in either graph is the full body above with its own draw.  With the dense exchange the RCCL
-    # all-reduce is captured with it; the touched-row exchange reads a row count on the host and stays eager.
-    launch = "eager"
-    U = max(1, int(args.graph_steps))
-    graph_u = graph_1 = None
-    loss_u = loss_1 = None
-    if not args.no_graph and not (use_dist and exchange == "touched"):
-        try:
-            for _ in range(3):
-                step_body()  # warm caches / allocate workspaces / RCCL channels outside capture
-            barrier()
-            graph_1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_1):
-                loss_1 = step_body()
-            if U > 1:
-                graph_u = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_u):
-                    for _ in range(U):
-                        loss_u = step_body()
-            launch = "hipgraph, %d step%s per replay, fresh batch per step%s" % (
-                U, "s" if U > 1 else "", " (all-reduce captured)" if use_dist else "")
-        except Exception as e:  # capture not possible on this stack: measure eagerly and say so
-            print("graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
-            graph_u = graph_1 = None
-            launch = "eager"
-            torch.cuda.synchronize()
+    # Gradient exchange under data parallelism (--exchange):
+    #   dense    one flat all-reduce of the whole bucket
+    #   gather   every rank moves the rows ITS slice touched into a fixed-size message, ONE all-gather, every rank adds all
+    #            messages back in rank order (dp.RowGatherReducer): no host read, graph-capturable, fewer bytes on the links
+    #            but pack / unpack launches on every rank; with --micro-batches M > 1 the slice runs as M fused steps and the
+    #            (asynchronous) all-gather of micro-batch k overlaps the fused kernel of micro-batch k + 1
+    #   touched  all-reduce of the union of all ranks' touched rows (row count read on the host: eager launches)
+    # auto = MEASURED: dense, gather and gather with micro-batches are each built (a gather candidate must first reproduce the
+    # dense all-reduce of one real step on every rank), run for a few steps on this node, and the fastest — by the slowest
+    # rank's clock — is rebuilt and timed.  The record says which one ran and what the others took.
+    def build_runner(kind, m):
+        """-> dict(run(k) -> loss, launch, reducer, ...) for one exchange; None if a gather candidate fails its check"""
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        if kind == "gather":
+            reducer = shine_dp.RowGatherReducer(feats, dec_params, dist, async_op=m > 1)
+        else:
+            reducer = shine_dp.TouchedRowReducer(feats, dec_params, dist)
+        flags = None
+        if use_dist and kind == "touched":
+            flags = shine_dp.mark_touched(octree, spool, spool.draw(8))
+            for f in flags:
+                f.zero_()
 
-    def run(k):
-        """exactly k steps -> the last step's loss"""
-        out = None
-        if graph_1 is None:
-            for _ in range(k):
-                out = step_body()
+        def run_micro(idx, n_surf):
+            """the rank's slice as m contiguous micro-batches: fused step (marks its rows) -> pack + all-gather; then add back"""
+            loss = None
+            for k in range(m):
+                a_, b_ = k * points // m, (k + 1) * points // m
+                l_, _, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool,
+                                            idx=idx[a_:b_], touched=reducer.flags)
+                loss = l_ if loss is None else loss + l_
+                reducer.exchange(finish=k == m - 1)
+            return loss
+
+        if use_dist and kind == "gather":  # one real step through the candidate == the dense all-reduce of the same grads
+            ok = 1
+            try:
+                idx = spool.draw(points, zero=reducer.flat, n_global=n_global, slice_begin=rank * points)
+                ns = None
+                if opts.ekional_loss_on:
+                    ns = (spool.weight[idx.long()] > 0).sum()
+                    reducer.all_reduce_scalar(ns)
+                fused_train_step(octree, decoder, None, None, None, opts, n_surf=ns, pool=spool, idx=idx)
+                want = reducer.flat.clone()
+                dist.all_reduce(want)
+                reducer.flat.zero_()
+                run_micro(idx, ns)
+                torch.cuda.synchronize()
+                err = float((reducer.flat - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+                if reducer.overflowed() or not err <= 1e-5:
+                    ok = 0
+            except Exception as e:  # an exchange that cannot run here must not take the measurement down with it
+                print("rank %d: gather exchange check failed: %s" % (rank, e), file=sys.stderr)
+                ok = 0
+            t = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if not int(t):
+                return None
+
+        # One stream: draw -> fused step -> reduction (-> exchange).  Every step draws its own fresh batch (the sampler's
+        # stream id lives in device memory and advances with every draw).  (Drawing the next batch on a forked graph branch
+        # under the fused kernel was measured slower — profiles/r03_ab_experiments.txt block 9.)
+        def step_body():
+            """draw (its first pass also clears the gradient bucket: opt.zero_grad()) -> fused step on this rank's slice
+            (-> exchange)"""
+            # this rank's contiguous slice of the ONE global sorted draw (same seed / draw count on every rank): only the
+            # slice's indices are generated (shine_sample_sorted_slice), so the draw does not grow with the world size
+            idx = spool.draw(points, out=idx_buf, zero=reducer.flat, graph_safe=True, n_global=n_global,
+                             slice_begin=rank * points, surf_parts=surf_parts)
+            # eikonal: the surface count of the batch comes out of the draw as 64 partial counts which the step's kernels add
+            # up (no launch of its own); data parallel: the global count = sum of the parts + an 8-byte all-reduce
+            n_surf = surf_parts
+            if surf_parts is not None and use_dist:
+                n_surf = surf_parts.sum()
+                reducer.all_reduce_scalar(n_surf)
+            if use_dist and kind == "gather":
+                return run_micro(idx, n_surf)
+            loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx)
+            if use_dist:
+                if kind == "touched":
+                    shine_dp.mark_touched(octree, spool, idx, flags)  # this rank's rows ...
+                    reducer.or_reduce_flags(flags)                    # ... OR-ed into the global row set
+                    reducer.all_reduce_touched(flags)
+                else:
+                    reducer.all_reduce_grads()
+            return loss
+
+        # The loop body has no host sync and no allocation outside torch's allocator, so it is captured into HIP graphs and
+        # replayed (launch-bound inner loops belong in hipGraphs): one graph of `--graph-steps` U consecutive steps — a
+        # replay costs ~9 us of idle GPU at its boundary whatever it holds, so K steps run as K // U replays of it plus K % U
+        # replays of a one-step graph; every step in either graph is the full body above with its own draw.  The collectives
+        # of the dense / gather exchange are captured with it; the touched-row exchange reads a row count on the host and
+        # stays eager.
+        launch = "eager"
+        graph_u = graph_1 = None
+        loss_u = loss_1 = None
+        if not args.no_graph and not (use_dist and kind == "touched"):
+            try:
+                for _ in range(3):
+                    step_body()  # warm caches / allocate workspaces / RCCL channels outside capture
+                barrier()
+                graph_1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_1):
+                    loss_1 = step_body()
+                if U > 1:
+                    graph_u = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_u):
+                        for _ in range(U):
+                            loss_u = step_body()
+                launch = "hipgraph, %d step%s per replay, fresh batch per step%s" % (
+                    U, "s" if U > 1 else "", " (collectives captured)" if use_dist else "")
+            except Exception as e:  # capture not possible on this stack: measure eagerly and say so
+                print("graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
+                graph_u = graph_1 = None
+                launch = "eager"
+                torch.cuda.synchronize()
+
+        def run(k):
+            """exactly k steps -> the last step's loss"""
+            out = None
+            if graph_1 is None:
+                for _ in range(k):
+                    out = step_body()
+                return out
+            q, r = divmod(k, U) if graph_u is not None else (0, k)
+            for _ in range(q):
+                graph_u.replay()
+                out = loss_u
+            for _ in range(r):
+                graph_1.replay()
+                out = loss_1
             return out
-        q, r = divmod(k, U) if graph_u is not None else (0, k)
-        for _ in range(q):
-            graph_u.replay()
-            out = loss_u
-        for _ in range(r):
-            graph_1.replay()
-            out = loss_1
-        return out
+
+        return dict(run=run, launch=launch, reducer=reducer, kind=kind, micro=m, keep=(graph_u, graph_1, flags))
+
+    exchange, micro, exchange_note, tuned = args.exchange, 1, None, None
+    want_m = max(1, int(args.micro_batches))
+    if not use_dist:
+        exchange = "dense"  # (no exchange at all on one rank)
+    if use_dist and exchange == "auto":
+        tuned = {}
+        for kind, m in [("dense", 1), ("gather", 1)] + ([("gather", want_m)] if want_m > 1 else []):
+            r_ = build_runner(kind, m)
+            name = kind if m == 1 else "%s x%d micro-batches" % (kind, m)
+            if r_ is None:
+                tuned[name] = "failed its check against the dense all-reduce"
+                continue
+            r_["run"](2 * U)
+            barrier()
+            t0 = time.perf_counter()
+            r_["run"](3 * U)
+            barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / (3 * U)], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # every rank sees the same number -> the same choice
+            tuned[name] = float(t) * 1e3
+            del r_
+            _release(dev)
+        best = min((v, k) for k, v in tuned.items() if isinstance(v, float))[1]
+        exchange, micro = ("gather", want_m if "x" in best else 1) if best.startswith("gather") else ("dense", 1)
+    elif use_dist and exchange == "gather":
+        micro = want_m
+    runner = build_runner(exchange, micro)
+    if runner is None:  # an explicitly requested gather exchange that does not reproduce the dense all-reduce here
+        exchange_note = "gather exchange (%d micro-batches) failed its check against the dense all-reduce: dense used" % micro
+        exchange, micro = "dense", 1
+        runner = build_runner(exchange, micro)
+    run, launch, reducer = runner["run"], runner["launch"], runner["reducer"]
 
     run(warmup)
     barrier()
@@ -627,6 +720,14 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
         per = [float(x) for x in all_t]
         dt = max(per)
         rank_ms = {"max": max(per) / steps * 1e3, "min": min(per) / steps * 1e3}
+
+    gather_overflow = None
+    if use_dist and exchange == "gather":  # a message too small for a step's rows makes that step's grads incomplete: say so
+        t = torch.tensor([1 if reducer.overflowed() else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gather_overflow = bool(int(t))
+        if gather_overflow and rank == 0:
+            print("WARNING: a rank touched more rows than a gather message holds during the timed steps", file=sys.stderr)
 
     roof = kernel_roofline(workload, octree, decoder, cfg, spool, points, None, launch_graph=not args.no_graph)
 
@@ -691,7 +792,15 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
             "grad_exchange": None if not use_dist else (
                 "touched rows: %d rows, %.1f MB per step (dense bucket %.1f MB)" % (
                     reducer.last_rows, reducer.last_bytes / 1e6, reducer.dense_bytes() / 1e6)
-                if exchange == "touched" else "dense flat all-reduce, %.1f MB per step" % (reducer.dense_bytes() / 1e6)),
+                if exchange == "touched" else
+                "own rows all-gather: %d micro-batch(es) per step, %.1f MB message per rank and micro-batch (capacity %d rows; "
+                "dense bucket %.1f MB), checked against the dense all-reduce before timing%s" % (
+                    micro, reducer.last_bytes / 1e6, reducer.capacity, reducer.dense_bytes() / 1e6,
+                    ", all-gather of micro-batch k under the fused kernel of k + 1" if micro > 1 else "")
+                if exchange == "gather" else "dense flat all-reduce, %.1f MB per step" % (reducer.dense_bytes() / 1e6)),
+            "grad_exchange_note": exchange_note,
+            "grad_exchange_tuning_ms_per_step": tuned,
+            "grad_exchange_overflow": gather_overflow,
         },
         "roofline": roof,
         "final_loss": float(loss),
@@ -745,7 +854,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--graph-steps", type=int, default=4,
                     help="steps captured per HIP graph (K steps = K // U replays + K % U one-step replays)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "dense", "touched"],
+    ap.add_argument("--micro-batches", type=int, default=2,
+                    help="data parallel, gather exchange: fused steps per rank and step; the all-gather of one overlaps the "
+                         "fused kernel of the next")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "gather", "dense", "touched"],
                     help="data-parallel gradient exchange: one flat all-reduce of the dense grads, or only the rows the "
                          "global batch touched (auto: touched when the dense bucket exceeds 64 MB)")
     ap.add_argument("--force-dist", action="store_true",

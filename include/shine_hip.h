@@ -306,6 +306,28 @@ int shine_touched_pack(int32_t n_levels, float* const* grads, const int32_t* con
 int shine_touched_unpack(int32_t n_levels, float* const* grads, const int32_t* const* idx, const int64_t* counts,
                          const int64_t* rows, uint8_t* const* flags, const float* msg, void* stream);
 
+/* ---- the same exchange with ONE collective, no host read and half the bytes: every rank packs only the rows IT touched and
+ *      the ranks all-gather the messages (no reference counterpart).  The gradient bucket is one flat float
+ *      array: n_rows 8-float rows (the L dense feature-grad tables [rows_l + 1][8] back to back), then — at float offset
+ *      tail_off — a dense tail of tail_n floats (the decoder's grads).  flags: one byte per row (the step's touched flags
+ *      of all levels back to back).  A message is shine_rows_message_words(cap, tail_n) 4-byte words:
+ *      {count, overflow, 0, 0 | ids int32[cap] | values float[cap][8] | tail float[tail_n]}, cap a multiple of 4.
+ *      shine_rows_pack: the flagged rows, ascending, MOVE into msg (zeroed in the bucket, flags cleared except keep_rows —
+ *        the host array of the <= 8 trash-row ids, whose flags stay set: every miss lands there), and so does the tail.  A
+ *        second micro-batch of the same step can therefore accumulate into the same bucket and be packed separately.  More
+ *        than cap flagged rows: msg[1] = 1 and the excess rows stay behind (the result is then incomplete — size cap from
+ *        a measured step, and check overflow_out).  workspace == NULL returns the required bytes.
+ *      shine_rows_unpack_add: msgs = world messages back to back (the all-gather's output, this rank's included): every row
+ *        is added into the bucket, one launch per rank in rank order (bit-identical results on every rank), the tails are
+ *        summed in rank order and stored; *overflow_out (device
+ *        int32, optional) is set to 1 if any rank overflowed. */
+int64_t shine_rows_message_words(int64_t cap, int64_t tail_n);
+int shine_rows_pack(uint8_t* flags, int64_t n_rows, const int64_t* keep_rows, int32_t n_keep, float* bucket,
+                    int64_t tail_off, int64_t tail_n, int64_t cap, int32_t* msg, void* workspace, size_t* workspace_bytes,
+                    void* stream);
+int shine_rows_unpack_add(const int32_t* msgs, int32_t world, int64_t cap, float* bucket, int64_t tail_off, int64_t tail_n,
+                          int32_t* overflow_out, void* stream);
+
 /* ---- Mesher.query_points (utils/mesher.py:33-108): query_feature(coord, faster=True) (model/feature_octree.py:237-244,
  *      :267-286) + Decoder.sdf (model/decoder.py:49-63) for n grid points in one launch.
  *      sdf_out[n] f32 = (negate ? -1 : +1) * sdf   (the mesher negates, mesher.py:69,92), may be NULL;

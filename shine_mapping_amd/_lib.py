@@ -102,6 +102,10 @@ _SIGNATURES = {
                                       C.POINTER(C.c_size_t), _P]),
     "shine_touched_pack": (C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                      _P, _P]),
+    "shine_rows_message_words": (C.c_int64, [C.c_int64, C.c_int64]),
+    "shine_rows_pack": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.c_int32, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P,
+                                  C.POINTER(C.c_size_t), _P]),
+    "shine_rows_unpack_add": (C.c_int, [_P, C.c_int32, C.c_int64, _P, C.c_int64, C.c_int64, _P, _P]),
     "shine_touched_unpack": (C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int64), C.POINTER(_P), _P, _P]),
     "shine_train_step_workspace_bytes": (C.c_size_t, [C.POINTER(StepConfig), C.c_int64]),

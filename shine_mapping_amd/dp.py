@@ -278,3 +278,176 @@ class TouchedRowReducer(GradReducer):
             off += p.numel()
         for f in flags:
             f.zero_()
+
+
+class RowGatherReducer(GradReducer):
+    """Gradient exchange by all-gather of the rows EACH RANK touched (the reference is single-GPU).
+
+    Under the sorted global draw a rank's slice is a contiguous stretch of the node-ordered batch: it touches ~1/world of the
+    feature rows, and the ranks' row sets overlap only at the slice borders.  Instead of all-reducing the dense bucket (or
+    the union of all ranks' rows, TouchedRowReducer), every rank MOVES the rows its own step flagged (ids + values, fixed
+    capacity) plus the decoder grads into one message, the ranks all-gather the messages, and every rank adds all of them
+    back into its bucket: ONE collective per exchange, about half the bytes of an all-reduce, no flag OR-reduce, no host
+    read — the whole step {draw, fused step, exchange} is capturable in a HIP graph.
+
+        red = RowGatherReducer(octree.hier_features, decoder.fused_params(), dist)
+        fused_train_step(..., touched=red.flags)      # the step marks the rows it touches
+        red.exchange()                                 # grads now hold the global sums
+
+    exchange() may be called after every MICRO-batch of a step (the pack moves the rows out of the bucket, so the next
+    micro-batch accumulates from zero and nothing is counted twice); finish() then adds everything back — with
+    async_op=True the all-gather of micro-batch k runs under the fused kernel of micro-batch k + 1.  `capacity_rows`:
+    rows per message (default: measured on the first exchange, x 1.5); a rank that touches more sets the overflow flag,
+    which `overflowed()` reads (one host sync — call it outside the hot loop; the result of such a step is incomplete).
+    CPU tensors (gloo tests) run the same algorithm in torch index ops."""
+
+    def __init__(self, feature_params, other_params, dist=None, group=None, capacity_rows=None, async_op=False):
+        super().__init__(list(feature_params) + list(other_params), dist, group)
+        self.async_op = bool(async_op)  # issue the all-gather asynchronously (it then runs on the backend's own stream, under
+        #                                 whatever the caller launches next — the next micro-batch); finish() waits for it
+        self.n_feat = len(list(feature_params))
+        feats = self.params[:self.n_feat]
+        self.F = int(feats[0].shape[1])
+        self.level_rows = [int(p.shape[0]) for p in feats]            # rows_l + 1 (the trash row is the last one)
+        self.n_rows = sum(self.level_rows)
+        self.tail_n = sum(p.numel() for p in self.params[self.n_feat:])
+        dev = feats[0].device
+        self._flags_flat = torch.zeros(self.n_rows, dtype=torch.uint8, device=dev)
+        self.flags, off, keep = [], 0, []
+        for r in self.level_rows:  # per-level views for fused_train_step(touched=...) / shine_mark_touched
+            self.flags.append(self._flags_flat[off: off + r])
+            keep.append(off + r - 1)
+            off += r
+        self._keep = keep
+        self._flags_flat[torch.tensor(keep, device=dev)] = 1  # every miss lands in a trash row: always exchanged
+        self.capacity = None if capacity_rows is None else self._round_cap(capacity_rows)
+        self._pending = []       # gathered messages not yet added back (micro-batches)
+        self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ws = None
+        self.last_rows = 0
+        self.last_bytes = 0
+
+    def _round_cap(self, rows):
+        return max(4, min((int(rows) + 3) // 4 * 4, (self.n_rows + 3) // 4 * 4))
+
+    def dense_bytes(self):
+        return sum(p.numel() for p in self.params) * 4
+
+    def world(self):
+        return self.dist.get_world_size(self.group) if self.dist is not None else 1
+
+    def _measure_capacity(self):
+        n = int(self._flags_flat.count_nonzero())  # (one host read, once)
+        if self.dist is not None:  # every rank must use the same message size
+            t = torch.tensor([n], dtype=torch.int64, device=self._flags_flat.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+            n = int(t)
+        self.capacity = self._round_cap(int(1.5 * n) + 1024)
+
+    def _words(self):
+        return 4 + self.capacity + self.capacity * self.F + self.tail_n
+
+    def exchange(self, finish=True):
+        """pack this rank's flagged rows (moving them out of the bucket) and all-gather; finish=True also adds every
+        gathered message back (finish=False after all but the last micro-batch of a step)"""
+        self._ensure_flat()
+        if self.capacity is None:
+            self._measure_capacity()
+        flat, dev = self._flat_padded, self._flat_padded.device
+        world = self.world()
+        words = self._words()
+        tail_off = self.n_rows * self.F
+        msg = torch.empty(words, dtype=torch.int32, device=dev)
+        if flat.is_cuda:
+            lib = _lib.lib()
+            stream = _lib.current_stream_handle()
+            if self._ws is None:
+                need = C.c_size_t(0)
+                _lib.check(lib.shine_rows_pack(None, self.n_rows, None, 0, None, 0, self.tail_n, self.capacity, None, None,
+                                               C.byref(need), stream), "shine_rows_pack")
+                self._ws = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev), int(need.value))
+            need = C.c_size_t(self._ws[1])
+            _lib.check(lib.shine_rows_pack(self._flags_flat.data_ptr(), self.n_rows, _lib.i64_array(self._keep), len(self._keep),
+                                           flat.data_ptr(), tail_off, self.tail_n, self.capacity, msg.data_ptr(),
+                                           self._ws[0].data_ptr(), C.byref(need), stream), "shine_rows_pack")
+        else:
+            self._pack_torch(flat, msg, tail_off)
+        work = None
+        if self.dist is not None:  # (also with one rank: the collective is then a copy, and the same code path is exercised)
+            gathered = torch.empty(world * words, dtype=torch.int32, device=dev)
+            if self.async_op:
+                work = self.dist.all_gather_into_tensor(gathered, msg, group=self.group, async_op=True)
+            else:
+                self.dist.all_gather_into_tensor(gathered, msg, group=self.group)
+        else:
+            gathered = msg
+        self._pending.append((gathered, work, msg))  # (msg is kept alive until the collective has read it)
+        self.last_bytes = words * 4
+        if finish:
+            self.finish()
+
+    def finish(self):
+        """add every gathered message (all ranks, all micro-batches) back into the bucket"""
+        flat = self._flat_padded
+        world = self.world()
+        tail_off = self.n_rows * self.F
+        first = True
+        for gathered, work, _ in self._pending:
+            if work is not None:
+                work.wait()  # the current stream waits for the collective (no host block on the NCCL / RCCL backend)
+            if flat.is_cuda:
+                _lib.check(_lib.lib().shine_rows_unpack_add(gathered.data_ptr(), world, self.capacity, flat.data_ptr(), tail_off,
+                                                            self.tail_n if first else 0, self._overflow.data_ptr(),
+                                                            _lib.current_stream_handle()), "shine_rows_unpack_add")
+                if not first and self.tail_n:  # later micro-batches ADD their tails
+                    words = self._words()
+                    g = gathered.view(world, words)[:, words - self.tail_n:].view(torch.float32)
+                    flat[tail_off: tail_off + self.tail_n] += g.sum(dim=0)
+            else:
+                self._unpack_torch(flat, gathered, world, tail_off, first)
+            first = False
+        self._pending = []
+
+    def overflowed(self):
+        """True if any rank of any exchange since the last call touched more rows than a message holds (host sync)"""
+        v = bool(int(self._overflow.item()))
+        self._overflow.zero_()
+        return v
+
+    # ---- the same algorithm in torch index ops (CPU tensors: the gloo tests)
+    def _pack_torch(self, flat, msg, tail_off):
+        F, cap = self.F, self.capacity
+        ids = torch.nonzero(self._flags_flat, as_tuple=False).flatten()
+        total = int(ids.numel())
+        self.last_rows = total
+        ids = ids[:cap]
+        n = int(ids.numel())
+        msg.zero_()
+        msg[0], msg[1] = n, 1 if total > cap else 0
+        msg[4: 4 + n] = ids.to(torch.int32)
+        table = flat[: self.n_rows * F].view(self.n_rows, F)
+        vals = msg[4 + cap: 4 + cap + cap * F].view(torch.float32).view(cap, F)
+        vals[:n] = table[ids]
+        table[ids] = 0
+        msg[4 + cap + cap * F:].view(torch.float32).copy_(flat[tail_off: tail_off + self.tail_n])
+        flat[tail_off: tail_off + self.tail_n] = 0
+        self._flags_flat.zero_()
+        self._flags_flat[torch.tensor(self._keep)] = 1
+
+    def _unpack_torch(self, flat, gathered, world, tail_off, first):
+        F, cap, words = self.F, self.capacity, self._words()
+        table = flat[: self.n_rows * F].view(self.n_rows, F)
+        tail = torch.zeros(self.tail_n, dtype=torch.float32)
+        for r in range(world):
+            m = gathered[r * words: (r + 1) * words]
+            n = int(m[0])
+            if int(m[1]):
+                self._overflow.fill_(1)
+            ids = m[4: 4 + n].long()
+            vals = m[4 + cap: 4 + cap + cap * F].view(torch.float32).view(cap, F)[:n]
+            table.index_add_(0, ids, vals)
+            tail += m[4 + cap + cap * F:].view(torch.float32)
+        if first:
+            flat[tail_off: tail_off + self.tail_n] = tail
+        else:
+            flat[tail_off: tail_off + self.tail_n] += tail

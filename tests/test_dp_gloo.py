@@ -142,3 +142,91 @@ def test_touched_row_exchange_equals_dense_all_reduce(name, tmp_path):
         assert torch.equal(s, d), "touched-row exchange differs from the dense all-reduce"
         assert float((s - r).abs().max()) <= 1e-5 * max(float(r.abs().max()), 1e-30)
     assert 0 < got["bytes"] < got["dense_bytes"]  # 4096 points touch a fraction of the fixture's rows
+
+
+def _worker_gather(rank, world, port, name, out_dir):
+    """The own-rows all-gather exchange (dp.RowGatherReducer): every rank flags the rows ITS slice touches, moves them into
+    a fixed-capacity message and the ranks all-gather — once per step, and once per MICRO-batch of a step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from shine_mapping_amd.dp import RowGatherReducer
+
+    fx = load_golden(name)
+    cfg, oct_, mlp = oracle_from_golden(fx)
+    n = fx["coord"].shape[0]
+    hidx = oct_.get_indices(fx["coord"])
+    order = torch.argsort(hidx[0][:, 0], stable=True)
+    gc, gl, gw = fx["coord"][order], fx["sdf_label"][order], fx["weight"][order]
+    L = len(oct_.hier_features)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    reducer = RowGatherReducer(list(oct_.hier_features), mlp.params(), dist, async_op=True)  # (finish() waits)
+    n_surf = int((gw > 0).sum())
+
+    def mark(a, b):  # what the fused step's touched pass does for points [a, b) of the global batch
+        sub = oct_.get_indices(gc[a:b])
+        for s in range(L):
+            u = sub[L - 1 - s].flatten().unique()
+            reducer.flags[s][u[u >= 0]] = 1
+
+    # (1) one exchange per step
+    loss = _sharded_step(oct_, mlp, gc[lo:hi], gl[lo:hi], gw[lo:hi], cfg, n, n_surf)
+    reducer._ensure_flat()
+    local = [p.grad.clone() for p in reducer.params]
+    mark(lo, hi)
+    reducer.exchange()
+    whole = [p.grad.clone() for p in reducer.params]
+    cap_measured = reducer.capacity
+    # (2) the same step as two micro-batches, each exchanged on its own, added back at the end
+    for p in reducer.params:
+        p.grad.zero_()
+    mid = (lo + hi) // 2
+    _sharded_step(oct_, mlp, gc[lo:mid], gl[lo:mid], gw[lo:mid], cfg, n, n_surf, reset=False)
+    mark(lo, mid)
+    reducer.exchange(finish=False)
+    assert all(float(p.grad.abs().max()) == 0.0 for p in reducer.params), "the pack moves the rows (and the tail) out"
+    _sharded_step(oct_, mlp, gc[mid:hi], gl[mid:hi], gw[mid:hi], cfg, n, n_surf, reset=False)
+    mark(mid, hi)
+    reducer.exchange(finish=True)
+    micro = [p.grad.clone() for p in reducer.params]
+    ok = not reducer.overflowed()
+    # (3) a message too small for the rows: reported, not silent
+    small = RowGatherReducer(list(oct_.hier_features), mlp.params(), dist, capacity_rows=8)
+    for p, g in zip(small.params, local):
+        p.grad.copy_(g)
+    sub = oct_.get_indices(gc[lo:hi])
+    for s in range(L):
+        u = sub[L - 1 - s].flatten().unique()
+        small.flags[s][u[u >= 0]] = 1
+    small.exchange()
+    overflow_seen = small.overflowed()
+    # the dense all-reduce of the same local grads
+    for p, g in zip(reducer.params, local):
+        p.grad.copy_(g)
+    reducer.all_reduce_grads()
+    dist.all_reduce(loss)
+    if rank == 0:
+        torch.save(dict(loss=loss, whole=whole, micro=micro, dense=[p.grad.clone() for p in reducer.params], ok=ok,
+                        overflow_seen=overflow_seen, bytes=reducer.last_bytes, dense_bytes=reducer.dense_bytes(),
+                        cap=cap_measured, flags_left=int(reducer._flags_flat.sum()), levels=L),
+                   os.path.join(out_dir, "dp_gather.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["maicity_bce_L3", "kitti_eik_L3"])
+def test_own_rows_all_gather_equals_dense_all_reduce(name, tmp_path):
+    world = 2
+    mp.spawn(_worker_gather, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "dp_gather.pt"), weights_only=False)
+    ref = load_golden(name)["out"]
+    refs = list(ref["feat_grads"]) + list(ref["mlp_grads"])
+    assert abs(float(got["loss"]) - float(ref["loss"])) <= 1e-5 * max(1.0, abs(float(ref["loss"])))
+    for w, m, d, r in zip(got["whole"], got["micro"], got["dense"], refs):
+        scale = max(float(r.abs().max()), 1e-30)
+        assert float((w - d).abs().max()) <= 1e-6 * scale, "own-rows all-gather differs from the dense all-reduce"
+        assert float((m - d).abs().max()) <= 1e-5 * scale, "two exchanged micro-batches differ from the dense all-reduce"
+        assert float((w - r).abs().max()) <= 1e-5 * scale
+    assert got["ok"] and got["overflow_seen"]
+    assert got["flags_left"] == got["levels"]  # only the trash rows stay flagged
+    assert 0 < got["bytes"] and got["cap"] % 4 == 0

@@ -43,6 +43,17 @@ class HostStaged:
         dist.all_reduce(c, op=op, group=group)
         t.copy_(c)
 
+    @staticmethod
+    def get_world_size(group=None):
+        return dist.get_world_size(group)
+
+    @staticmethod
+    def all_gather_into_tensor(out, inp, group=None):
+        c = inp.detach().cpu()
+        parts = [torch.empty_like(c) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, c, group=group)
+        out.copy_(torch.cat(parts))
+
 
 torch.cuda.set_device(0)
 wl = synth.build_workload(kind, frames=8, device="cuda", seed=42, tree_level_feat=3, azimuths=300)
@@ -53,7 +64,8 @@ opts = StepOptions(sigma=cfg.sigma_sigmoid, loss_reduction=cfg.loss_reduction, e
 params = list(octree.hier_features) + decoder.fused_params()
 for p in params:
     p.grad = torch.zeros_like(p)
-reducer = shine_dp.TouchedRowReducer(list(octree.hier_features), decoder.fused_params(), None if single else HostStaged)
+Reducer = shine_dp.RowGatherReducer if exchange == "gather" else shine_dp.TouchedRowReducer
+reducer = Reducer(list(octree.hier_features), decoder.fused_params(), None if single else HostStaged)
 octree._require_tables(with_ranks=True)
 spool = SortedPool(octree, pool.coord, pool.sdf_label, pool.weight, seed=1000, canonical=True)
 flags = None
@@ -70,9 +82,13 @@ for it in range(3):
     if opts.ekional_loss_on:
         n_surf = (spool.weight[idx.long()] > 0).sum()
         reducer.all_reduce_scalar(n_surf)
-    loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx)
+    loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx,
+                                     touched=reducer.flags if exchange == "gather" else None)
     loss = loss.detach().clone()
-    if exchange == "touched":
+    if exchange == "gather":  # own rows (flagged by the step itself) -> message -> all-gather -> added back
+        reducer.exchange()
+        assert not reducer.overflowed()
+    elif exchange == "touched":
         shine_dp.mark_touched(octree, spool, idx, flags)
         reducer.or_reduce_flags(flags)
         reducer.all_reduce_touched(flags)
@@ -123,7 +139,7 @@ def _run(tmp_path, kind, exchange, points, world, tag):
 
 
 @pytest.mark.parametrize("kind,exchange", [("maicity", "dense"), ("maicity", "touched"), ("kitti", "dense"),
-                                           ("kitti", "touched")])
+                                           ("kitti", "touched"), ("maicity", "gather"), ("kitti", "gather")])
 def test_two_ranks_match_one_process(kind, exchange, tmp_path):
     points = 8192 + 40  # per rank; ragged against the 16-point tiles and the sampler's 1024-draw blocks
     two = _run(tmp_path, kind, exchange, points, 2, "two")

@@ -780,3 +780,81 @@ def test_step_adds_up_the_surface_count_parts(n):
         assert all(rel_err(x, y) <= TOL for x, y in zip(a[3], b[3]))
     c = run(parts, variant=5)  # the check library's kernel takes one count: the Python layer adds the parts up for it
     assert abs_err(c[1], b[1]) <= TOL and abs(c[0] - b[0]) <= TOL * max(1.0, abs(b[0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap", [None, 4096])
+def test_own_rows_all_gather_device_path(cap):
+    """dp.RowGatherReducer on CUDA tensors (shine_rows_pack / shine_rows_unpack_add).  With a stand-in all-gather of two
+    identical ranks the flagged rows, the trash rows and the decoder grads must come back doubled and everything else
+    untouched; the pack must MOVE the rows (bucket zero in between), clear the flags except the trash rows', build the same
+    message as the torch-indexing path of the gloo tests, and report a message that is too small instead of truncating
+    silently."""
+    from shine_mapping_amd import dp
+
+    class TwoIdenticalRanks:
+        class ReduceOp:
+            MAX = "max"
+
+        def __init__(self):
+            self.msgs = []
+
+        def get_world_size(self, group=None):
+            return 2
+
+        def all_reduce(self, t, op=None, group=None):  # (the capacity measurement: MAX over identical ranks)
+            pass
+
+        def all_gather_into_tensor(self, out, inp, group=None):
+            self.msgs.append(inp.detach().cpu().clone())
+            out.view(2, -1).copy_(inp.unsqueeze(0).expand(2, -1))
+            self.mid = [p.grad.detach().clone() for p in self.params]
+
+    torch.manual_seed(0)
+    rows = [37, 1000, 70001]
+    feats = [torch.nn.Parameter(torch.randn(r + 1, 8, device="cuda")) for r in rows]
+    mlp = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in (256, 32, 1024, 32, 32, 1)]
+    for p in feats + mlp:
+        p.grad = torch.randn_like(p)
+    before = [p.grad.clone() for p in feats + mlp]
+    fake = TwoIdenticalRanks()
+    fake.params = feats + mlp
+    red = dp.RowGatherReducer(feats, mlp, fake, capacity_rows=cap)
+    marks = [(torch.rand(r + 1, device="cuda") < frac) for r, frac in zip(rows, (0.5, 0.0, 0.1))]
+    for f, m, r in zip(red.flags, marks, rows):
+        m[r] = True  # (the trash row's flag is always set)
+        f[m] = 1
+    n_flagged = sum(int(m.sum()) for m in marks)
+    red.exchange()
+    torch.cuda.synchronize()
+    overflow = red.overflowed()
+    if cap is not None and n_flagged > cap:
+        assert overflow  # 4096 < the ~7.5 k flagged rows: reported
+        return
+    assert not overflow
+    assert all(float(g.abs().max()) == 0.0 for g, m in zip(fake.mid[:3], marks) for g in [g[m]])  # moved out of the bucket
+    assert all(float(g.abs().max()) == 0.0 for g in fake.mid[3:])                                  # ... and the tail
+    for p, b, m in zip(feats, before[:3], marks):
+        assert torch.equal(p.grad[m], 2 * b[m]) and torch.equal(p.grad[~m], b[~m])
+    for p, b in zip(mlp, before[3:]):
+        assert torch.equal(p.grad, 2 * b)
+    assert int(red._flags_flat.sum()) == 3 and all(int(f[r]) == 1 for f, r in zip(red.flags, rows))
+    # the torch-indexing path (CPU tensors) builds the same message
+    cpu_feats = [torch.nn.Parameter(p.detach().cpu()) for p in feats]
+    cpu_mlp = [torch.nn.Parameter(p.detach().cpu()) for p in mlp]
+    for p, b in zip(cpu_feats + cpu_mlp, before):
+        p.grad = b.cpu().clone()
+    fake2 = TwoIdenticalRanks()
+    fake2.params = cpu_feats + cpu_mlp
+    red2 = dp.RowGatherReducer(cpu_feats, cpu_mlp, fake2, capacity_rows=red.capacity)
+    for f, m in zip(red2.flags, marks):
+        f[m.cpu()] = 1
+    red2.exchange()
+    a, b, capr = fake.msgs[0], fake2.msgs[0], red.capacity
+    n = int(a[0])
+    assert n == n_flagged and torch.equal(a[:4], b[:4])                     # header: count, overflow
+    assert torch.equal(a[4: 4 + n], b[4: 4 + n])                             # ids, ascending
+    assert torch.equal(a[4 + capr: 4 + capr + 8 * n], b[4 + capr: 4 + capr + 8 * n])  # values (unused slots are undefined)
+    assert torch.equal(a[4 + 9 * capr:], b[4 + 9 * capr:])                   # tail
+    for p, q in zip(feats + mlp, cpu_feats + cpu_mlp):
+        assert torch.equal(p.grad.cpu(), q.grad)
