@@ -76,6 +76,11 @@ typedef struct shine_step_config {
   double* zero_f64;        /* one device double cleared by the step (shine_regularize's accumulator: out_zeroed = 1 there) */
   int32_t n_surf_parts;    /* shine_train_step's n_surf points at this many (<= 64) int64 partial counts which the kernels add up
                               (what shine_sample_sorted_* writes to surf_parts); 0 / 1 = one count */
+  int32_t defer_reduce;    /* 1: shine_train_step launches the fused kernel ONLY and leaves its per-workgroup partial sums
+                              (decoder grads, trash-row grads, loss terms) in the workspace: shine_finish_iteration consumes
+                              them in the optimiser's launch.  loss_parts is then written by that call, and adam_state /
+                              zero_f64 are served by the fused kernel itself.  (shine_importance_sweep uses it too: it needs
+                              none of those sums.) */
 } shine_step_config;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -353,6 +358,25 @@ int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t seed, uint64_
 int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const float* weight_decay,
                         float beta1, float beta2, float eps, int64_t* step_state, int32_t zero_grad, void* stream);
+
+/* ---- the tail of a training iteration in ONE launch (shine_batch.py:208-210, shine_incre.py:152-181): after a
+ *      shine_train_step with cfg->defer_reduce = 1 (same cfg and n; workspace = that call's workspace, n_surf as given there)
+ *        - the step's per-workgroup partial sums are added up where they are consumed (decoder grads, trash-row grads) and
+ *          loss_parts[4] is written as shine_train_step would have;
+ *        - lambda_forget != 0: FeatureOctree.cal_regularization (model/feature_octree.py:246-255) on the rows the step
+ *          flagged in touched[s] (flags cleared): *reg_out += the unweighted value (cleared by the step: cfg->zero_f64 =
+ *          reg_out), gradient 2 lambda importance (F - F_last) unless grad_on[s] == 0 — as shine_regularize;
+ *        - torch's Adam on every tensor, gradients cleared — as shine_adam_step_dev with zero_grad = 1 | 2: step_state was
+ *          advanced by the step (cfg->adam_state = step_state), lr_dev[lr_index[i]] is tensor i's learning rate.
+ *      Tensors: the L feature tables TOP-DOWN ([rows_l + 1][8]), then the decoder's W1, b1, W2, b2, w3, b3 (or only the
+ *      tables when the decoder is frozen).  An iteration at the reference's batch size is then {draw, fused step, this}. */
+int shine_finish_iteration(const shine_step_config* cfg, int64_t n, const void* workspace, const int64_t* n_surf,
+                           double* loss_parts, const float* const* feats_last, const float* const* importance,
+                           unsigned char* const* touched, const int32_t* grad_on, float lambda_forget, double* reg_out,
+                           int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                           float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const int32_t* lr_index,
+                           const float* weight_decay, float beta1, float beta2, float eps, const int64_t* step_state,
+                           void* stream);
 
 /* ---- measurement aid (tools/ab_build.py AB_PROF): per-wave phase cycle counters of the fused kernel.  buffer = device
  *      int64 [waves][8] (setup, query, decoder forward, loss+backward, scatter, weight grads, flush, block wait) that

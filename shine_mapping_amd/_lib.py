@@ -42,6 +42,7 @@ class StepConfig(C.Structure):
         ("adam_beta2", C.c_float),
         ("zero_f64", C.c_void_p),
         ("n_surf_parts", C.c_int32),
+        ("defer_reduce", C.c_int32),
     ]
 
 
@@ -94,6 +95,11 @@ _SIGNATURES = {
     "shine_adam_step_dev": (
         C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
                   _P, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _P, C.c_int32, _P]),
+    "shine_finish_iteration": (
+        C.c_int, [C.POINTER(StepConfig), C.c_int64, _P, _P, _P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                  C.POINTER(C.c_int32), C.c_float, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                  C.POINTER(C.c_int64), _P, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _P,
+                  _P]),
     "shine_sample_sorted_dev": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, _P, _P, _P, C.c_size_t, _P, _P, _P,
                                           C.POINTER(C.c_size_t), _P]),
     "shine_sample_sorted_slice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, _P,

@@ -73,6 +73,8 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
   // shipped yaml).  The check library adds 1 = the lane-per-point reference kernel (any batch, up to 8 levels; the
   // on-device cross-check of the tests) and 5 = the role-specialised experimental kernel (check/shine_step_v5.hip).
   const int variant = cfg->kernel_variant & 0xff;
+  if (cfg->defer_reduce && (variant == 1 || variant == 5 || cfg->n_levels > shine::LCAP || !slots))
+    return shine::set_error(SHINE_E_INVALID, "shine_train_step: defer_reduce is for the product kernel on a planned batch");
   if (cfg->n_surf_parts > 1 && (variant == 1 || variant == 5 || cfg->n_levels > shine::LCAP || !slots))
     return shine::set_error(SHINE_E_INVALID, "shine_train_step: n_surf_parts > 1 is for the product kernel (sum the parts first)");
   if (variant == 5) {

@@ -186,6 +186,10 @@ extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_co
     shine_step_config cc = *cfg;  // the reference normalises every chunk by its own size (sdf_bce_loss 'mean')
     cc.n_global = n;
     cc.inv_n = cc.reduction_sum ? 1.0 : 1.0 / (double)n;
+    // no reduction launch: the decoder is frozen, the loss is not read, and the trash rows' sums would be cleared below anyway
+    cc.defer_reduce = 1;
+    cc.adam_state = nullptr;
+    cc.zero_f64 = nullptr;
     int rc = shine_train_step(t, &cc, coord, sdf_label, weight, idx + b, slots, nullptr, n, feats, rows, mlp, pred_scratch,
                               nullptr, grad_feats, nullptr, loss_parts, nullptr, workspace, workspace_bytes, stream);
     if (rc != SHINE_OK) return rc;

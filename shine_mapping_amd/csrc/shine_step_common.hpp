@@ -36,6 +36,7 @@ struct V1Args {
   const int* slots;  // [n][L] hash slots per point IN VISITING ORDER (shine_plan_batch), or null: probe in-kernel
   const long long* n_surf;  // [n_surf_parts] partial counts of the batch's surface samples (eikonal), summed by the kernels
   int n_surf_parts;
+  int defer_reduce;         // cfg->defer_reduce: no reduction launch; the fused kernel serves the iteration hooks itself
   const float* ext_delta;  // Tier A backward (shine_interp_sdf_backward): d loss / d pred per point, indexed like pred;
                            // the kernel then skips its own loss and backpropagates this instead
   const float* mlp[6];
@@ -156,6 +157,7 @@ inline int fill_step_args(V1Args* a, const shine_tables* t, const shine_step_con
   a->n_surf = cfg->eikonal_on ? reinterpret_cast<const long long*>(n_surf) : nullptr;
   if (cfg->n_surf_parts > 64) return set_error(SHINE_E_INVALID, "shine_train_step: at most 64 n_surf parts");
   a->n_surf_parts = cfg->n_surf_parts > 1 ? cfg->n_surf_parts : 1;
+  a->defer_reduce = cfg->defer_reduce ? 1 : 0;
   a->pred = pred_out;
   a->grad_x = grad_x_out;
   a->loss_parts = loss_parts;

@@ -928,6 +928,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     dl[1] = s_loss[1];
     dl[2] = s_loss[2];
   }
+  // cfg->defer_reduce: no reduction launch follows, so the iteration hooks (optimiser step count, regulariser accumulator)
+  // ride here — nothing in this launch reads either
+  if (a.defer_reduce && blockIdx.x == 0) {
+    if (tid == 0 && a.adam_state) adam_advance(a.adam_state, a.adam_b1, a.adam_b2);
+    if (tid == 64 && a.zero_f64) *a.zero_f64 = 0.0;
+  }
 #undef SHINE_STAMP
 }
 
@@ -1056,7 +1062,7 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
     }
   }
   SHINE_HIP_CHECK(hipGetLastError());
-  if (!(a.ablate & 32)) {  // (ablate bit 32: measurement only — time the dominant kernel by itself)
+  if (!(a.ablate & 32) && !a.defer_reduce) {  // (ablate bit 32: measurement only — time the dominant kernel by itself)
     hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks);
     SHINE_HIP_CHECK(hipGetLastError());
   }

@@ -5,9 +5,9 @@ The reference's inner loop (shine_batch.py:105-210, shine_incre.py:114-181) at i
 host: ~7 kernel launches per iteration at ~100 us of Python/driver time against ~75 us of GPU time.  This helper captures
 
     idx = pool.draw(n)                                       sorted batch from the node-ordered pool
-    loss = fused_train_step(..., pool=pool, idx=idx)          query + decode + loss + backward
-    [reg = fused_regularization(...)]                         incremental mapping only
-    opt.step(zero_grad=True)                                  fused dense Adam, also clears the grads
+    loss = fused_train_step(..., pool=pool, idx=idx)          query + decode + loss + backward (the fused kernel only)
+    opt.finish_iteration(...)                                 sums of the kernel's partial vectors + [regulariser,
+                                                              incremental mapping only] + fused dense Adam + grads cleared
 
 once and replays it.  The scalars that change per iteration — the sampler's stream id and Adam's step count — live in
 device memory and are advanced by the kernels themselves (shine_sample_sorted_dev / shine_adam_step_dev), so every
@@ -57,9 +57,11 @@ def _capture(fn):
 
 
 class GraphedIteration:
-    def __init__(self, octree, decoder, pool, opt, opts: StepOptions, n: int, lambda_forget: float = 0.0, unroll: int = 1):
+    def __init__(self, octree, decoder, pool, opt, opts: StepOptions, n: int, lambda_forget: float = 0.0, unroll: int = 1,
+                 fold: bool = True):
         self.octree, self.decoder, self.pool, self.opt, self.opts, self.n = octree, decoder, pool, opt, opts, int(n)
         self.lambda_forget = float(lambda_forget)
+        self.fold = bool(fold)  # the iteration's tail as one launch (False: reduction, regulariser and Adam as three)
         self.regularize = self.lambda_forget != 0.0
         self.touched = touched_flags(octree) if self.regularize else None
         self._epoch = octree._tables_epoch
@@ -101,8 +103,16 @@ class GraphedIteration:
             self._hooked.adam_state, self._hooked.adam_betas = state, tuple(self.opt.betas)
             self._hooked.zero_f64 = self._reg_out
         opts = self._hooked if hooked else self.opts
+        # hooked (every iteration but the eager warm-up): the fused kernel only, then ONE launch for {sums of its partial
+        # vectors, regulariser, Adam, clearing the grads} (FusedAdam.finish_iteration) — 3 launches per iteration instead of 5
+        fold = hooked and self.fold and hasattr(self.opt, "finish_iteration")
+        pending = {} if fold else None
         loss, _, _ = fused_train_step(self.octree, self.decoder, None, None, None, opts, n_surf=n_surf, pool=self.pool,
-                                      idx=idx, touched=self.touched)
+                                      idx=idx, touched=self.touched, pending=pending)
+        if fold:
+            self.opt.finish_iteration(pending, dict(lambda_forget=self.lambda_forget, touched=self.touched,
+                                                    out=self._reg_out) if self.regularize else None)
+            return loss, (self._reg_out[0] if self.regularize else None)
         reg = None
         if self.regularize:
             reg = fused_regularization(self.octree, self.lambda_forget, self.touched, out=self._reg_out, out_zeroed=hooked)

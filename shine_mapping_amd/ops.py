@@ -96,7 +96,7 @@ def forward_sdf(octree, decoder, coord, want_feat=False, want_indices=False, wan
 
 def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
                      n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None,
-                     pool=None, idx: Optional[torch.Tensor] = None):
+                     pool=None, idx: Optional[torch.Tensor] = None, pending: Optional[dict] = None):
     """One training iteration's forward+backward (no optimiser): the fused Tier-B step, raw form.
 
     coord [N,3], sdf_label [N], weight [N] (sign: + surface / - free space, utils/data_sampler.py:102-103).
@@ -104,9 +104,13 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     included — what ``cur_loss.backward()`` produces, shine_batch.py:209).  Returns (loss, pred, g) where
     loss is a 0-dim float64 device tensor (no host sync, NO grad_fn — the gradients are already in place) and
     g = get_gradient(coord,pred)*sigma or None.  `train_step` is the same launch as an autograd node.
+
+    `pending` (a dict): the step launches its fused kernel only (cfg->defer_reduce) and leaves the per-workgroup partial sums
+    — decoder grads, trash-row grads, loss terms — in the workspace for the optimiser's launch; the dict is filled with what
+    FusedAdam.finish_iteration(pending, ...) needs, and `loss` is valid after that call.
     """
     return _fused_launch(octree, decoder, coord, sdf_label, weight, opts, want_grad_x=want_grad_x, perm=perm,
-                         n_surf=n_surf, slots=slots, touched=touched, pool=pool, idx=idx)
+                         n_surf=n_surf, slots=slots, touched=touched, pool=pool, idx=idx, pending=pending)
 
 
 def train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
@@ -130,7 +134,7 @@ def train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, wan
 
 def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
                   n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None,
-                  pool=None, idx: Optional[torch.Tensor] = None, gfeat=None, gmlp=None, dec_grad=None):
+                  pool=None, idx: Optional[torch.Tensor] = None, gfeat=None, gmlp=None, dec_grad=None, pending=None):
     """shine_train_step on explicit gradient buffers (gfeat: L tensors or None entries, gmlp: 6 tensors; default: the
     parameters' own dense `.grad`)."""
     t = octree._require_tables()
@@ -205,6 +209,13 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
                                                     and slots.numel() == n * octree.featured_level_num):
         raise ValueError("slots must come with perm from dp.plan_batch: CUDA int32 [N, L]")
     ws = _workspace(dev, cfg)
+    if pending is not None:
+        if variant not in (0, 4) or slots is None:
+            raise ValueError("pending= (deferred reduction) needs the product kernel on a planned / pool batch")
+        cfg.defer_reduce = 1
+        pending.clear()
+        pending.update(cfg=cfg, n=n, workspace=ws, n_surf=n_surf, loss_parts=loss_parts, dec_grad=bool(dec_grad),
+                       octree=octree, decoder=decoder)
     # the product library serves kernel_variant 0 / 4 on <= 4 levels; the reference kernel (1), the experimental kernel (5)
     # and deeper trees need the check library (tests / tools)
     library = _lib.check_lib() if (variant in (1, 5) or octree.featured_level_num > 4) else _lib.lib()

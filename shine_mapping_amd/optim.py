@@ -174,3 +174,55 @@ def setup_optimizer(config, octree_feat, mlp_geo_param, mlp_sem_param=None, sigm
         groups.append({"params": [octree_feat[L - i - 1]], "lr": lr_cur})
         lr_cur *= getattr(config, "lr_level_reduce_ratio", 1.0)
     return FusedAdam(groups, betas=(0.9, 0.99), eps=getattr(config, "adam_eps", 1e-15))
+
+
+def _finish_iteration(self, pending, regulariser=None):
+    """The tail of an iteration in ONE launch (shine_finish_iteration): `pending` is the dict a
+    fused_train_step(..., pending=...) filled — its partial sums are added up where they are consumed, the regulariser
+    (regulariser = dict(lambda_forget, touched, out) as for ops.fused_regularization) is evaluated on the touched rows, Adam
+    is applied to every tensor and the grads are cleared.  Graph-replayable only: the step must have counted the optimiser
+    step (StepOptions.adam_state = device_state())."""
+    if self._dev is None:
+        raise RuntimeError("finish_iteration needs the device-side step state: run one step(graph_safe=True) first")
+    octree, decoder = pending["octree"], pending["decoder"]
+    ts = self._tensors()
+    by_param = {id(t[0]): (i, t) for i, t in enumerate(ts)}
+    order = list(octree.hier_features) + (list(decoder.fused_params()) if pending["dec_grad"] else [])
+    if len(order) != len(ts) or any(id(p) not in by_param for p in order):
+        raise NotImplementedError("finish_iteration: the optimiser must hold exactly the feature tables and the decoder tensors "
+                                  "that receive grads")
+    if self._dev[1].numel() != len(ts):
+        raise RuntimeError("finish_iteration: the set of tensors changed since the device state was made")
+    sel = [by_param[id(p)] for p in order]
+    for _, (p, m, v, _, _) in sel:
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+            raise ValueError("FusedAdam needs contiguous CUDA float32 parameters and grads")
+    n = len(sel)
+    L = len(octree.hier_features)
+    cfg = pending["cfg"]
+    lam, last, imp, touched, grad_on, reg_out = 0.0, None, None, None, None, None
+    if regulariser is not None and float(regulariser["lambda_forget"]) != 0.0:
+        lam = float(regulariser["lambda_forget"])
+        keep = pending.setdefault("keep", [])  # (contiguous copies must outlive the launch)
+        lasts = [t.detach().contiguous() for t in octree.features_last_frame]
+        imps = [t.contiguous() for t in octree.importance_weight]
+        keep += lasts + imps
+        last = _lib.ptr_array([t.data_ptr() for t in lasts])
+        imp = _lib.ptr_array([t.data_ptr() for t in imps])
+        touched = _lib.ptr_array([t.data_ptr() for t in regulariser["touched"]])
+        grad_on = (C.c_int32 * L)(*[1 if g else 0 for g in octree._reg_grad_on])
+        reg_out = regulariser["out"].data_ptr()
+    ns = pending["n_surf"]
+    _lib.check(
+        _lib.lib().shine_finish_iteration(
+            C.byref(cfg), pending["n"], pending["workspace"].data_ptr(), ns.data_ptr() if ns is not None else None,
+            pending["loss_parts"].data_ptr(), last, imp, touched, grad_on, lam, reg_out, n,
+            _lib.ptr_array([t[0].data_ptr() for _, t in sel]), _lib.ptr_array([t[0].grad.data_ptr() for _, t in sel]),
+            _lib.ptr_array([t[1].data_ptr() for _, t in sel]), _lib.ptr_array([t[2].data_ptr() for _, t in sel]),
+            _lib.i64_array([t[0].numel() for _, t in sel]), self._dev[1].data_ptr(), (C.c_int32 * n)(*[i for i, _ in sel]),
+            (C.c_float * n)(*[t[4] for _, t in sel]), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+            self._dev[0].data_ptr(), _lib.current_stream_handle()),
+        "shine_finish_iteration")
+
+
+FusedAdam.finish_iteration = _finish_iteration

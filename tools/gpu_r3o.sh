@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r03o; O=gpurun_out/r03o
+for u in 1 7 49; do
+  echo "== ncd-incre unroll $u"; timeout 300 python bench.py --workload ncd-incre --no-cpu-baseline --unroll $u 2>>$O/err.log | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        r=json.loads(l); print(r['frames_per_s'], r['per_frame_ms_median'])"
+done
