@@ -369,14 +369,25 @@ int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* g
  *        - torch's Adam on every tensor, gradients cleared — as shine_adam_step_dev with zero_grad = 1 | 2: step_state was
  *          advanced by the step (cfg->adam_state = step_state), lr_dev[lr_index[i]] is tensor i's learning rate.
  *      Tensors: the L feature tables TOP-DOWN ([rows_l + 1][8]), then the decoder's W1, b1, W2, b2, w3, b3 (or only the
- *      tables when the decoder is frozen).  An iteration at the reference's batch size is then {draw, fused step, this}. */
+ *      tables when the decoder is frozen).  next_draw (optional): the sorted draw of the NEXT iteration — what
+ *      shine_sample_sorted_dev(pool_size, n, seed, stream_state, idx_out, NULL, 0, weight, surf_parts, ...) would launch, for
+ *      n < 16 K draws — done by a few extra blocks of this launch (the fused kernel is done with the index buffer by then),
+ *      so an iteration at the reference's batch size is {fused step, this}: two launches. */
+typedef struct shine_next_draw {
+  int64_t pool_size, n;
+  uint64_t seed;
+  uint64_t* stream_state;  /* device uint64[4], as shine_sample_sorted_dev */
+  int32_t* idx_out;        /* [n] */
+  const float* weight;     /* with surf_parts: the pool's weights */
+  int64_t* surf_parts;     /* int64[SHINE_SURF_PARTS] or NULL */
+} shine_next_draw;
 int shine_finish_iteration(const shine_step_config* cfg, int64_t n, const void* workspace, const int64_t* n_surf,
                            double* loss_parts, const float* const* feats_last, const float* const* importance,
                            unsigned char* const* touched, const int32_t* grad_on, float lambda_forget, double* reg_out,
                            int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                            float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const int32_t* lr_index,
                            const float* weight_decay, float beta1, float beta2, float eps, const int64_t* step_state,
-                           void* stream);
+                           const shine_next_draw* next_draw, void* stream);
 
 /* ---- measurement aid (tools/ab_build.py AB_PROF): per-wave phase cycle counters of the fused kernel.  buffer = device
  *      int64 [waves][8] (setup, query, decoder forward, loss+backward, scatter, weight grads, flush, block wait) that

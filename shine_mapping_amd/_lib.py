@@ -46,6 +46,11 @@ class StepConfig(C.Structure):
     ]
 
 
+class NextDraw(C.Structure):  # include/shine_hip.h shine_next_draw
+    _fields_ = [("pool_size", C.c_int64), ("n", C.c_int64), ("seed", C.c_uint64), ("stream_state", C.c_void_p),
+                ("idx_out", C.c_void_p), ("weight", C.c_void_p), ("surf_parts", C.c_void_p)]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -99,7 +104,7 @@ _SIGNATURES = {
         C.c_int, [C.POINTER(StepConfig), C.c_int64, _P, _P, _P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                   C.POINTER(C.c_int32), C.c_float, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                   C.POINTER(C.c_int64), _P, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _P,
-                  _P]),
+                  C.POINTER(NextDraw), _P]),
     "shine_sample_sorted_dev": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, _P, _P, _P, C.c_size_t, _P, _P, _P,
                                           C.POINTER(C.c_size_t), _P]),
     "shine_sample_sorted_slice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, _P,

@@ -9,8 +9,10 @@
 //   * adds them up where they are consumed — the decoder's gradient elements and the trash rows' — and writes loss_parts,
 //   * evaluates the regulariser (value and gradient) on the rows the step flagged, clearing the flags,
 //   * applies torch's Adam to every tensor and clears the gradients (opt.step() + opt.zero_grad()),
+//   * optionally draws the NEXT iteration's sorted batch in a few extra blocks (the one-launch sampler as a device function),
 // one thread per feature row (8 floats), one wave per 8 elements whose gradient is a sum over the workgroups (trash rows,
 // decoder): the lanes split the partial vectors.
+#include "shine_sampler_dev.hpp"
 #include "shine_step_common.hpp"
 
 namespace shine {
@@ -53,6 +55,14 @@ struct FinArgs {
   float b1, b2, eps;
   const long long* step_state;  // already advanced for this step (by the fused kernel, cfg->adam_state)
   const float* lr_dev;
+  // the sorted draw of the NEXT iteration (shine_next_draw), by nd_blocks extra blocks; nd_blocks == 0: none
+  int nd_blocks;
+  long long nd_n, nd_pool;
+  unsigned long long nd_seed;
+  unsigned long long* nd_stream;
+  int* nd_idx;
+  const float* nd_weight;
+  long long* nd_surf;
 };
 
 struct FinScalars {
@@ -68,10 +78,16 @@ __device__ __forceinline__ void fin_adam1(float& p, float g, float& m, float& v,
 }
 
 // blocks [0, fb): feature rows, one thread per row; blocks [fb, fb + db): decoder, one wave per unit of 8 elements;
-// block fb + db: the loss terms
+// block fb + db: the loss terms; blocks behind it: the sorted draw of the next iteration (one-launch form of the sampler)
 __global__ __launch_bounds__(256) void k_finish(const FinArgs a, int fb, int db) {
   __shared__ float s_lr[FIN_MAX_SEG];
   __shared__ double s_red[4];
+  __shared__ SampleShared s_sample;
+  if ((int)blockIdx.x > fb + db) {  // (nothing of this iteration reads the index buffer any more: the fused kernel is done)
+    sample_fused_block(s_sample, (int)blockIdx.x - (fb + db + 1), a.nd_blocks, a.nd_n, a.nd_pool, a.nd_seed, 0ull, a.nd_stream,
+                       a.nd_idx, a.nd_weight, a.nd_surf);
+    return;
+  }
   const float* bc = reinterpret_cast<const float*>(a.step_state + 1);
   const FinScalars sc = {a.b1, a.b2, a.eps, bc[0], bc[1]};
   if (threadIdx.x < a.n_seg) s_lr[threadIdx.x] = a.lr_dev[a.seg[threadIdx.x].lr_idx];
@@ -207,7 +223,8 @@ extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, c
                                       double* reg_out, int32_t n_tensors, float* const* params, float* const* grads,
                                       float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                                       const float* lr_dev, const int32_t* lr_index, const float* weight_decay, float beta1,
-                                      float beta2, float eps, const int64_t* step_state, void* stream) {
+                                      float beta2, float eps, const int64_t* step_state, const shine_next_draw* next_draw,
+                                      void* stream) {
   if (!cfg || n < 1 || !workspace || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr_dev || !lr_index ||
       !weight_decay || !step_state)
     return set_error(SHINE_E_INVALID, "shine_finish_iteration: null argument");
@@ -278,10 +295,26 @@ extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, c
   a.eps = eps;
   a.step_state = reinterpret_cast<const long long*>(step_state);
   a.lr_dev = lr_dev;
+  if (next_draw) {
+    const long long nb = (next_draw->n + 1 + SB - 1) / SB;
+    if (next_draw->n < 1 || nb > FUSED_MAX_BLOCKS || next_draw->pool_size < 1 || next_draw->pool_size > 0x7fffffffll ||
+        !next_draw->stream_state || !next_draw->idx_out || (next_draw->surf_parts && !next_draw->weight))
+      return set_error(SHINE_E_INVALID, "shine_finish_iteration: next_draw wants 1 <= n < 16 K draws, a device stream state and "
+                                        "an index buffer");
+    a.nd_blocks = (int)nb;
+    a.nd_n = next_draw->n;
+    a.nd_pool = next_draw->pool_size;
+    a.nd_seed = next_draw->seed;
+    a.nd_stream = reinterpret_cast<unsigned long long*>(next_draw->stream_state);
+    a.nd_idx = next_draw->idx_out;
+    a.nd_weight = next_draw->weight;
+    a.nd_surf = reinterpret_cast<long long*>(next_draw->surf_parts);
+  }
   long long fb = (a.feat_units + 255) / 256;
   if (fb > 4096) fb = 4096;
   const long long db = (a.dec_units + 3) / 4;
-  hipLaunchKernelGGL(k_finish, dim3((unsigned)(fb + db + 1)), dim3(256), 0, (hipStream_t)stream, a, (int)fb, (int)db);
+  hipLaunchKernelGGL(k_finish, dim3((unsigned)(fb + db + 1 + a.nd_blocks)), dim3(256), 0, (hipStream_t)stream, a, (int)fb,
+                     (int)db);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }

@@ -4,10 +4,11 @@ hipGraphs).
 The reference's inner loop (shine_batch.py:105-210, shine_incre.py:114-181) at its own batch size (4096) is bound by the
 host: ~7 kernel launches per iteration at ~100 us of Python/driver time against ~75 us of GPU time.  This helper captures
 
-    idx = pool.draw(n)                                       sorted batch from the node-ordered pool
     loss = fused_train_step(..., pool=pool, idx=idx)          query + decode + loss + backward (the fused kernel only)
     opt.finish_iteration(...)                                 sums of the kernel's partial vectors + [regulariser,
                                                               incremental mapping only] + fused dense Adam + grads cleared
+                                                              + idx = pool.draw(n) for the NEXT iteration (sorted batch
+                                                              from the node-ordered pool; the first one is drawn up front)
 
 once and replays it.  The scalars that change per iteration — the sampler's stream id and Adam's step count — live in
 device memory and are advanced by the kernels themselves (shine_sample_sorted_dev / shine_adam_step_dev), so every
@@ -71,7 +72,14 @@ class GraphedIteration:
         self.loss = self.reg = None
         self._reg_out = torch.zeros(1, dtype=torch.float64, device=pool.coord.device) if self.regularize else None
         self._hooked = None  # StepOptions with the iteration hooks (made once the optimiser has its device state)
+        self._ahead = False
         self._body()  # eager warm-up: allocates workspaces, optimiser state and device counters outside the capture
+        # From here on the optimiser's launch also draws the NEXT iteration's batch (a few extra blocks, no launch of its own):
+        # an iteration is {fused kernel, tail}.  `_idx` then holds the batch of the iteration to come; it is primed here.
+        self._ahead = (self.fold and hasattr(self.opt, "finish_iteration") and hasattr(self.opt, "device_state")
+                       and self.opt.device_state() is not None and self.n + 1 <= 16 * 1024)
+        if self._ahead:
+            self.pool.draw(self.n, out=self._idx, graph_safe=True, surf_parts=self._surf)
         self.graph, (self.loss, self.reg) = _capture(self._body)
         # `unroll` iterations in ONE graph: at the reference's batch size an iteration is ~8 small launches, and a graph
         # replay costs ~10-16 us of host time whatever it holds — run(n) replays the long graph n // unroll times.  It pays
@@ -88,7 +96,7 @@ class GraphedIteration:
             self.graph_k, (self.loss_k, self.reg_k) = _capture(body_k)
 
     def _body(self):
-        idx = self.pool.draw(self.n, out=self._idx, graph_safe=True, surf_parts=self._surf)
+        idx = self._idx if self._ahead else self.pool.draw(self.n, out=self._idx, graph_safe=True, surf_parts=self._surf)
         n_surf = self._surf
         # Iteration hooks: the step's reduction launch also counts the optimiser step (+ bias corrections) and clears the
         # regulariser's accumulator, so neither costs a launch of its own (an iteration at N = 4096 is a chain of small
@@ -111,7 +119,8 @@ class GraphedIteration:
                                       idx=idx, touched=self.touched, pending=pending)
         if fold:
             self.opt.finish_iteration(pending, dict(lambda_forget=self.lambda_forget, touched=self.touched,
-                                                    out=self._reg_out) if self.regularize else None)
+                                                    out=self._reg_out) if self.regularize else None,
+                                      next_draw=self.pool.next_draw(self.n, self._idx, self._surf) if self._ahead else None)
             return loss, (self._reg_out[0] if self.regularize else None)
         reg = None
         if self.regularize:

@@ -176,11 +176,12 @@ def setup_optimizer(config, octree_feat, mlp_geo_param, mlp_sem_param=None, sigm
     return FusedAdam(groups, betas=(0.9, 0.99), eps=getattr(config, "adam_eps", 1e-15))
 
 
-def _finish_iteration(self, pending, regulariser=None):
+def _finish_iteration(self, pending, regulariser=None, next_draw=None):
     """The tail of an iteration in ONE launch (shine_finish_iteration): `pending` is the dict a
     fused_train_step(..., pending=...) filled — its partial sums are added up where they are consumed, the regulariser
     (regulariser = dict(lambda_forget, touched, out) as for ops.fused_regularization) is evaluated on the touched rows, Adam
-    is applied to every tensor and the grads are cleared.  Graph-replayable only: the step must have counted the optimiser
+    is applied to every tensor and the grads are cleared; next_draw = SortedPool.next_draw(...) also draws the next
+    iteration's batch in the same launch.  Graph-replayable only: the step must have counted the optimiser
     step (StepOptions.adam_state = device_state())."""
     if self._dev is None:
         raise RuntimeError("finish_iteration needs the device-side step state: run one step(graph_safe=True) first")
@@ -221,7 +222,7 @@ def _finish_iteration(self, pending, regulariser=None):
             _lib.ptr_array([t[1].data_ptr() for _, t in sel]), _lib.ptr_array([t[2].data_ptr() for _, t in sel]),
             _lib.i64_array([t[0].numel() for _, t in sel]), self._dev[1].data_ptr(), (C.c_int32 * n)(*[i for i, _ in sel]),
             (C.c_float * n)(*[t[4] for _, t in sel]), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-            self._dev[0].data_ptr(), _lib.current_stream_handle()),
+            self._dev[0].data_ptr(), C.byref(next_draw) if next_draw is not None else None, _lib.current_stream_handle()),
         "shine_finish_iteration")
 
 

@@ -111,6 +111,24 @@ class SortedPool:
             self.draws += 1
         return idx
 
+    def next_draw(self, n, out, surf_parts=None):
+        """The graph-replayable draw(n, out=out, surf_parts=...) as a shine_next_draw record for
+        FusedAdam.finish_iteration(next_draw=...): the optimiser's launch then draws the NEXT iteration's batch in a few extra
+        blocks (n < 16 K).  Keeps the device stream state of graph_safe draws."""
+        dev = self.coord.device
+        if self._stream_state is None:
+            self._stream_state = torch.tensor([self.draws, 0, self.draws, 0], dtype=torch.int64, device=dev)
+        if not (out.is_cuda and out.dtype == torch.int32 and out.is_contiguous() and out.numel() == int(n)):
+            raise ValueError("next_draw: out must be a contiguous CUDA int32 tensor of n entries")
+        if surf_parts is not None and (surf_parts.dtype != torch.int64 or surf_parts.numel() != SURF_PARTS):
+            raise ValueError("next_draw: surf_parts must be surf_parts_buffer()")
+        nd = _lib.NextDraw()
+        nd.pool_size, nd.n, nd.seed = self.size, int(n), self.seed
+        nd.stream_state, nd.idx_out = self._stream_state.data_ptr(), out.data_ptr()
+        nd.weight = self.weight.data_ptr()
+        nd.surf_parts = surf_parts.data_ptr() if surf_parts is not None else None
+        return nd
+
     def surf_parts_buffer(self, n=None):
         """int64[64] buffer for draw(n, surf_parts=...): the partial surface counts of a batch (SHINE_SURF_PARTS)"""
         return torch.zeros(SURF_PARTS, dtype=torch.int64, device=self.coord.device)

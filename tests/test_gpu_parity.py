@@ -920,19 +920,22 @@ def test_graphed_iteration_matches_eager_loop(mode):
         if incremental:
             fused_regularization(octree, 1e3, touched)
         opt.step(zero_grad=True)
+    eager_idx.append(pool.draw(N).clone())  # (the batch iteration K + 1 would use)
+    pool.draws -= 1
     eager_feats = [p.detach().clone() for p in octree.hier_features]
     eager_mlp = [p.detach().clone() for p in dec.fused_params()]
 
     # the same K iterations: 1 eager inside the constructor + K-1 replays of the captured graph
     cfg, octree2, dec2, opt2, pool2, opts2 = make()
     step = GraphedIteration(octree2, dec2, pool2, opt2, opts2, N, lambda_forget=1e3 if incremental else 0.0)
-    assert torch.equal(step._idx, eager_idx[0])
+    # the optimiser's launch draws the NEXT iteration's batch: after iteration k, `_idx` holds batch k + 1
+    assert step._ahead and torch.equal(step._idx, eager_idx[1])
     seen = []
     for it in range(1, K):
         loss = step()
         seen.append(step._idx.clone())
     torch.cuda.synchronize()
-    assert all(torch.equal(a, b) for a, b in zip(seen, eager_idx[1:])), "replays must draw the eager loop's batches"
+    assert all(torch.equal(a, b) for a, b in zip(seen, eager_idx[2:])), "replays must draw the eager loop's batches"
     assert not torch.equal(seen[0], seen[1])
     assert opt2.steps_taken() == K and float(loss) == float(loss)
     # Both loops run the step in its DETERMINISTIC mode (StepOptions.deterministic: one wave walks the batch, the feature-grad
