@@ -521,12 +521,12 @@ def test_sorted_sampler_is_sorted_uniform_and_reproducible():
     pool, n = 1_000_003, 1 << 16
     need = C.c_size_t(0)
     st = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.shine_sample_sorted(pool, n, 7, 0, None, None, 0, None, C.byref(need), st))
+    _lib.check(lib.shine_sample_sorted(pool, n, 7, 0, None, None, 0, None, None, None, C.byref(need), st))
     ws = torch.empty(need.value, dtype=torch.uint8, device="cuda")
     draws = []
     for stream_id in (0, 1, 0):
         idx = torch.empty(n, dtype=torch.int32, device="cuda")
-        _lib.check(lib.shine_sample_sorted(pool, n, 7, stream_id, idx.data_ptr(), None, 0, ws.data_ptr(), C.byref(need), st))
+        _lib.check(lib.shine_sample_sorted(pool, n, 7, stream_id, idx.data_ptr(), None, 0, None, None, ws.data_ptr(), C.byref(need), st))
         torch.cuda.synchronize()
         draws.append(idx.cpu().long())
     a, b, a2 = draws
