@@ -706,6 +706,23 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
         runner = build_runner(exchange, micro)
     run, launch, reducer = runner["run"], runner["launch"], runner["reducer"]
 
+    # Clock ramp: the driver's own invocation (--steps 20 --warmup 5) times ~2 ms after ~0.5 ms of warm-up — the GPU would
+    # still be climbing out of its idle clocks and the line would not be the steady state the longer runs under profiles/
+    # show.  A fixed stretch of the SAME replays runs first: not timed, and reported (`preheat_ms`).  Then W warm-up steps,
+    # then exactly K timed steps.
+    preheat_ms = 0.0
+    if args.preheat_ms > 0:
+        barrier()
+        t_pre = time.perf_counter()
+        run(2 * U)
+        barrier()
+        est = torch.tensor([(time.perf_counter() - t_pre) / (2 * U)], device=dev, dtype=torch.float64)
+        if dist is not None:  # every rank must replay the same number of steps (the collectives are in the step)
+            dist.all_reduce(est, op=dist.ReduceOp.MAX)
+        n_pre = int(min(4000, max(1, args.preheat_ms * 1e-3 / max(float(est), 1e-6))) // U + 1) * U
+        run(n_pre)
+        barrier()
+        preheat_ms = (time.perf_counter() - t_pre) * 1e3
     run(warmup)
     barrier()
     t0 = time.perf_counter()
@@ -798,6 +815,7 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
                     micro, reducer.last_bytes / 1e6, reducer.capacity, reducer.dense_bytes() / 1e6,
                     ", all-gather of micro-batch k under the fused kernel of k + 1" if micro > 1 else "")
                 if exchange == "gather" else "dense flat all-reduce, %.1f MB per step" % (reducer.dense_bytes() / 1e6)),
+            "preheat_ms": preheat_ms,
             "grad_exchange_note": exchange_note,
             "grad_exchange_tuning_ms_per_step": tuned,
             "grad_exchange_overflow": gather_overflow,
@@ -852,6 +870,8 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default invocation: skip the abbreviated kitti / ncd-incre legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--preheat-ms", type=float, default=40.0,
+                    help="untimed replays of the step before the warm-up steps, so that short runs see ramped-up clocks")
     ap.add_argument("--graph-steps", type=int, default=4,
                     help="steps captured per HIP graph (K steps = K // U replays + K % U one-step replays)")
     ap.add_argument("--micro-batches", type=int, default=2,

@@ -277,14 +277,15 @@ int shine_plan_batch(const shine_tables* t, const shine_step_config* cfg, const 
  *      the drawn batch is already ordered: pass idx_out as `perm` to shine_train_step with cfg->sorted_input = 2.
  *      idx_out [n] int32 ascending; (seed, stream_id) select the random stream (use the iteration number as
  *      stream_id).  zero_ptr/zero_bytes: optional 16-B aligned buffer cleared in the same pass (the gradient bucket).
- *      surf_parts (optional, with weight = the pool's weights [pool_size]): device int64[SHINE_SURF_PARTS]; the launches that
- *      write the indices also count the draws (of the slice, for shine_sample_sorted_slice) with weight > 0 — the surface
+ *      surf_parts (optional, with surf_bits = one bit per pool sample, bit (i & 31) of word i >> 5 set iff weight[i] > 0):
+ *      device int64[SHINE_SURF_PARTS]; the launches that write the indices also count the draws (of the slice, for
+ *      shine_sample_sorted_slice) whose bit is set — the surface
  *      samples the eikonal term averages over (shine_batch.py:183-185) — as 64 partial counts (overwritten): hand them to
  *      shine_train_step as n_surf with cfg->n_surf_parts = SHINE_SURF_PARTS.  workspace == NULL returns the required
  *      bytes. --------------------------------------------------------------------------------------------------------- */
 #define SHINE_SURF_PARTS 64
 int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,
-                        void* zero_ptr, size_t zero_bytes, const float* weight, int64_t* surf_parts, void* workspace,
+                        void* zero_ptr, size_t zero_bytes, const uint32_t* surf_bits, int64_t* surf_parts, void* workspace,
                         size_t* workspace_bytes, void* stream);
 
 /* the same draw for ONE data-parallel rank: only draws [slice_begin, slice_begin + slice_n) of the global sorted batch of
@@ -293,7 +294,7 @@ int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t st
  * uint64[4] (graph-replayable, as shine_sample_sorted_dev) or NULL to use stream_id. */
 int shine_sample_sorted_slice(int64_t pool_size, int64_t n, int64_t slice_begin, int64_t slice_n, uint64_t seed,
                               uint64_t stream_id, uint64_t* stream_state, int32_t* idx_out, void* zero_ptr,
-                              size_t zero_bytes, const float* weight, int64_t* surf_parts, void* workspace,
+                              size_t zero_bytes, const uint32_t* surf_bits, int64_t* surf_parts, void* workspace,
                               size_t* workspace_bytes, void* stream);
 
 /* ---- data-parallel exchange of the rows a step touched (the reference is single-GPU: no counterpart).
@@ -353,7 +354,7 @@ int shine_query_points(const shine_tables* t, const shine_step_config* cfg, cons
  *      (cfg->adam_state): no preparation launch;  lr_dev: device float[n_tensors]
  *      (step_lr_decay, utils/tools.py:135-155, becomes a small device copy outside the graph). --------------------- */
 int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t seed, uint64_t* stream_state, int32_t* idx_out,
-                            void* zero_ptr, size_t zero_bytes, const float* weight, int64_t* surf_parts, void* workspace,
+                            void* zero_ptr, size_t zero_bytes, const uint32_t* surf_bits, int64_t* surf_parts, void* workspace,
                             size_t* workspace_bytes, void* stream);
 int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const float* weight_decay,
@@ -370,7 +371,7 @@ int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* g
  *          advanced by the step (cfg->adam_state = step_state), lr_dev[lr_index[i]] is tensor i's learning rate.
  *      Tensors: the L feature tables TOP-DOWN ([rows_l + 1][8]), then the decoder's W1, b1, W2, b2, w3, b3 (or only the
  *      tables when the decoder is frozen).  next_draw (optional): the sorted draw of the NEXT iteration — what
- *      shine_sample_sorted_dev(pool_size, n, seed, stream_state, idx_out, NULL, 0, weight, surf_parts, ...) would launch, for
+ *      shine_sample_sorted_dev(pool_size, n, seed, stream_state, idx_out, NULL, 0, surf_bits, surf_parts, ...) would launch, for
  *      n < 16 K draws — done by a few extra blocks of this launch (the fused kernel is done with the index buffer by then),
  *      so an iteration at the reference's batch size is {fused step, this}: two launches. */
 typedef struct shine_next_draw {
@@ -378,7 +379,7 @@ typedef struct shine_next_draw {
   uint64_t seed;
   uint64_t* stream_state;  /* device uint64[4], as shine_sample_sorted_dev */
   int32_t* idx_out;        /* [n] */
-  const float* weight;     /* with surf_parts: the pool's weights */
+  const uint32_t* surf_bits; /* with surf_parts: one bit per pool sample, weight > 0 */
   int64_t* surf_parts;     /* int64[SHINE_SURF_PARTS] or NULL */
 } shine_next_draw;
 int shine_finish_iteration(const shine_step_config* cfg, int64_t n, const void* workspace, const int64_t* n_surf,

@@ -48,7 +48,7 @@ class StepConfig(C.Structure):
 
 class NextDraw(C.Structure):  # include/shine_hip.h shine_next_draw
     _fields_ = [("pool_size", C.c_int64), ("n", C.c_int64), ("seed", C.c_uint64), ("stream_state", C.c_void_p),
-                ("idx_out", C.c_void_p), ("weight", C.c_void_p), ("surf_parts", C.c_void_p)]
+                ("idx_out", C.c_void_p), ("surf_bits", C.c_void_p), ("surf_parts", C.c_void_p)]
 
 
 _P = C.c_void_p

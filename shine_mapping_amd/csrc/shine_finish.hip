@@ -61,7 +61,7 @@ struct FinArgs {
   unsigned long long nd_seed;
   unsigned long long* nd_stream;
   int* nd_idx;
-  const float* nd_weight;
+  const unsigned int* nd_bits;
   long long* nd_surf;
 };
 
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_finish(const FinArgs a, int fb, int db)
   __shared__ SampleShared s_sample;
   if ((int)blockIdx.x > fb + db) {  // (nothing of this iteration reads the index buffer any more: the fused kernel is done)
     sample_fused_block(s_sample, (int)blockIdx.x - (fb + db + 1), a.nd_blocks, a.nd_n, a.nd_pool, a.nd_seed, 0ull, a.nd_stream,
-                       a.nd_idx, a.nd_weight, a.nd_surf);
+                       a.nd_idx, a.nd_bits, a.nd_surf);
     return;
   }
   const float* bc = reinterpret_cast<const float*>(a.step_state + 1);
@@ -298,7 +298,7 @@ extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, c
   if (next_draw) {
     const long long nb = (next_draw->n + 1 + SB - 1) / SB;
     if (next_draw->n < 1 || nb > FUSED_MAX_BLOCKS || next_draw->pool_size < 1 || next_draw->pool_size > 0x7fffffffll ||
-        !next_draw->stream_state || !next_draw->idx_out || (next_draw->surf_parts && !next_draw->weight))
+        !next_draw->stream_state || !next_draw->idx_out || (next_draw->surf_parts && !next_draw->surf_bits))
       return set_error(SHINE_E_INVALID, "shine_finish_iteration: next_draw wants 1 <= n < 16 K draws, a device stream state and "
                                         "an index buffer");
     a.nd_blocks = (int)nb;
@@ -307,7 +307,7 @@ extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, c
     a.nd_seed = next_draw->seed;
     a.nd_stream = reinterpret_cast<unsigned long long*>(next_draw->stream_state);
     a.nd_idx = next_draw->idx_out;
-    a.nd_weight = next_draw->weight;
+    a.nd_bits = next_draw->surf_bits;
     a.nd_surf = reinterpret_cast<long long*>(next_draw->surf_parts);
   }
   long long fb = (a.feat_units + 255) / 256;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_sample_pass1(double* block_sum, long lo
 __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, int nblocks, long long n, long long pool,
                                                       unsigned long long seed, unsigned long long stream,
                                                       unsigned long long* stream_dev, int* idx, int blk0, long long lo,
-                                                      long long cnt, const float* weight, long long* surf_parts) {
+                                                      long long cnt, const unsigned int* surf_bits, long long* surf_parts) {
   __shared__ double s_red[4];
   __shared__ double s_wave_pre[4];
   __shared__ int s_cnt[4];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, i
       long long v = (long long)((s / total) * (double)pool);
       v = v < 0 ? 0 : (v >= pool ? pool - 1 : v);
       idx[k0 + j - lo] = (int)v;
-      if (surf_parts) surf += weight[v] > 0.f ? 1 : 0;
+      if (surf_parts) surf += (int)((surf_bits[v >> 5] >> (v & 31)) & 1u);
     }
   }
   if (surf_parts) block_count_256(surf, s_cnt, surf_parts, (blk0 + (int)blockIdx.x) & (SURF_PARTS - 1), false);
@@ -104,12 +104,12 @@ __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, i
 
 __global__ __launch_bounds__(256) void k_sample_fused(int nblocks, long long n, long long pool, unsigned long long seed,
                                                       unsigned long long stream, unsigned long long* stream_dev, int* idx,
-                                                      float4* zero_ptr, long long zero_n16, const float* weight,
+                                                      float4* zero_ptr, long long zero_n16, const unsigned int* surf_bits,
                                                       long long* surf_parts) {
   __shared__ SampleShared sm;
   const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
   for (long long z = gt; z < zero_n16; z += (long long)gridDim.x * 256) zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
-  sample_fused_block(sm, (int)blockIdx.x, nblocks, n, pool, seed, stream, stream_dev, idx, weight, surf_parts);
+  sample_fused_block(sm, (int)blockIdx.x, nblocks, n, pool, seed, stream, stream_dev, idx, surf_bits, surf_parts);
 }
 
 static size_t align256s(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -120,7 +120,7 @@ using namespace shine;
 
 static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id,
                               unsigned long long* stream_dev, int32_t* idx_out, void* zero_ptr, size_t zero_bytes,
-                              const float* weight, int64_t* surf_parts, void* workspace, size_t* workspace_bytes,
+                              const uint32_t* surf_bits, int64_t* surf_parts, void* workspace, size_t* workspace_bytes,
                               void* stream, int64_t slice_begin = 0, int64_t slice_n = -1) {
   if (slice_n < 0) slice_n = n - slice_begin;
   if (!workspace_bytes || n < 0 || pool_size < 1 || pool_size > 0x7fffffffll || slice_begin < 0 || slice_n < 0 ||
@@ -140,7 +140,7 @@ static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint6
   // pass 2 over the blocks that hold the slice (an empty slice still runs one block: it advances the device stream id)
   const long long b0 = slice_n > 0 ? slice_begin / SB : 0;
   const long long b1 = slice_n > 0 ? (slice_begin + slice_n - 1) / SB : 0;
-  if (surf_parts && !weight) return set_error(SHINE_E_INVALID, "shine_sample_sorted: surf_parts needs the pool's weights");
+  if (surf_parts && !surf_bits) return set_error(SHINE_E_INVALID, "shine_sample_sorted: surf_parts needs surf_bits");
   if (n == 0) {
     if (zero_ptr && zero_bytes) SHINE_HIP_CHECK(hipMemsetAsync(zero_ptr, 0, zero_bytes, st));
     if (surf_parts) SHINE_HIP_CHECK(hipMemsetAsync(surf_parts, 0, (size_t)SURF_PARTS * 8, st));
@@ -150,7 +150,7 @@ static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint6
   if (nblocks <= FUSED_MAX_BLOCKS && slice_begin == 0 && slice_n == n) {
     hipLaunchKernelGGL(k_sample_fused, dim3((unsigned)nblocks), dim3(256), 0, st, (int)nblocks, (long long)n,
                        (long long)pool_size, (unsigned long long)seed, (unsigned long long)stream_id, stream_dev,
-                       (int*)idx_out, (float4*)zero_ptr, zero_ptr ? (long long)(zero_bytes / 16) : 0ll, weight,
+                       (int*)idx_out, (float4*)zero_ptr, zero_ptr ? (long long)(zero_bytes / 16) : 0ll, (const unsigned int*)surf_bits,
                        (long long*)surf_parts);
     SHINE_HIP_CHECK(hipGetLastError());
     return SHINE_OK;
@@ -162,7 +162,7 @@ static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint6
   SHINE_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_sample_pass2, dim3((unsigned)(b1 - b0 + 1)), dim3(256), 0, st, bs, (int)nblocks, (long long)n,
                      (long long)pool_size, (unsigned long long)seed, (unsigned long long)stream_id, stream_dev,
-                     (int*)idx_out, (int)b0, (long long)slice_begin, (long long)slice_n, weight, (long long*)surf_parts);
+                     (int*)idx_out, (int)b0, (long long)slice_begin, (long long)slice_n, (const unsigned int*)surf_bits, (long long*)surf_parts);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }
@@ -172,23 +172,23 @@ static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint6
 // shine_sample_sorted_dev, or NULL to use stream_id.
 extern "C" int shine_sample_sorted_slice(int64_t pool_size, int64_t n, int64_t slice_begin, int64_t slice_n, uint64_t seed,
                                          uint64_t stream_id, uint64_t* stream_state, int32_t* idx_out, void* zero_ptr,
-                                         size_t zero_bytes, const float* weight, int64_t* surf_parts, void* workspace,
+                                         size_t zero_bytes, const uint32_t* surf_bits, int64_t* surf_parts, void* workspace,
                                          size_t* workspace_bytes, void* stream) {
   return sample_sorted_impl(pool_size, n, seed, stream_id, (unsigned long long*)stream_state, idx_out, zero_ptr,
-                            zero_bytes, weight, surf_parts, workspace, workspace_bytes, stream, slice_begin, slice_n);
+                            zero_bytes, surf_bits, surf_parts, workspace, workspace_bytes, stream, slice_begin, slice_n);
 }
 
 extern "C" int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,
-                                   void* zero_ptr, size_t zero_bytes, const float* weight, int64_t* surf_parts,
+                                   void* zero_ptr, size_t zero_bytes, const uint32_t* surf_bits, int64_t* surf_parts,
                                    void* workspace, size_t* workspace_bytes, void* stream) {
-  return sample_sorted_impl(pool_size, n, seed, stream_id, nullptr, idx_out, zero_ptr, zero_bytes, weight, surf_parts,
+  return sample_sorted_impl(pool_size, n, seed, stream_id, nullptr, idx_out, zero_ptr, zero_bytes, surf_bits, surf_parts,
                             workspace, workspace_bytes, stream);
 }
 
 extern "C" int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t seed, uint64_t* stream_state,
-                                       int32_t* idx_out, void* zero_ptr, size_t zero_bytes, const float* weight,
+                                       int32_t* idx_out, void* zero_ptr, size_t zero_bytes, const unsigned int* surf_bits,
                                        int64_t* surf_parts, void* workspace, size_t* workspace_bytes, void* stream) {
   if (workspace && !stream_state) return set_error(SHINE_E_INVALID, "shine_sample_sorted_dev: null stream_state");
   return sample_sorted_impl(pool_size, n, seed, 0, (unsigned long long*)stream_state, idx_out, zero_ptr, zero_bytes,
-                            weight, surf_parts, workspace, workspace_bytes, stream);
+                            surf_bits, surf_parts, workspace, workspace_bytes, stream);
 }

@@ -30,7 +30,9 @@ __device__ __forceinline__ double block_sum_256(double v, double* s_red) {
 }
 
 // Surface count of the batch (the eikonal term averages over the samples with weight > 0, shine_batch.py:183-185): the launch
-// that writes the indices also counts its draws with weight > 0 into surf_parts, int64[SHINE_SURF_PARTS = 64] partial counts
+// that writes the indices also counts its draws with weight > 0 (bit v of surf_bits: one bit per pool sample, so the 10^5-10^6
+// look-ups of a draw hit a cache-resident array instead of gathering 4-byte words from the whole pool: 24 -> 7 us for pass 2
+// at 2^20 draws from a 10^7-sample pool) into surf_parts, int64[SHINE_SURF_PARTS = 64] partial counts
 // that the fused step adds up itself (one load per lane, cfg->n_surf_parts) — no launch of its own; in torch the same number
 // costs six launches (index, compare, sum, ...: 45 us at 2^20 draws).  Two-launch form: pass 1 clears the 64 parts, block j of
 // pass 2 adds its count to part j % 64 with one relaxed atomic (<= 16-fold contention per address for 2^20 draws; ONE shared
@@ -66,7 +68,7 @@ struct SampleShared {
 
 __device__ __forceinline__ void sample_fused_block(SampleShared& sm, int vb, int nblocks, long long n, long long pool,
                                                    unsigned long long seed, unsigned long long stream,
-                                                   unsigned long long* stream_dev, int* idx, const float* weight,
+                                                   unsigned long long* stream_dev, int* idx, const unsigned int* surf_bits,
                                                    long long* surf_parts) {
   if (stream_dev) stream = stream_dev[0];
   const long long n1 = n + 1;
@@ -115,7 +117,7 @@ __device__ __forceinline__ void sample_fused_block(SampleShared& sm, int vb, int
       long long v = (long long)((sacc / total) * (double)pool);
       v = v < 0 ? 0 : (v >= pool ? pool - 1 : v);
       idx[k0 + j] = (int)v;
-      if (surf_parts) surf += weight[v] > 0.f ? 1 : 0;
+      if (surf_parts) surf += (int)((surf_bits[v >> 5] >> (v & 31)) & 1u);
     }
   }
   if (surf_parts) {

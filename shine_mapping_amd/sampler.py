@@ -50,6 +50,7 @@ class SortedPool:
         self.coord = coord[p].contiguous()
         self.sdf_label = sdf_label[p].contiguous()
         self.weight = weight[p].contiguous()
+        self._surf_bits = None
         self.slots = slots  # already in pool (= visiting) order
         self.size = int(coord.shape[0])
         self.tables_epoch = self.octree._tables_epoch
@@ -91,7 +92,7 @@ class SortedPool:
                     or surf_parts.numel() != SURF_PARTS):
                 raise ValueError("surf_parts must be a contiguous int64[%d] tensor on the pool's device "
                                  "(surf_parts_buffer())" % SURF_PARTS)
-            surf_args = (self.weight.data_ptr(), surf_parts.data_ptr())
+            surf_args = (self.surf_bits().data_ptr(), surf_parts.data_ptr())
         state = None
         if graph_safe:
             if self._stream_state is None:
@@ -125,9 +126,21 @@ class SortedPool:
         nd = _lib.NextDraw()
         nd.pool_size, nd.n, nd.seed = self.size, int(n), self.seed
         nd.stream_state, nd.idx_out = self._stream_state.data_ptr(), out.data_ptr()
-        nd.weight = self.weight.data_ptr()
+        nd.surf_bits = self.surf_bits().data_ptr() if surf_parts is not None else None
         nd.surf_parts = surf_parts.data_ptr() if surf_parts is not None else None
         return nd
+
+    def surf_bits(self):
+        """one bit per pool sample: weight > 0 (a surface sample of the eikonal term) — what the draw's surface count reads
+        instead of the weights themselves (1/32 of the bytes: cache resident).  Built on first use after a rebuild."""
+        if self._surf_bits is None:
+            pos = (self.weight > 0)
+            pad = (-pos.numel()) % 32
+            if pad:
+                pos = torch.cat([pos, pos.new_zeros(pad)])
+            w = (pos.view(-1, 32).to(torch.int64) << torch.arange(32, device=pos.device, dtype=torch.int64)).sum(dim=1)
+            self._surf_bits = torch.where(w >= (1 << 31), w - (1 << 32), w).to(torch.int32).contiguous()
+        return self._surf_bits
 
     def surf_parts_buffer(self, n=None):
         """int64[64] buffer for draw(n, surf_parts=...): the partial surface counts of a batch (SHINE_SURF_PARTS)"""

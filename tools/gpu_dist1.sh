@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r03m; O=gpurun_out/r03m
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/dist1; O=gpurun_out/dist1
 timeout 1200 python -m pytest tests -m gpu -x -q -k "own_rows or two_ranks or touched_row" > $O/pytest_subset.log 2>&1; tail -5 $O/pytest_subset.log
 for f in "" "--exchange gather --micro-batches 1"; do
   echo "== dist1 maicity $f"

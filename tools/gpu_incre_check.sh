@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r03p; O=gpurun_out/r03p
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/incre_check; O=gpurun_out/incre_check
 timeout 1200 python -m pytest tests -m gpu -x -q -k "iteration_tail or graphed or unrolled or importance or incre or regulariser" > $O/pytest_subset.log 2>&1; tail -15 $O/pytest_subset.log
 echo "== ncd-incre"; timeout 300 python bench.py --workload ncd-incre --no-cpu-baseline 2>>$O/err.log | python -c "
 import json,sys
