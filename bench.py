@@ -561,13 +561,25 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
             for f in flags:
                 f.zero_()
 
+        # The first pass of the NEXT step's draw (the block sums of its spacings: it depends on nothing but the sampler's stream
+        # id) rides on this step's reduction launch (StepOptions.next_draw), so the draw in front of a step is ONE launch
+        # (shine_sample_sorted_finish) instead of two.  The very first draw of a runner does both passes itself.
+        rider = spool.next_draw(points, surf_parts=surf_parts, n_global=n_global) if points + 1 > 16 * 1024 else None
+        opts_last = opts
+        if rider is not None:
+            import copy
+
+            opts_last = copy.copy(opts)
+            opts_last.next_draw = rider
+        primed = [False]
+
         def run_micro(idx, n_surf):
             """the rank's slice as m contiguous micro-batches: fused step (marks its rows) -> pack + all-gather; then add back"""
             loss = None
             for k in range(m):
                 a_, b_ = k * points // m, (k + 1) * points // m
-                l_, _, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool,
-                                            idx=idx[a_:b_], touched=reducer.flags)
+                l_, _, _ = fused_train_step(octree, decoder, None, None, None, opts_last if k == m - 1 else opts, n_surf=n_surf,
+                                            pool=spool, idx=idx[a_:b_], touched=reducer.flags)
                 loss = l_ if loss is None else loss + l_
                 reducer.exchange(finish=k == m - 1)
             return loss
@@ -606,7 +618,8 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
             # this rank's contiguous slice of the ONE global sorted draw (same seed / draw count on every rank): only the
             # slice's indices are generated (shine_sample_sorted_slice), so the draw does not grow with the world size
             idx = spool.draw(points, out=idx_buf, zero=reducer.flat, graph_safe=True, n_global=n_global,
-                             slice_begin=rank * points, surf_parts=surf_parts)
+                             slice_begin=rank * points, surf_parts=surf_parts, pass1_done=primed[0])
+            primed[0] = rider is not None
             # eikonal: the surface count of the batch comes out of the draw as 64 partial counts which the step's kernels add
             # up (no launch of its own); data parallel: the global count = sum of the parts + an 8-byte all-reduce
             n_surf = surf_parts
@@ -615,7 +628,7 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
                 reducer.all_reduce_scalar(n_surf)
             if use_dist and kind == "gather":
                 return run_micro(idx, n_surf)
-            loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx)
+            loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts_last, n_surf=n_surf, pool=spool, idx=idx)
             if use_dist:
                 if kind == "touched":
                     shine_dp.mark_touched(octree, spool, idx, flags)  # this rank's rows ...
@@ -647,8 +660,9 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
                     with torch.cuda.graph(graph_u):
                         for _ in range(U):
                             loss_u = step_body()
-                launch = "hipgraph, %d step%s per replay, fresh batch per step%s" % (
-                    U, "s" if U > 1 else "", " (collectives captured)" if use_dist else "")
+                launch = "hipgraph, %d step%s per replay, fresh batch per step%s%s" % (
+                    U, "s" if U > 1 else "", " (collectives captured)" if use_dist else "",
+                    ", first pass of the next draw on the step's reduction launch" if rider is not None else "")
             except Exception as e:  # capture not possible on this stack: measure eagerly and say so
                 print("graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
                 graph_u = graph_1 = None

@@ -45,6 +45,21 @@ extern "C" {
 
 typedef struct shine_tables shine_tables; /* opaque: device hash tables node-morton -> 8 corner ids */
 
+/* a sorted draw of the NEXT iteration handed to a call of THIS iteration, so that it costs no launch (or one launch less) of
+ * its own: what shine_sample_sorted_dev(pool_size, n, seed, stream_state, idx_out, NULL, 0, surf_bits, surf_parts, ...) would
+ * launch.  Taken by shine_finish_iteration (whole draw, n < 16 K) and by shine_step_config.next_draw (pass 1 of a large draw). */
+#define SHINE_SURF_PARTS 64
+typedef struct shine_next_draw {
+  int64_t pool_size, n;
+  uint64_t seed;
+  uint64_t* stream_state;  /* device uint64[4], as shine_sample_sorted_dev */
+  int32_t* idx_out;        /* [n] */
+  const uint32_t* surf_bits; /* with surf_parts: one bit per pool sample, weight > 0 */
+  int64_t* surf_parts;     /* int64[SHINE_SURF_PARTS] or NULL */
+  void* workspace;         /* the draw's workspace (shine_sample_sorted_* with workspace == NULL sizes it): used by
+                              shine_step_config.next_draw only */
+} shine_next_draw;
+
 /* scalar configuration of one hot-path call (plain-old-data, passed by pointer from the host) */
 typedef struct shine_step_config {
   int32_t n_levels;        /* L = tree_level_feat                      (utils/config.py:78)  */
@@ -76,6 +91,10 @@ typedef struct shine_step_config {
   double* zero_f64;        /* one device double cleared by the step (shine_regularize's accumulator: out_zeroed = 1 there) */
   int32_t n_surf_parts;    /* shine_train_step's n_surf points at this many (<= 64) int64 partial counts which the kernels add up
                               (what shine_sample_sorted_* writes to surf_parts); 0 / 1 = one count */
+  const shine_next_draw* next_draw; /* host pointer or NULL: pass 1 of the NEXT large sorted draw (the block sums of its spacings:
+                              n, seed, stream_state, surf_parts and workspace of the record are used) rides on this step's
+                              reduction launch; that draw is then completed by shine_sample_sorted_finish (one launch
+                              instead of two).  Ignored with defer_reduce. */
   int32_t defer_reduce;    /* 1: shine_train_step launches the fused kernel ONLY and leaves its per-workgroup partial sums
                               (decoder grads, trash-row grads, loss terms) in the workspace: shine_finish_iteration consumes
                               them in the optimiser's launch.  loss_parts is then written by that call, and adam_state /
@@ -283,7 +302,6 @@ int shine_plan_batch(const shine_tables* t, const shine_step_config* cfg, const 
  *      samples the eikonal term averages over (shine_batch.py:183-185) — as 64 partial counts (overwritten): hand them to
  *      shine_train_step as n_surf with cfg->n_surf_parts = SHINE_SURF_PARTS.  workspace == NULL returns the required
  *      bytes. --------------------------------------------------------------------------------------------------------- */
-#define SHINE_SURF_PARTS 64
 int shine_sample_sorted(int64_t pool_size, int64_t n, uint64_t seed, uint64_t stream_id, int32_t* idx_out,
                         void* zero_ptr, size_t zero_bytes, const uint32_t* surf_bits, int64_t* surf_parts, void* workspace,
                         size_t* workspace_bytes, void* stream);
@@ -296,6 +314,14 @@ int shine_sample_sorted_slice(int64_t pool_size, int64_t n, int64_t slice_begin,
                               uint64_t stream_id, uint64_t* stream_state, int32_t* idx_out, void* zero_ptr,
                               size_t zero_bytes, const uint32_t* surf_bits, int64_t* surf_parts, void* workspace,
                               size_t* workspace_bytes, void* stream);
+/* the second half of a graph-replayable draw whose pass 1 rode on the previous shine_train_step (cfg->next_draw): ONE launch
+ * (index writing, surface count, ride-along clear); arguments as shine_sample_sorted_slice with a device stream state.  Valid
+ * ONLY as the first use of that stream state after such a step, for the same n (the workspace then holds this draw's block
+ * sums and the state's shadow word names it); anything else must use shine_sample_sorted_dev / _slice. */
+int shine_sample_sorted_finish(int64_t pool_size, int64_t n, int64_t slice_begin, int64_t slice_n, uint64_t seed,
+                               uint64_t* stream_state, int32_t* idx_out, void* zero_ptr, size_t zero_bytes,
+                               const uint32_t* surf_bits, int64_t* surf_parts, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* ---- data-parallel exchange of the rows a step touched (the reference is single-GPU: no counterpart).
  *      flags[l]: uint8 [rows[l]] from shine_mark_touched (OR-reduced over the ranks), rows[l] = the level's row count
@@ -373,15 +399,7 @@ int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* g
  *      tables when the decoder is frozen).  next_draw (optional): the sorted draw of the NEXT iteration — what
  *      shine_sample_sorted_dev(pool_size, n, seed, stream_state, idx_out, NULL, 0, surf_bits, surf_parts, ...) would launch, for
  *      n < 16 K draws — done by a few extra blocks of this launch (the fused kernel is done with the index buffer by then),
- *      so an iteration at the reference's batch size is {fused step, this}: two launches. */
-typedef struct shine_next_draw {
-  int64_t pool_size, n;
-  uint64_t seed;
-  uint64_t* stream_state;  /* device uint64[4], as shine_sample_sorted_dev */
-  int32_t* idx_out;        /* [n] */
-  const uint32_t* surf_bits; /* with surf_parts: one bit per pool sample, weight > 0 */
-  int64_t* surf_parts;     /* int64[SHINE_SURF_PARTS] or NULL */
-} shine_next_draw;
+ *      so an iteration at the reference's batch size is {fused step, this}: two launches (shine_next_draw: above). */
 int shine_finish_iteration(const shine_step_config* cfg, int64_t n, const void* workspace, const int64_t* n_surf,
                            double* loss_parts, const float* const* feats_last, const float* const* importance,
                            unsigned char* const* touched, const int32_t* grad_on, float lambda_forget, double* reg_out,

@@ -18,6 +18,11 @@ HIDDEN_DIM = 32
 MLP_PARAMS = 1377
 
 
+class NextDraw(C.Structure):  # include/shine_hip.h shine_next_draw
+    _fields_ = [("pool_size", C.c_int64), ("n", C.c_int64), ("seed", C.c_uint64), ("stream_state", C.c_void_p),
+                ("idx_out", C.c_void_p), ("surf_bits", C.c_void_p), ("surf_parts", C.c_void_p), ("workspace", C.c_void_p)]
+
+
 class StepConfig(C.Structure):
     """struct shine_step_config (include/shine_hip.h)."""
 
@@ -42,13 +47,9 @@ class StepConfig(C.Structure):
         ("adam_beta2", C.c_float),
         ("zero_f64", C.c_void_p),
         ("n_surf_parts", C.c_int32),
+        ("next_draw", C.POINTER(NextDraw)),
         ("defer_reduce", C.c_int32),
     ]
-
-
-class NextDraw(C.Structure):  # include/shine_hip.h shine_next_draw
-    _fields_ = [("pool_size", C.c_int64), ("n", C.c_int64), ("seed", C.c_uint64), ("stream_state", C.c_void_p),
-                ("idx_out", C.c_void_p), ("surf_bits", C.c_void_p), ("surf_parts", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -105,6 +106,8 @@ _SIGNATURES = {
                   C.POINTER(C.c_int32), C.c_float, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                   C.POINTER(C.c_int64), _P, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _P,
                   C.POINTER(NextDraw), _P]),
+    "shine_sample_sorted_finish": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, _P, _P, _P, C.c_size_t, _P,
+                                             _P, _P, C.c_size_t, _P]),
     "shine_sample_sorted_dev": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, _P, _P, _P, C.c_size_t, _P, _P, _P,
                                           C.POINTER(C.c_size_t), _P]),
     "shine_sample_sorted_slice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, _P,

@@ -1097,7 +1097,7 @@ extern "C" int shine_train_step_v5(const shine_tables* t, const shine_step_confi
   }
   SHINE_HIP_CHECK(hipGetLastError());
   if (!(a.ablate & 32)) {  // (ablate bit 32: measurement only — time the dominant kernel by itself)
-    hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks, Pass1Args{});
     SHINE_HIP_CHECK(hipGetLastError());
   }
   return SHINE_OK;

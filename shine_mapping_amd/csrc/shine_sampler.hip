@@ -48,16 +48,25 @@ __global__ __launch_bounds__(256) void k_sample_pass1(double* block_sum, long lo
 // [lo, lo + cnt): the part of the n sorted draws this launch writes (idx[k - lo]); block b of the launch is block
 // blk0 + b of the whole draw.  A data-parallel rank draws only its contiguous slice of the GLOBAL batch this way: pass 1
 // still covers all n + 1 spacings (compute only), pass 2 only the slice's blocks.
+// FINISH = the second half of a draw whose pass 1 ran inside the previous fused step's reduction launch (cfg->next_draw): the
+// same kernel, plus the ride-along clear of the gradient bucket that pass 1 does in the two-launch form.  (It trusts the block
+// sums: the caller guarantees the rider ran for this draw — SortedPool.draw(pass1_done=True) checks it on the host.)
+template <bool FINISH>
 __global__ __launch_bounds__(256) void k_sample_pass2(const double* block_sum, int nblocks, long long n, long long pool,
                                                       unsigned long long seed, unsigned long long stream,
                                                       unsigned long long* stream_dev, int* idx, int blk0, long long lo,
-                                                      long long cnt, const unsigned int* surf_bits, long long* surf_parts) {
+                                                      long long cnt, const unsigned int* surf_bits, long long* surf_parts,
+                                                      float4* zero_ptr, long long zero_n16) {
   __shared__ double s_red[4];
   __shared__ double s_wave_pre[4];
   __shared__ int s_cnt[4];
   if (stream_dev) {
     stream = stream_dev[2] - 1ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) stream_dev[0] = stream + 1ull;
+  }
+  if (FINISH) {
+    for (long long z = (long long)blockIdx.x * 256 + threadIdx.x; z < zero_n16; z += (long long)gridDim.x * 256)
+      zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // prefix of the blocks in front of this one, and the grand total (nblocks is a few hundred)
   double before = 0.0, total = 0.0;
@@ -160,9 +169,10 @@ static int sample_sorted_impl(int64_t pool_size, int64_t n, uint64_t seed, uint6
                      (unsigned long long)stream_id, (const unsigned long long*)stream_dev, (float4*)zero_ptr,
                      zero_ptr ? (long long)(zero_bytes / 16) : 0ll, (long long*)surf_parts);
   SHINE_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_sample_pass2, dim3((unsigned)(b1 - b0 + 1)), dim3(256), 0, st, bs, (int)nblocks, (long long)n,
+  hipLaunchKernelGGL(k_sample_pass2<false>, dim3((unsigned)(b1 - b0 + 1)), dim3(256), 0, st, bs, (int)nblocks, (long long)n,
                      (long long)pool_size, (unsigned long long)seed, (unsigned long long)stream_id, stream_dev,
-                     (int*)idx_out, (int)b0, (long long)slice_begin, (long long)slice_n, (const unsigned int*)surf_bits, (long long*)surf_parts);
+                     (int*)idx_out, (int)b0, (long long)slice_begin, (long long)slice_n, (const unsigned int*)surf_bits, (long long*)surf_parts,
+                     (float4*)nullptr, 0ll);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }
@@ -191,4 +201,29 @@ extern "C" int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t se
   if (workspace && !stream_state) return set_error(SHINE_E_INVALID, "shine_sample_sorted_dev: null stream_state");
   return sample_sorted_impl(pool_size, n, seed, 0, (unsigned long long*)stream_state, idx_out, zero_ptr, zero_bytes,
                             surf_bits, surf_parts, workspace, workspace_bytes, stream);
+}
+
+// The second half of a graph-replayable draw whose pass 1 rode on the previous shine_train_step (cfg->next_draw): ONE launch
+// (index writing + surface count + the ride-along clear).  ONLY valid directly after such a step for the same draw size.
+extern "C" int shine_sample_sorted_finish(int64_t pool_size, int64_t n, int64_t slice_begin, int64_t slice_n, uint64_t seed,
+                                          uint64_t* stream_state, int32_t* idx_out, void* zero_ptr, size_t zero_bytes,
+                                          const uint32_t* surf_bits, int64_t* surf_parts, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  if (slice_n < 0) slice_n = n - slice_begin;
+  const long long nblocks = ((long long)n + 1 + SB - 1) / SB;
+  if (n < 1 || pool_size < 1 || pool_size > 0x7fffffffll || slice_begin < 0 || slice_n < 0 || slice_begin + slice_n > n ||
+      !stream_state || !idx_out || !workspace || workspace_bytes < (size_t)nblocks * sizeof(double) ||
+      (surf_parts && !surf_bits))
+    return set_error(SHINE_E_INVALID, "shine_sample_sorted_finish: bad argument (n >= 1, device stream state, the draw's workspace)");
+  if (zero_ptr && (((size_t)zero_ptr | zero_bytes) & 15))
+    return set_error(SHINE_E_INVALID, "shine_sample_sorted_finish: zero buffer must be 16-byte aligned and sized");
+  const long long b0 = slice_n > 0 ? slice_begin / SB : 0;
+  const long long b1 = slice_n > 0 ? (slice_begin + slice_n - 1) / SB : 0;
+  hipLaunchKernelGGL(k_sample_pass2<true>, dim3((unsigned)(b1 - b0 + 1)), dim3(256), 0, (hipStream_t)stream,
+                     (const double*)workspace, (int)nblocks, (long long)n, (long long)pool_size, (unsigned long long)seed, 0ull,
+                     (unsigned long long*)stream_state, (int*)idx_out, (int)b0, (long long)slice_begin, (long long)slice_n,
+                     (const unsigned int*)surf_bits, (long long*)surf_parts, (float4*)zero_ptr,
+                     zero_ptr ? (long long)(zero_bytes / 16) : 0ll);
+  SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
 }

@@ -108,7 +108,18 @@ extern long long* g_prof_buffer;
 
 // second stage of a fused step (shine_step_support.hip): add `nblocks` per-workgroup partial vectors [PART_STRIDE floats each]
 // into the gradient tensors / loss, re-zero the trash rows (set_zero, model/feature_octree.py:78-81)
-__global__ void k_reduce_partials(V1Args a, int nblocks);
+// cfg->next_draw: pass 1 of the NEXT sorted draw (two-launch form of the sampler: the block sums of its Exp(1) spacings) rides
+// on this launch as extra blocks — it depends on nothing but the sampler's stream id
+struct Pass1Args {
+  double* block_sum;             // null: off
+  long long n1;                  // n + 1 spacings
+  unsigned long long seed;
+  unsigned long long* stream_dev;
+  long long* surf_parts;         // cleared here (pass 2 adds to them) or null
+  int nblocks;                   // sampler blocks of 1024 draws
+};
+__global__ void k_reduce_partials(V1Args a, int nblocks, Pass1Args p1);
+int fill_pass1_args(Pass1Args* p1, const shine_step_config* cfg);  // shine_step_support.hip
 __global__ void k_mark_touched(V1Args a);
 
 // host: fill everything of V1Args that does not depend on the launch geometry (argument checks included)

@@ -1,6 +1,7 @@
 // shine_step_support.hip — what surrounds the fused-step kernel (shine_step_v3.hip) in a step: the second stage that adds up
 // the per-workgroup partial vectors, the touched-row marking pass, workspace sizing / launch facts for bench.py, and the
 // MFMA lane-map self-test the GPU suite pins the operand layouts with.
+#include "shine_sampler_dev.hpp"
 #include "shine_tile16.hpp"
 
 namespace shine {
@@ -43,9 +44,32 @@ __global__ __launch_bounds__(256) void k_mark_touched(V1Args a) {
 
 // second stage: add the per-workgroup partial vectors into the gradient tensors / loss.
 // One 1024-thread block per 64 entries: lane = entry (coalesced 256-B rows), the 16 waves split the blocks.
-__global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks) {
+__global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks, Pass1Args p1) {
   __shared__ float s_red[16][64];
   __shared__ double s_dred[16][3];
+  constexpr int RB = (PART_FLOATS + 63) / 64;  // blocks of the reduction proper
+  if ((int)blockIdx.x >= RB) {
+    // pass 1 of the next sorted draw (k_sample_pass1's arithmetic and summation order: the draw is bit-identical to the
+    // stand-alone form): each 256-thread quarter of this block is one sampler block of 1024 draws
+    __shared__ double s_p1[16];
+    const unsigned long long stream = p1.stream_dev[0];
+    const int vb = ((int)blockIdx.x - RB) * 4 + (int)(threadIdx.x >> 8), t256 = threadIdx.x & 255;
+    if (vb == 0 && t256 == 0) p1.stream_dev[2] = stream + 1ull;
+    if (vb == 0 && p1.surf_parts && t256 < SURF_PARTS) p1.surf_parts[t256] = 0;
+    const long long k0 = (long long)vb * SB + t256 * 4;
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (vb < p1.nblocks && k0 + j < p1.n1) v += exp1v(p1.seed, stream, (unsigned long long)(k0 + j));
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) s_p1[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (t256 == 0 && vb < p1.nblocks) {
+      const int w = (int)(threadIdx.x >> 6);
+      p1.block_sum[vb] = s_p1[w] + s_p1[w + 1] + s_p1[w + 2] + s_p1[w + 3];
+    }
+    return;
+  }
   __shared__ long long s_ns;  // the batch's surface count (eikonal): the sum of the <= 64 parts of cfg->n_surf_parts
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
@@ -149,7 +173,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks)
   // iteration hooks (include/shine_hip.h, shine_step_config): scalar housekeeping of the launches that FOLLOW the step rides
   // here — the optimiser's step count + bias corrections, the regulariser's accumulator — one thread each, in a block that
   // has little else to do
-  if (blockIdx.x == gridDim.x - 1) {
+  if (blockIdx.x == RB - 1) {
     if (threadIdx.x == 0 && a.adam_state) adam_advance(a.adam_state, a.adam_b1, a.adam_b2);
     if (threadIdx.x == 64 && a.zero_f64) *a.zero_f64 = 0.0;
   }
@@ -165,6 +189,23 @@ __global__ void k_selftest_mfma16(const float* A, const float* B, float* D) {
 }
 
 long long* g_prof_buffer = nullptr;
+
+// host: cfg->next_draw -> the pass-1 rider of the reduction launch
+int fill_pass1_args(Pass1Args* p1, const shine_step_config* cfg) {
+  *p1 = Pass1Args{};
+  const shine_next_draw* d = cfg->next_draw;
+  if (!d) return SHINE_OK;
+  const long long nb = (d->n + 1 + SB - 1) / SB;
+  if (d->n < 1 || !d->stream_state || !d->workspace || nb > 0x3fffff)
+    return set_error(SHINE_E_INVALID, "shine_train_step: next_draw wants n >= 1, a device stream state and the draw's workspace");
+  p1->block_sum = reinterpret_cast<double*>(d->workspace);
+  p1->n1 = d->n + 1;
+  p1->seed = d->seed;
+  p1->stream_dev = reinterpret_cast<unsigned long long*>(d->stream_state);
+  p1->surf_parts = reinterpret_cast<long long*>(d->surf_parts);
+  p1->nblocks = (int)nb;
+  return SHINE_OK;
+}
 
 }  // namespace shine
 

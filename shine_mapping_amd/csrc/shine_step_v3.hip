@@ -1063,7 +1063,11 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
   }
   SHINE_HIP_CHECK(hipGetLastError());
   if (!(a.ablate & 32) && !a.defer_reduce) {  // (ablate bit 32: measurement only — time the dominant kernel by itself)
-    hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks);
+    Pass1Args p1;  // cfg->next_draw: pass 1 of the next sorted draw as extra blocks of this launch (4 sampler blocks each)
+    rc = fill_pass1_args(&p1, cfg);
+    if (rc != SHINE_OK) return rc;
+    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((PART_FLOATS + 63) / 64 + (p1.nblocks + 3) / 4)), dim3(1024), 0, st, a,
+                       (int)g.blocks, p1);
     SHINE_HIP_CHECK(hipGetLastError());
   }
   return SHINE_OK;
@@ -1106,7 +1110,7 @@ extern "C" int shine_interp_sdf_backward(const shine_tables* t, const shine_step
     default: launch_v3_ext<4>(a, g, st); break;
   }
   SHINE_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks, Pass1Args{});
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }

@@ -37,6 +37,8 @@ class StepOptions:
     adam_state: Optional[torch.Tensor] = None   # FusedAdam's device step state: the step counts the optimiser step
     adam_betas: tuple = (0.9, 0.99)
     zero_f64: Optional[torch.Tensor] = None     # one float64 element cleared by the step (the regulariser's accumulator)
+    next_draw: Optional[object] = None          # SortedPool.next_draw(...): the first pass of the NEXT large sorted draw rides on
+                                                # the step's reduction launch; complete it with pool.draw(..., pass1_done=True)
     kernel_variant: int = 0           # 0 the fused step; tests / tools: 1 the lane-per-point reference kernel, 5 the
                                       # role-specialised experimental kernel (both in libshine_check.so)
 
@@ -187,6 +189,8 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         cfg.adam_beta1, cfg.adam_beta2 = float(opts.adam_betas[0]), float(opts.adam_betas[1])
     if opts.zero_f64 is not None:
         cfg.zero_f64 = opts.zero_f64.data_ptr()
+    if opts.next_draw is not None:
+        cfg.next_draw = C.pointer(opts.next_draw)
     if eik and n_surf is None:
         n_surf = (weight > 0).sum()  # stays on the device; under DP the caller all-reduces it first
     if eik and n_surf.numel() > 1:  # the sampler's per-block partial counts (SortedPool.draw(surf_parts=...))
@@ -237,6 +241,8 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         ),
         "shine_train_step",
     )
+    if opts.next_draw is not None and pending is None and getattr(opts.next_draw, "_pool", None) is not None:
+        opts.next_draw._pool._rider_for = int(opts.next_draw.n)  # its reduction launch carried that draw's first pass
     return loss_parts[3], pred, gx  # 0-dim float64 view: BCE (+ weight_e * eikonal), no extra launch
 
 

@@ -39,6 +39,7 @@ class SortedPool:
         self.draws = 0
         self._ws = {}  # per batch size, never replaced: captured HIP graphs bake the address in
         self._stream_state = None  # device uint64[4] for graph-replayable draws (loop.GraphedIteration)
+        self._rider_for = None     # size of the draw whose first pass the last fused step carried (StepOptions.next_draw)
         self.rebuild(coord, sdf_label, weight)
 
     def rebuild(self, coord, sdf_label, weight):
@@ -59,7 +60,8 @@ class SortedPool:
         for k in [k for k in self._ws if k[1] != self.size]:
             del self._ws[k]
 
-    def draw(self, n, out=None, zero=None, graph_safe=False, n_global=None, slice_begin=0, surf_parts=None):
+    def draw(self, n, out=None, zero=None, graph_safe=False, n_global=None, slice_begin=0, surf_parts=None,
+             pass1_done=False):
         """n sorted i.i.d. uniform sample indices (int32, device).  `zero`: optional contiguous float tensor cleared in
         the same pass (the flat gradient bucket, i.e. opt.zero_grad()).  `graph_safe`: the stream id is read from (and
         advanced in) device memory, so a captured HIP graph of this call draws a fresh batch at every replay.
@@ -68,12 +70,21 @@ class SortedPool:
         slice of the node-ordered global batch without generating the other ranks' indices.
         `surf_parts` (surf_parts_buffer()): the launches that write the indices also count the drawn samples with weight > 0
         (the eikonal term's surface samples, shine_batch.py:183-185) into it, as 64 partial counts — pass the tensor to
-        fused_train_step as n_surf (the kernels add the parts up); in torch the count costs six launches."""
+        fused_train_step as n_surf (the kernels add the parts up); in torch the count costs six launches.
+        `pass1_done` (graph_safe draws of >= 16 K): the previous fused step carried this draw's first pass on its reduction
+        launch (StepOptions.next_draw = pool.next_draw(...)), so the draw is ONE launch (shine_sample_sorted_finish).  Honoured
+        only if that step really was the last user of the pool's device stream state (tracked on the host) — otherwise both
+        passes run.  A captured graph of {draw(pass1_done=True), step with the rider} must not be interleaved with other
+        graph_safe draws of the same pool between replays."""
         dev = self.coord.device
         lib = _lib.lib()
         stream = _lib.current_stream_handle()
         sliced = n_global is not None and (int(n_global) != n or slice_begin)
         nd = int(n_global) if sliced else n  # the draw whose spacings pass 1 sums
+        # the one-launch completion is valid only if the LAST thing this pool's device stream state saw was a fused step that
+        # carried the first pass of exactly this draw (ops marks the pool when it launches one); otherwise both passes run
+        pass1_done = bool(pass1_done and graph_safe and self._rider_for == nd)
+        self._rider_for = None
         ws = self._ws.get((nd, self.size))
         none13 = (None, None)
         if ws is None:
@@ -98,6 +109,11 @@ class SortedPool:
             if self._stream_state is None:
                 self._stream_state = torch.tensor([self.draws, 0, self.draws, 0], dtype=torch.int64, device=dev)
             state = self._stream_state.data_ptr()
+        if pass1_done:
+            _lib.check(lib.shine_sample_sorted_finish(self.size, nd, int(slice_begin) if sliced else 0, n, self.seed, state,
+                                                      idx.data_ptr(), *zero_args, *surf_args, ws[0].data_ptr(), ws[2], stream),
+                       "shine_sample_sorted_finish")
+            return idx
         if sliced:
             _lib.check(lib.shine_sample_sorted_slice(self.size, nd, int(slice_begin), n, self.seed, self.draws, state,
                                                      idx.data_ptr(), *zero_args, *surf_args, ws[0].data_ptr(),
@@ -112,11 +128,24 @@ class SortedPool:
             self.draws += 1
         return idx
 
-    def next_draw(self, n, out, surf_parts=None):
-        """The graph-replayable draw(n, out=out, surf_parts=...) as a shine_next_draw record for
-        FusedAdam.finish_iteration(next_draw=...): the optimiser's launch then draws the NEXT iteration's batch in a few extra
-        blocks (n < 16 K).  Keeps the device stream state of graph_safe draws."""
+    def next_draw(self, n, out=None, surf_parts=None, n_global=None):
+        """The graph-replayable draw(n, out=out, surf_parts=...) as a shine_next_draw record, for
+          * FusedAdam.finish_iteration(next_draw=...): the optimiser's launch draws the NEXT iteration's batch in a few extra
+            blocks (n < 16 K; `out` required);
+          * StepOptions.next_draw: the fused step's reduction launch carries the first pass of the NEXT large draw (n_global:
+            the size of the global draw when this rank draws a slice of it), which draw(..., pass1_done=True) completes.
+        Keeps the device stream state of graph_safe draws."""
         dev = self.coord.device
+        nsp = int(n_global) if n_global is not None else int(n)
+        ws = self._ws.get((nsp, self.size))
+        if ws is None:
+            need = C.c_size_t(0)
+            _lib.check(_lib.lib().shine_sample_sorted(self.size, nsp, self.seed, 0, None, None, 0, None, None, None,
+                                                      C.byref(need), _lib.current_stream_handle()), "shine_sample_sorted")
+            ws = (torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev), nsp, int(need.value))
+            self._ws[(nsp, self.size)] = ws
+        if out is None:
+            out = torch.empty(int(n), dtype=torch.int32, device=dev)  # (the step's rider does not write indices)
         if self._stream_state is None:
             self._stream_state = torch.tensor([self.draws, 0, self.draws, 0], dtype=torch.int64, device=dev)
         if not (out.is_cuda and out.dtype == torch.int32 and out.is_contiguous() and out.numel() == int(n)):
@@ -124,7 +153,9 @@ class SortedPool:
         if surf_parts is not None and (surf_parts.dtype != torch.int64 or surf_parts.numel() != SURF_PARTS):
             raise ValueError("next_draw: surf_parts must be surf_parts_buffer()")
         nd = _lib.NextDraw()
-        nd.pool_size, nd.n, nd.seed = self.size, int(n), self.seed
+        nd._pool = self  # (ops marks the pool when a step carries this record)
+        nd.pool_size, nd.n, nd.seed = self.size, nsp, self.seed
+        nd.workspace = ws[0].data_ptr()
         nd.stream_state, nd.idx_out = self._stream_state.data_ptr(), out.data_ptr()
         nd.surf_bits = self.surf_bits().data_ptr() if surf_parts is not None else None
         nd.surf_parts = surf_parts.data_ptr() if surf_parts is not None else None

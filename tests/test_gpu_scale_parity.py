@@ -920,3 +920,62 @@ def test_the_iteration_tail_as_one_launch_equals_the_three_launches(mode):
     for k, (x, y) in enumerate(zip(a[4], b[4])):  # the trash rows: zeroed before their update in both forms
         frac = float(((x - y).abs() > 1e-6 * float(y.abs().max())).float().mean())
         assert frac <= 0.02, "parameters of tensor %d: %.4f of the elements differ" % (k, frac)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,world", [(16 * 1024, 1), ((1 << 18) + 37, 1), (100003, 4)])
+def test_first_pass_of_the_next_draw_rides_on_the_step(n, world):
+    """StepOptions.next_draw: the fused step's reduction launch carries pass 1 of the NEXT sorted draw (extra blocks), and
+    draw(..., pass1_done=True) completes it in one launch (shine_sample_sorted_finish).  The batches must be bit-identical to
+    the two-launch graph-replayable draw — whole draws and a data-parallel rank's slice, with the surface count — and
+    pass1_done=True without a rider in front of it (the pool tracks that on the host) must fall back to both passes."""
+    import copy
+
+    from shine_mapping_amd import StepOptions, fused_train_step
+    from shine_mapping_amd.sampler import SortedPool
+
+    fx = load_golden("kitti_eik_L3")
+
+    def make():
+        cfg, octree, dec = product_from_golden(fx)
+        dec = dec.cuda()
+        octree._require_tables(with_ranks=True)
+        sp = SortedPool(octree, fx["coord"].cuda().repeat(40, 1), fx["sdf_label"].cuda().repeat(40), fx["weight"].cuda().repeat(40),
+                        seed=11, canonical=True)
+        for p in list(octree.hier_features) + dec.fused_params():
+            p.grad = torch.zeros_like(p)
+        return octree, dec, sp, StepOptions(sigma=fx["sigma"], ekional_loss_on=True, weight_e=0.1)
+
+    per = n // world
+    lo = (world - 1) * per if world > 1 else 0  # the last rank's slice
+    kw = dict(n_global=n, slice_begin=lo) if world > 1 else {}
+    K = 4
+    # reference: the two-launch graph-replayable draw
+    o1, d1, p1, s1 = make()
+    parts1 = p1.surf_parts_buffer()
+    want = []
+    for _ in range(K):
+        idx = p1.draw(per, graph_safe=True, surf_parts=parts1, **kw)
+        want.append((idx.clone(), int(parts1.sum())))
+        fused_train_step(o1, d1, None, None, None, s1, n_surf=parts1, pool=p1, idx=idx)
+    # rider: the first draw does both passes, every later one is completed by one launch
+    o2, d2, p2, s2 = make()
+    parts2 = p2.surf_parts_buffer()
+    s2r = copy.copy(s2)
+    s2r.next_draw = p2.next_draw(per, surf_parts=parts2, n_global=n if world > 1 else None)
+    grad_probe = torch.ones(1024, device="cuda")
+    for k in range(K):
+        idx = p2.draw(per, graph_safe=True, surf_parts=parts2, pass1_done=k > 0, zero=grad_probe if k == 2 else None, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(idx, want[k][0]) and int(parts2.sum()) == want[k][1], "draw %d" % k
+        loss2, _, _ = fused_train_step(o2, d2, None, None, None, s2r, n_surf=parts2, pool=p2, idx=idx)
+    assert float(grad_probe.abs().max()) == 0.0  # the finish launch carries the ride-along clear
+    assert torch.isfinite(loss2)
+    # another draw of the pool came in between (its sums are gone): pass1_done=True must notice and run both passes
+    fused_train_step(o2, d2, None, None, None, s2, n_surf=parts2, pool=p2, idx=idx)  # (overwrites nothing of the sampler)
+    p2.draw(3000, graph_safe=True)                                                     # a different draw in between: stale sums
+    p1.draw(3000, graph_safe=True)
+    want_after = p1.draw(per, graph_safe=True, **kw).clone()
+    got_after = p2.draw(per, graph_safe=True, pass1_done=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got_after, want_after) and not torch.equal(want_after, want[K - 1][0])
