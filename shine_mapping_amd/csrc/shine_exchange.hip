@@ -10,16 +10,9 @@
 // values, fixed capacity, counts stay on the device) and the ranks all-gather their messages — one collective, no host read,
 // capturable in a HIP graph, half the bytes of an all-reduce of the union.
 #include <cstring>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
-
 #include "shine_internal.hpp"
 
 namespace shine {
-
-struct FlagToInt {
-  __host__ __device__ int operator()(unsigned char f) const { return f ? 1 : 0; }
-};
 
 __global__ void k_touched_compact(const unsigned char* flags, const int* pos, long long n, int* idx_out,
                                   long long* count_out) {
@@ -79,9 +72,7 @@ extern "C" int shine_touched_index(int32_t n_levels, const uint8_t* const* flags
   long long max_rows = 0;
   for (int l = 0; l < n_levels; ++l) max_rows = rows[l] > max_rows ? rows[l] : max_rows;
   size_t scan_bytes = 0;
-  auto it0 = rocprim::make_transform_iterator((const unsigned char*)nullptr, FlagToInt());
-  SHINE_HIP_CHECK(rocprim::exclusive_scan(nullptr, scan_bytes, it0, (int*)nullptr, 0, (size_t)(max_rows > 0 ? max_rows : 1),
-                                          rocprim::plus<int>(), st));
+  SHINE_HIP_CHECK(prim_scan_flags(nullptr, scan_bytes, nullptr, nullptr, (size_t)(max_rows > 0 ? max_rows : 1), st));
   const size_t need = xalign(scan_bytes) + xalign((size_t)max_rows * sizeof(int));
   if (!workspace) {
     *workspace_bytes = need;
@@ -97,9 +88,8 @@ extern "C" int shine_touched_index(int32_t n_levels, const uint8_t* const* flags
       SHINE_HIP_CHECK(hipMemsetAsync(counts_dev + l, 0, sizeof(int64_t), st));
       continue;
     }
-    auto it = rocprim::make_transform_iterator((const unsigned char*)flags[l], FlagToInt());
     size_t sb = scan_bytes;
-    SHINE_HIP_CHECK(rocprim::exclusive_scan(tmp, sb, it, pos, 0, (size_t)n, rocprim::plus<int>(), st));
+    SHINE_HIP_CHECK(prim_scan_flags(tmp, sb, (const unsigned char*)flags[l], pos, (size_t)n, st));
     hipLaunchKernelGGL(k_touched_compact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                        (const unsigned char*)flags[l], (const int*)pos, n, (int*)idx_out[l], (long long*)(counts_dev + l));
     SHINE_HIP_CHECK(hipGetLastError());
@@ -158,10 +148,6 @@ extern "C" int shine_touched_unpack(int32_t n_levels, float* const* grads, const
 namespace shine {
 
 constexpr int ROWS_HDR = 4;  // message header words: count, overflow, reserved x 2
-
-struct FlagByteToInt {
-  __host__ __device__ int operator()(unsigned char f) const { return f ? 1 : 0; }
-};
 
 // one thread per row: the flagged rows move into the message (ids ascending = scan order)
 struct KeepRows {
@@ -242,8 +228,7 @@ extern "C" int shine_rows_pack(uint8_t* flags, int64_t n_rows, const int64_t* ke
     return set_error(SHINE_E_INVALID, "shine_rows_pack: bad argument");
   hipStream_t st = (hipStream_t)stream;
   size_t scan_bytes = 0;
-  auto it0 = rocprim::make_transform_iterator((const unsigned char*)nullptr, FlagByteToInt());
-  SHINE_HIP_CHECK(rocprim::exclusive_scan(nullptr, scan_bytes, it0, (int*)nullptr, 0, (size_t)n_rows, rocprim::plus<int>(), st));
+  SHINE_HIP_CHECK(prim_scan_flags(nullptr, scan_bytes, nullptr, nullptr, (size_t)n_rows, st));
   const size_t need = xalign(scan_bytes) + xalign((size_t)n_rows * sizeof(int));
   if (!workspace) {
     *workspace_bytes = need;
@@ -255,9 +240,8 @@ extern "C" int shine_rows_pack(uint8_t* flags, int64_t n_rows, const int64_t* ke
   if (cap & 3) return set_error(SHINE_E_INVALID, "shine_rows_pack: cap must be a multiple of 4 (16-byte aligned value rows)");
   char* tmp = (char*)workspace;
   int* pos = (int*)(tmp + xalign(scan_bytes));
-  auto it = rocprim::make_transform_iterator((const unsigned char*)flags, FlagByteToInt());
   size_t sb = scan_bytes;
-  SHINE_HIP_CHECK(rocprim::exclusive_scan(tmp, sb, it, pos, 0, (size_t)n_rows, rocprim::plus<int>(), st));
+  SHINE_HIP_CHECK(prim_scan_flags(tmp, sb, (const unsigned char*)flags, pos, (size_t)n_rows, st));
   hipLaunchKernelGGL(k_rows_pack, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, (unsigned char*)flags,
                      (const int*)pos, (long long)n_rows, bucket, (int*)msg, (long long)cap, keep);
   SHINE_HIP_CHECK(hipGetLastError());

@@ -17,8 +17,6 @@
 //   C  per level: insert new corners with ids base+i; look the 8 corners of every fresh node up; insert the nodes.
 // The two syncs return 2L integers the host needs anyway (rows to append to the feature tables, :139,153).
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "shine_internal.hpp"
 
@@ -251,8 +249,8 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   // ---------------- phase A: fresh nodes per level, Morton order
   const unsigned end_bit = 3u * (unsigned)cfg->max_level;
   size_t sort_bytes = 0, scan_bytes = 0;
-  SHINE_HIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, (u64*)nullptr, (u64*)nullptr, (size_t)n, 0u, end_bit, st));
-  SHINE_HIP_CHECK(rocprim::exclusive_scan(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, 0, (size_t)n, rocprim::plus<int>(), st));
+  SHINE_HIP_CHECK(prim_sort_keys_u64(nullptr, sort_bytes, nullptr, nullptr, (size_t)n, 0u, end_bit, st));
+  SHINE_HIP_CHECK(prim_scan_int(nullptr, scan_bytes, nullptr, nullptr, (size_t)n, st));
   const size_t kb = galign((size_t)n * 8), ib = galign((size_t)n * 4);
   const size_t tmp_a = galign(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
   const size_t need_a = 2 * kb + 2 * ib + tmp_a + (size_t)L * kb + galign(2 * SHINE_MAX_LEVELS * 8);
@@ -271,14 +269,14 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   const float res = (float)(1u << cfg->max_level);
   hipLaunchKernelGGL(k_leaf_keys, dim3(blocks_for(n)), dim3(256), 0, st, points, (long long)n, res, k0);
   SHINE_HIP_CHECK(hipGetLastError());
-  SHINE_HIP_CHECK(rocprim::radix_sort_keys(tmp, sort_bytes, k0, k1, (size_t)n, 0u, end_bit, st));
+  SHINE_HIP_CHECK(prim_sort_keys_u64(tmp, sort_bytes, k0, k1, (size_t)n, 0u, end_bit, st));
   for (int s = 0; s < L; ++s) {
     const int level = cfg->max_level - (L - 1 - s);
     const int sh = 3 * (cfg->max_level - level);
     ProbeTable T = {t->lv[s].keys, t->lv[s].shift, t->lv[s].mask};
     G.fresh_keys[s] = (u64*)(fresh_base + (size_t)s * kb);
     hipLaunchKernelGGL(k_flag_fresh, dim3(blocks_for(n)), dim3(256), 0, st, k1, (long long)n, sh, T, flags);
-    SHINE_HIP_CHECK(rocprim::exclusive_scan(tmp, scan_bytes, flags, pos, 0, (size_t)n, rocprim::plus<int>(), st));
+    SHINE_HIP_CHECK(prim_scan_int(tmp, scan_bytes, flags, pos, (size_t)n, st));
     hipLaunchKernelGGL(k_compact, dim3(blocks_for(n)), dim3(256), 0, st, k1, (long long)n, sh, flags, pos,
                        G.fresh_keys[s], d_counts + s);
     SHINE_HIP_CHECK(hipGetLastError());
@@ -298,8 +296,8 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   // ---------------- phase B: new corners per level, lexicographic order
   const size_t mc = (size_t)max_nf * 8;
   size_t csort_bytes = 0, cscan_bytes = 0;
-  SHINE_HIP_CHECK(rocprim::radix_sort_keys(nullptr, csort_bytes, (u64*)nullptr, (u64*)nullptr, mc, 0u, 64u, st));
-  SHINE_HIP_CHECK(rocprim::exclusive_scan(nullptr, cscan_bytes, (int*)nullptr, (int*)nullptr, 0, mc, rocprim::plus<int>(), st));
+  SHINE_HIP_CHECK(prim_sort_keys_u64(nullptr, csort_bytes, nullptr, nullptr, mc, 0u, 64u, st));
+  SHINE_HIP_CHECK(prim_scan_int(nullptr, cscan_bytes, nullptr, nullptr, mc, st));
   const size_t ckb = galign(mc * 8), cib = galign(mc * 4);
   const size_t tmp_b = galign(csort_bytes > cscan_bytes ? csort_bytes : cscan_bytes);
   size_t need_b = 2 * ckb + 2 * cib + tmp_b;
@@ -327,9 +325,9 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
     ProbeTable T = {t->cl[s].keys, t->cl[s].shift, t->cl[s].mask};
     hipLaunchKernelGGL(k_expand_corners, dim3(blocks_for(m)), dim3(256), 0, st, G.fresh_keys[s], nf, c0);
     size_t sb = csort_bytes, cb = cscan_bytes;
-    SHINE_HIP_CHECK(rocprim::radix_sort_keys(ctmp, sb, c0, c1, (size_t)m, 0u, 64u, st));
+    SHINE_HIP_CHECK(prim_sort_keys_u64(ctmp, sb, c0, c1, (size_t)m, 0u, 64u, st));
     hipLaunchKernelGGL(k_flag_fresh, dim3(blocks_for(m)), dim3(256), 0, st, c1, m, 0, T, cflags);
-    SHINE_HIP_CHECK(rocprim::exclusive_scan(ctmp, cb, cflags, cpos, 0, (size_t)m, rocprim::plus<int>(), st));
+    SHINE_HIP_CHECK(prim_scan_int(ctmp, cb, cflags, cpos, (size_t)m, st));
     hipLaunchKernelGGL(k_compact, dim3(blocks_for(m)), dim3(256), 0, st, c1, m, 0, cflags, cpos, G.new_corners[s],
                        d_counts + SHINE_MAX_LEVELS + s);
     SHINE_HIP_CHECK(hipGetLastError());
@@ -390,8 +388,7 @@ extern "C" int shine_tables_rank_nodes(shine_tables* t, int64_t* n_buckets_out, 
   }
   if (total_cap >= (1ll << 31)) return set_error(SHINE_E_INVALID, "shine_tables_rank_nodes: more than 2^31 slots");
   size_t sort_bytes = 0;
-  SHINE_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, sort_bytes, (u64*)nullptr, (u64*)nullptr, (u64*)nullptr,
-                                            (u64*)nullptr, (size_t)total_cap, 0u, 64u, st));
+  SHINE_HIP_CHECK(prim_sort_pairs_u64(nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)total_cap, 0u, 64u, st));
   const size_t kb = galign((size_t)total_cap * 8);
   GrowScratch& G = t->grow;
   int rc = ensure(&G.b, &G.b_bytes, 4 * kb + galign(sort_bytes), st);  // grow results in b are consumed by now
@@ -412,7 +409,7 @@ extern "C" int shine_tables_rank_nodes(shine_tables* t, int64_t* n_buckets_out, 
     off += T.cap;
   }
   SHINE_HIP_CHECK(hipGetLastError());
-  SHINE_HIP_CHECK(rocprim::radix_sort_pairs(b + 4 * kb, sort_bytes, rk0, rk1, rv0, rv1, (size_t)total_cap, 0u, 64u, st));
+  SHINE_HIP_CHECK(prim_sort_pairs_u64(b + 4 * kb, sort_bytes, rk0, rk1, rv0, rv1, (size_t)total_cap, 0u, 64u, st));
   if (total_nodes)
     hipLaunchKernelGGL(k_rank_scatter, dim3(blocks_for(total_nodes)), dim3(256), 0, st, rv1, total_nodes, P);
   SHINE_HIP_CHECK(hipGetLastError());

@@ -112,4 +112,13 @@ inline int make_level_set(const shine_tables* t, const shine_step_config* cfg, c
   return SHINE_OK;
 }
 
+// rocPRIM behind four host wrappers, instantiated once (shine_prims.hip).  tmp == nullptr: `bytes` = temporary storage needed.
+hipError_t prim_scan_int(void* tmp, size_t& bytes, const int* in, int* out, size_t n, hipStream_t st);
+hipError_t prim_scan_flags(void* tmp, size_t& bytes, const unsigned char* flags, int* out, size_t n, hipStream_t st);
+hipError_t prim_sort_keys_u64(void* tmp, size_t& bytes, const unsigned long long* k0, unsigned long long* k1, size_t n,
+                              unsigned begin_bit, unsigned end_bit, hipStream_t st);
+hipError_t prim_sort_pairs_u64(void* tmp, size_t& bytes, const unsigned long long* k0, unsigned long long* k1,
+                               const unsigned long long* v0, unsigned long long* v1, size_t n, unsigned begin_bit,
+                               unsigned end_bit, hipStream_t st);
+
 }  // namespace shine

@@ -16,7 +16,6 @@
 // (L2 locality), and the heavy MFMA kernel no longer hashes or probes: it reads its slots coalesced.
 // ~3 small launches instead of a histogram + 3..5 radix passes; order inside a bucket is arbitrary (atomics).
 #include <cstring>
-#include <rocprim/device/device_scan.hpp>
 
 #include "shine_internal.hpp"
 
@@ -149,7 +148,7 @@ extern "C" int shine_plan_batch(const shine_tables* t, const shine_step_config* 
   hipStream_t st = (hipStream_t)stream;
   const size_t nb = (size_t)t->n_buckets, cnt = (size_t)(n > 0 ? n : 1);
   size_t scan_bytes = 0;
-  SHINE_HIP_CHECK(rocprim::exclusive_scan(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, 0, nb, rocprim::plus<int>(), st));
+  SHINE_HIP_CHECK(prim_scan_int(nullptr, scan_bytes, nullptr, nullptr, nb, st));
   const size_t o_count = 0, o_bucket = o_count + align256(nb * 4), o_local = o_bucket + align256(cnt * 4),
                o_slots = o_local + align256(cnt * 4), o_scan = o_slots + align256(cnt * (size_t)L * 4),
                need = o_scan + align256(scan_bytes);
@@ -194,7 +193,7 @@ extern "C" int shine_plan_batch(const shine_tables* t, const shine_step_config* 
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   hipLaunchKernelGGL(k_plan_count, grid, block, 0, st, a);
   SHINE_HIP_CHECK(hipGetLastError());
-  SHINE_HIP_CHECK(rocprim::exclusive_scan(w + o_scan, scan_bytes, a.count, a.count, 0, nb, rocprim::plus<int>(), st));
+  SHINE_HIP_CHECK(prim_scan_int(w + o_scan, scan_bytes, a.count, a.count, nb, st));
   hipLaunchKernelGGL(k_plan_scatter, grid, block, 0, st, a);
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;

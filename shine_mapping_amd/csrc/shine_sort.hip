@@ -9,8 +9,6 @@
 //             (only locality matters here: the fused kernel detects node runs by comparing corner ids)
 //   perm    = argsort(key) by rocPRIM's radix sort over exactly those bits.
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "shine_internal.hpp"
 
 namespace shine {
@@ -24,7 +22,7 @@ struct SortBox {
 // key = [x_hi | y_hi | z_hi | interleave3(x_lo, y_lo, z_lo)]: Z-order inside cubes of 2^bmin voxels, the cubes
 // themselves in x-major order — bx+by+bz significant bits for an elongated (street-shaped) map.
 template <typename K>
-__global__ void k_sort_keys(const float* coord, long long n, float res, SortBox b, K* keys, int* vals) {
+__global__ void k_sort_keys(const float* coord, long long n, float res, SortBox b, K* keys, unsigned long long* vals) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int vx = (int)quantize(coord[3 * i], res) - b.ox, vy = (int)quantize(coord[3 * i + 1], res) - b.oy,
@@ -42,29 +40,28 @@ __global__ void k_sort_keys(const float* coord, long long n, float res, SortBox 
   sh += b.by - b.bmin;
   key |= (unsigned long long)(ux >> b.bmin) << sh;
   keys[i] = (K)key;
-  vals[i] = (int)i;
+  vals[i] = (unsigned long long)i;
+}
+
+__global__ void k_sort_perm(const unsigned long long* vals, long long n, int* perm) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) perm[i] = (int)vals[i];
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// ONE radix-sort instantiation (64-bit keys, rocPRIM's default configuration).  Rounds 1-2 carried four (32- / 64-bit keys x a
-// small-batch and a large-batch onesweep geometry): 3.5 MB of code object for a function the hot path no longer calls — a
-// batch is ordered by the counting sort of shine_plan.hip, ~2x faster than any radix sort at these sizes.
-template <typename K>
-static hipError_t run_sort(void* tmp, size_t& tmp_bytes, K* k0, K* k1, int* v0, int* v1, size_t n, unsigned end_bit,
-                           hipStream_t st) {
-  return rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, n, 0u, end_bit, st);
-}
-
+// The radix sort is the library's one (u64 key, u64 value) instantiation (shine_prims.hip): rounds 1-2 carried four sort
+// configurations here — 3.5 MB of code object for a function the hot path no longer calls (a batch is ordered by the
+// counting sort of shine_plan.hip, ~2x faster than any radix sort at these sizes).
 template <typename K>
 static int sort_impl(const float* coord, long long n, float res, const SortBox& box, int32_t* perm_out,
                      void* workspace, size_t* workspace_bytes, hipStream_t st) {
   const unsigned end_bit = (unsigned)(box.bx + box.by + box.bz);
   const size_t cnt = (size_t)(n > 0 ? n : 1);
   size_t tmp_bytes = 0;
-  SHINE_HIP_CHECK(run_sort<K>(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, cnt, end_bit, st));
-  const size_t kb = align256(cnt * sizeof(K)), vb = align256(cnt * 4);
-  const size_t need = 2 * kb + vb + align256(tmp_bytes);
+  SHINE_HIP_CHECK(prim_sort_pairs_u64(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, cnt, 0u, end_bit, st));
+  const size_t kb = align256(cnt * sizeof(K)), vb = align256(cnt * 8);
+  const size_t need = 2 * kb + 2 * vb + align256(tmp_bytes);
   if (!workspace) {
     *workspace_bytes = need;
     return SHINE_OK;
@@ -74,11 +71,14 @@ static int sort_impl(const float* coord, long long n, float res, const SortBox& 
   char* w = (char*)workspace;
   K* k0 = (K*)w;
   K* k1 = (K*)(w + kb);
-  int* v0 = (int*)(w + 2 * kb);
-  void* tmp = w + 2 * kb + vb;
+  unsigned long long* v0 = (unsigned long long*)(w + 2 * kb);
+  unsigned long long* v1 = (unsigned long long*)(w + 2 * kb + vb);
+  void* tmp = w + 2 * kb + 2 * vb;
   hipLaunchKernelGGL((k_sort_keys<K>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, coord, n, res, box, k0, v0);
   SHINE_HIP_CHECK(hipGetLastError());
-  SHINE_HIP_CHECK(run_sort<K>(tmp, tmp_bytes, k0, k1, v0, (int*)perm_out, (size_t)n, end_bit, st));
+  SHINE_HIP_CHECK(prim_sort_pairs_u64(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0u, end_bit, st));
+  hipLaunchKernelGGL(k_sort_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v1, n, (int*)perm_out);
+  SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }
 
@@ -86,7 +86,7 @@ static int sort_impl(const float* coord, long long n, float res, const SortBox& 
 
 using namespace shine;
 
-// workspace layout: keys_in | keys_out | vals_in | rocPRIM temp
+// workspace layout: keys_in | keys_out | vals_in | vals_out | rocPRIM temp
 extern "C" int shine_morton_sort(const shine_step_config* cfg, const float* coord, int64_t n, int32_t* perm_out,
                                  void* workspace, size_t* workspace_bytes, void* stream) {
   if (!cfg || !workspace_bytes || n < 0) return set_error(SHINE_E_INVALID, "shine_morton_sort: null argument");
