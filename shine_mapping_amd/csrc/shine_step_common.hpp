@@ -51,7 +51,7 @@ struct V1Args {
   long long* prof;  // debug: per-wave phase cycle counters [waves][8] (shine_debug_set_profile_buffer) or null
   long long n;
   long long chunk;
-  long long tiles;        // v2: tiles of the launch (16 points each) ...
+  long long tiles;        // tiles of the launch (16 points each) ...
   long long waves_total;  // ... dealt evenly to this many waves: wave w owns tiles [w T / W, (w + 1) T / W)
   int n_levels;
   int reduction_sum;

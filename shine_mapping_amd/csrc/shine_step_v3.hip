@@ -252,7 +252,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   const long long second = begin + V3_TP;
 #endif
 
-  // software prefetch of the {perm -> coord, label, slot} chain, index two tiles ahead (as in v1 / v2)
+  // software prefetch of the {perm -> coord, label, slot} chain, index two tiles ahead
   long long np = 0;
   float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, nlabel = 0.f, nweight = 0.f;
   int nslot = -1;
