@@ -135,7 +135,11 @@ __global__ __launch_bounds__(256) void k_finish(const FinArgs a, int fb, int db)
       mp[1] = make_float4(m[4], m[5], m[6], m[7]);
       vp[0] = make_float4(v[0], v[1], v[2], v[3]);
       vp[1] = make_float4(v[4], v[5], v[6], v[7]);
-      gp[0] = gp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // most rows of a map were not touched by a 4096-point batch: their gradient is already zero and is not rewritten
+      // (1/8 of this launch's traffic)
+      if ((g0.x != 0.f) | (g0.y != 0.f) | (g0.z != 0.f) | (g0.w != 0.f) | (g1.x != 0.f) | (g1.y != 0.f) | (g1.z != 0.f) |
+          (g1.w != 0.f))
+        gp[0] = gp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (a.lambda != 0.f) {
       acc = wave_sum_d(acc);
