@@ -201,10 +201,25 @@ def make_frames(cfg, frames=100, beams=64, azimuths=450, seed=42, device="cuda")
 
 def build_workload(kind="maicity", frames=100, device="cuda", seed=42, beams=64, azimuths=450, **over):
     """Pool + octree + decoder for a preset: what shine_batch.py:69-95 has in hand when the hot loop starts."""
+    import hashlib
+    import os
+
     from .decoder import Decoder
     from .feature_octree import FeatureOctree
 
     cfg = make_config(kind, device=device, **over)
+    # measurement aid: SHINE_WORKLOAD_CACHE=<dir> keeps the built workload on disk, so that the profiler passes of
+    # tools/collect_profiles.sh (one process per counter group) build a large map once instead of once per pass
+    cache = os.environ.get("SHINE_WORKLOAD_CACHE")
+    path = None
+    if cache:
+        key = repr((kind, frames, seed, beams, azimuths, sorted(over.items())))
+        path = os.path.join(cache, "workload_%s.pt" % hashlib.sha1(key.encode()).hexdigest()[:16])
+        if os.path.isfile(path):
+            blob = torch.load(path, weights_only=False)
+            octree, decoder = blob["octree"], blob["decoder"].to(device)
+            pool = SimpleNamespace(**{k: v.to(device) for k, v in blob["pool"].items()})
+            return SimpleNamespace(cfg=cfg, octree=octree, decoder=decoder, pool=pool)
     torch.manual_seed(seed)
     octree = FeatureOctree(cfg)
     decoder = Decoder(cfg)
@@ -215,6 +230,9 @@ def build_workload(kind="maicity", frames=100, device="cuda", seed=42, beams=64,
         labels.append(l)
         weights.append(w)
     pool = SimpleNamespace(coord=torch.cat(coords), sdf_label=torch.cat(labels), weight=torch.cat(weights))
+    if path is not None:
+        os.makedirs(cache, exist_ok=True)
+        torch.save(dict(octree=octree, decoder=decoder, pool={k: v.cpu() for k, v in vars(pool).items()}), path)
     return SimpleNamespace(cfg=cfg, octree=octree, decoder=decoder, pool=pool)
 
 
