@@ -51,6 +51,9 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 #ifndef SHINE_V3_CH  // measurement builds: > 0 = the stream is cut into chunks of this many tiles dealt round-robin to ALL waves of
 #define SHINE_V3_CH 0  // the launch (node runs restart at chunk borders); 0 = one contiguous range per wave
 #endif
+#ifndef SHINE_V3_IDPF  // 1: the corner ids of tile t + 1 are requested during tile t (perm three tiles ahead -> slot two ahead -> ids
+#define SHINE_V3_IDPF 0  // one ahead): one dependent round trip less in front of a tile's row gathers, 8 more live VGPRs
+#endif
 #ifndef SHINE_V3_PREFIX  // 1: prefix-sum scatter (scatter_level_prefix, shine_tile16.hpp) instead of the serial walk
 #define SHINE_V3_PREFIX 0
 #endif
@@ -259,6 +262,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   bool nvalid = begin + pt < end;
   int np2 = 0;
   if (a.perm && second + pt < end) np2 = a.perm[second + pt];
+#if SHINE_V3_IDPF
+  int np3 = 0, nslot2 = -1;
+  int4 nia = make_int4(0, 0, 0, 0), nib = nia;
+  if (a.perm && second + V3_TP + pt < end) np3 = a.perm[second + V3_TP + pt];
+#endif
   if (nvalid) {
     np = a.perm ? (long long)a.perm[begin + pt] : begin + pt;
     const long long si = a.pool_mode ? np : begin + pt;
@@ -268,7 +276,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     nx2 = a.coord[3 * np + 2];
     nlabel = a.label[np];
     if (EIK || a.weighted) nweight = a.weight[np];
+#if SHINE_V3_IDPF
+    const unsigned int sl0 = nslot >= 0 ? (unsigned int)nslot : 0u;
+    nia = lv_vals[2u * sl0];
+    nib = lv_vals[2u * sl0 + 1u];
+#endif
   }
+#if SHINE_V3_IDPF
+  if (second + pt < end && lvl_on) {
+    const long long p1 = a.perm ? (long long)np2 : second + pt;
+    nslot2 = __builtin_nontemporal_load(a.slots + (a.pool_mode ? p1 : second + pt) * L + g);
+  }
+#endif
   SHINE_STAMP(0)  // setup
 
 #if SHINE_V3_CH > 0
@@ -392,8 +411,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     }
 #else
     {  // every lane gathers the 8 ids and the 8 x 32-B rows of its own (point, level)
+#if SHINE_V3_IDPF
+      const int4 ia = nia, ib = nib;  // requested during the previous tile
+#else
       const unsigned int sl = hit ? (unsigned int)slot : 0u;
       const int4 ia = lv_vals[2u * sl], ib = lv_vals[2u * sl + 1u];  // the eight corner ids: two 16-B loads
+#endif
       const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
       // staging for the scatter: a miss stages -1 (trash row), never the speculative ids
       const int mneg = hit ? 0 : -1;
@@ -452,6 +475,30 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
       np = 0;
       nx0 = nx1 = nx2 = nlabel = nweight = 0.f;
       nslot = -1;
+#if SHINE_V3_IDPF
+      int4 tia = make_int4(0, 0, 0, 0), tib = tia;
+      if (nvalid) {
+        np = a.perm ? (long long)np2 : ni;
+        nslot = nslot2;  // requested one tile ago
+        const unsigned int sl1 = nslot >= 0 ? (unsigned int)nslot : 0u;
+        tia = lv_vals[2u * sl1];  // the next tile's corner ids: its row gathers will not wait for them
+        tib = lv_vals[2u * sl1 + 1u];
+        nx0 = __builtin_nontemporal_load(a.coord + 3 * np);
+        nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
+        nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
+        nlabel = __builtin_nontemporal_load(a.label + np);
+        if (EIK || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
+      }
+      nia = tia;
+      nib = tib;
+      nslot2 = -1;
+      if (ni2 < end && lvl_on) {
+        const long long p2 = a.perm ? (long long)np3 : ni2;
+        nslot2 = __builtin_nontemporal_load(a.slots + (a.pool_mode ? p2 : ni2) * L + g);
+      }
+      np2 = np3;
+      if (a.perm && ni2 + V3_TP < end) np3 = __builtin_nontemporal_load(a.perm + ni2 + V3_TP);
+#else
       if (nvalid) {
         np = a.perm ? (long long)np2 : ni;
         const long long si = a.pool_mode ? np : ni;
@@ -463,6 +510,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
         if (EIK || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
       }
       if (a.perm && ni2 < end) np2 = __builtin_nontemporal_load(a.perm + ni2);
+#endif
     }
     // reduce-scatter of the per-level sums over the point's four lanes: lane g ends with features (2g, 2g+1)
     float f2[2];
