@@ -87,7 +87,7 @@ def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
     """argsort of the batch by leaf-level node Morton key -> int32 perm [N] (device; no host sync)."""
     coord = octree._check_coord(coord.detach())
     n = coord.shape[0]
-    cfg = octree.step_config()
+    cfg = octree.step_config(with_sort_box=True)
     lib = _lib.lib()
     stream = _lib.current_stream_handle()
     wide = sum(cfg.sort_bits) > 32 or min(cfg.sort_bits) <= 0

@@ -145,6 +145,7 @@ class FeatureOctree(nn.Module):
         self._dev_log = [[] for _ in range(L)]
         self._corners_on_device = False  # the handle's corner tables hold every corner of every level
         self._box = None  # running (lo, hi) of the coarsest featured level's node coords, for _sort_box
+        self._box_pending = []  # device tensors of coarse node keys not yet folded into _box
         # a level's regulariser contributes gradient only while its features_last_frame copy is detached
         # (first-frame branch :146); the later branch :160 stores an attached clone -> zero net gradient.
         self._reg_grad_on = [True] * L
@@ -328,7 +329,8 @@ class FeatureOctree(nn.Module):
             first = self._corner_count[s] == 0
             self._corner_count[s] += na
             if s == 0:
-                self._grow_box(keys.cpu().numpy())
+                self._box_pending.append(keys)  # (the sort box is derived lazily: no host read per frame)
+                self._sort_box_cache = None
             self._append_rows(s, first, na, incremental_on, dev)
         if grew:
             self._dict_cache = None
@@ -429,16 +431,17 @@ class FeatureOctree(nn.Module):
             off += n
         return out
 
-    def step_config(self, **kw) -> _lib.StepConfig:
+    def step_config(self, with_sort_box=False, **kw) -> _lib.StepConfig:
         cfg = _lib.StepConfig()
         cfg.n_levels = self.featured_level_num
         cfg.max_level = self.max_level
         cfg.poly_int_on = 1 if self.polynomial_interpolation else 0
         cfg.sigma = 1.0
         cfg.inv_n = 1.0
-        origin, bits = self._sort_box()
-        cfg.sort_origin[0], cfg.sort_origin[1], cfg.sort_origin[2] = origin
-        cfg.sort_bits[0], cfg.sort_bits[1], cfg.sort_bits[2] = bits
+        if with_sort_box:  # only shine_morton_sort reads it (dp.morton_order); it costs a host read after a device-side update
+            origin, bits = self._sort_box()
+            cfg.sort_origin[0], cfg.sort_origin[1], cfg.sort_origin[2] = origin
+            cfg.sort_bits[0], cfg.sort_bits[1], cfg.sort_bits[2] = bits
         for k, v in kw.items():
             setattr(cfg, k, v)
         return cfg
@@ -446,6 +449,10 @@ class FeatureOctree(nn.Module):
     def _sort_box(self):
         """Leaf-level voxel bounding box of the map (from the coarsest featured level's nodes, tracked as the tree
         grows): lets shine_morton_sort use bx+by+bz-bit keys instead of 3*tree_level_world."""
+        if self._box_pending:  # coarse node keys the device added since the box was last read: one host read, on demand
+            pend, self._box_pending = self._box_pending, []
+            for keys in pend:
+                self._grow_box(keys.cpu().numpy())
         if self._sort_box_cache is None:
             if self._box is None:
                 self._sort_box_cache = ((0, 0, 0), (0, 0, 0))
@@ -538,6 +545,7 @@ class FeatureOctree(nn.Module):
     # ------------------------------------------------------------------ checkpoints (utils/tools.py:200-213 pickles the module)
     def __getstate__(self):
         self._sync_host()
+        self._sort_box()  # folds the coarse node keys the device added into the host-side box (device tensors do not pickle)
         state = self.__dict__.copy()
         state["_tables"] = None
         state["_dict_cache"] = None
@@ -571,6 +579,7 @@ class FeatureOctree(nn.Module):
         self._corner_id_of_lex = [np.zeros(0, np.int64) for _ in range(L)]
         self._corner_count = [0] * L
         self._dict_cache = self._sort_box_cache = self._tables = self._box = None
+        self._box_pending = []
         self._ranks_uploaded = False
         self._n_buckets = 0
         self._tables_epoch = 0
@@ -594,7 +603,9 @@ class FeatureOctree(nn.Module):
             self._sync_host()
         self._dev_log = [[] for _ in range(self.featured_level_num)]
         self._corners_on_device = False
-        if getattr(self, "_box", None) is None:
+        if getattr(self, "_box_pending", None) is None:  # (pickles written before the box became lazy)
+            self._box_pending = []
+        if getattr(self, "_box", None) is None and not self._box_pending:
             self._box = None
             self._grow_box(self._node_keys[0])
         self._tables = None
@@ -611,6 +622,7 @@ class FeatureOctree(nn.Module):
         self._sort_box_cache = None
         self._dev_log = [[] for _ in range(self.featured_level_num)]
         self._box = None
+        self._box_pending = []
         for s, (keys, ids) in enumerate(tables):
             keys_np = keys.cpu().numpy().astype(np.int64)
             ids_np = ids.cpu().numpy().astype(np.int32).reshape(-1, 8)
