@@ -264,7 +264,7 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         data = type("Pool", (), {"coord_pool": coord, "sdf_label_pool": label})()
-        cal_feature_importance(data, octree, dec, cfg.sigma_sigmoid, bs, 2, "sum")
+        cal_feature_importance(data, octree, dec, cfg.sigma_sigmoid, bs, 2, "sum", pool=pool)  # (re-uses the frame's plan)
         torch.cuda.synchronize()
         t4 = time.perf_counter()
         split[fi] = (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)

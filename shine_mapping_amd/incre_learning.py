@@ -32,8 +32,10 @@ def chunk_partition(perm, sample_count, batch_interval, down_rate):
     return idx, begin
 
 
-def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduction="mean", loss_weight_on=False):
+def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduction="mean", loss_weight_on=False, pool=None):
     """Same signature as the reference; `data` needs .coord_pool and .sdf_label_pool (utils/incre_learning.py:14-26).
+    `pool` (extension): the frame's sampler.SortedPool built from the SAME data.coord_pool / sdf_label_pool — its plan (node
+    order, hash slots, node-ordered copies) is re-used instead of planning the pool a second time.
 
     The reference walks the pool in chunks [n*bs*down_rate, (n+1)*bs*down_rate) taking every down_rate-th sample
     (:27-31); a chunk's gradient is summed before the abs (:36-38), so chunk MEMBERSHIP is part of the result, the order
@@ -51,10 +53,17 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
     if iter_n == 0:
         return
     t = octree._require_tables(with_ranks=True)
-    perm, slots = plan_batch(octree, coord_pool)  # sorted position j holds pool sample perm[j]
-    p = perm.long()
-    coord_s = octree._check_coord(coord_pool)[p].contiguous()
-    label_s = label_pool[p].contiguous()
+    if pool is not None:
+        if pool.size != sample_count or pool.tables_epoch != octree._tables_epoch or pool.coord.device != dev:
+            raise ValueError("cal_feature_importance(pool=...): the pool must be the SortedPool of this frame's data, planned "
+                             "on the current octree")
+        perm, slots = pool.perm, pool.slots
+        coord_s, label_s = octree._check_coord(pool.coord), pool.sdf_label.to(torch.float32).contiguous()
+    else:
+        perm, slots = plan_batch(octree, coord_pool)  # sorted position j holds pool sample perm[j]
+        p = perm.long()
+        coord_s = octree._check_coord(coord_pool)[p].contiguous()
+        label_s = label_pool[p].contiguous()
     idx, begin = chunk_partition(perm, sample_count, batch_interval, down_rate)
     max_chunk = max(b - a for a, b in zip(begin[:-1], begin[1:]))
     opts = StepOptions(sigma=float(sigma), loss_reduction=loss_reduction, decoder_grad_on=False)

@@ -48,6 +48,7 @@ class SortedPool:
             order = canonical_order(perm, slots)
             perm, slots = perm[order].contiguous(), slots[order].contiguous()
         p = perm.long()
+        self.perm = perm  # sorted position j holds source sample perm[j] (cal_feature_importance(pool=...) re-uses the plan)
         self.coord = coord[p].contiguous()
         self.sdf_label = sdf_label[p].contiguous()
         self.weight = weight[p].contiguous()

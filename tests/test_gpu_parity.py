@@ -445,6 +445,21 @@ def test_importance_sweep_chunking_matches_oracle(reduction, bs, down_rate, take
         assert float(a[-1].abs().max()) == 0.0
     for f in octree.hier_features:  # the sweep leaves the gradients cleared (incre_learning.py:38)
         assert float(f.grad.abs().max()) == 0.0
+    # the same sweep re-using the plan of the frame's SortedPool (what the incremental loop has in hand) instead of planning
+    # the pool a second time: chunk membership comes from the pool's own permutation
+    from shine_mapping_amd.sampler import SortedPool
+
+    first = [t.clone() for t in octree.importance_weight]
+    for canonical in (False, True):
+        octree._require_tables(with_ranks=True)
+        sp = SortedPool(octree, data.coord_pool, data.sdf_label_pool, torch.ones_like(data.sdf_label_pool), seed=1,
+                        canonical=canonical)
+        for t in octree.importance_weight:
+            t.zero_()
+        cal_feature_importance(data, octree, dec, fx["sigma"], bs, down_rate, reduction, pool=sp)
+        torch.cuda.synchronize()
+        for a, b in zip(octree.importance_weight, first):
+            assert rel_err(a, b) <= 1e-5
 
 
 def test_fused_adam_matches_torch_adam():
