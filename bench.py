@@ -258,9 +258,10 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
         pool = SortedPool(octree, coord, label, weight, seed=fi)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        step = GraphedIteration(octree, dec, pool, opt, opts, bs, lambda_forget=cfg.lambda_forget,
-                                unroll=args.unroll)  # = iteration 1
-        loss = step.run(iters - 1)
+        # frame 0: the constructor runs iteration 1 eagerly; later frames capture straight away and replay all of them
+        step = GraphedIteration(octree, dec, pool, opt, opts, bs, lambda_forget=cfg.lambda_forget, unroll=args.unroll,
+                                eager_first=fi == 0)
+        loss = step.run(iters - 1 if step.ran_eager else iters)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         data = type("Pool", (), {"coord_pool": coord, "sdf_label_pool": label})()

@@ -176,6 +176,30 @@ def setup_optimizer(config, octree_feat, mlp_geo_param, mlp_sem_param=None, sigm
     return FusedAdam(groups, betas=(0.9, 0.99), eps=getattr(config, "adam_eps", 1e-15))
 
 
+def _prepare_graph_safe(self):
+    """Create the device-side step state (what the first step(graph_safe=True) does) without taking a step, so that an
+    iteration can be captured into a HIP graph without an eager one in front of it."""
+    for g in self.param_groups:  # the dense gradient tensors the fused step would create on its first launch
+        for p in g["params"]:
+            if p.requires_grad and p.grad is None:
+                p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    ts = self._tensors()
+    if not ts:
+        raise RuntimeError("prepare_graph_safe: no parameter requires grad")
+    ages = [self._age.get(t[0], 0) for t in ts]
+    if len(set(ages)) != 1 or (self._dev is None and ages[0] != self.step_count):
+        raise NotImplementedError("graph-replayable FusedAdam steps need all tensors to have the same age")
+    if self._dev is None or self._dev[1].numel() != len(ts):
+        if self._dev is not None:
+            taken = self.steps_taken()
+            for p in list(self._age):
+                self._age[p] += taken - self.step_count
+            self.step_count = taken
+        dev = ts[0][0].device
+        self._dev = (self._make_dev_state(dev), torch.tensor([t[3] for t in ts], dtype=torch.float32, device=dev))
+    return self._dev[0]
+
+
 def _finish_iteration(self, pending, regulariser=None, next_draw=None):
     """The tail of an iteration in ONE launch (shine_finish_iteration): `pending` is the dict a
     fused_train_step(..., pending=...) filled — its partial sums are added up where they are consumed, the regulariser
@@ -227,3 +251,4 @@ def _finish_iteration(self, pending, regulariser=None, next_draw=None):
 
 
 FusedAdam.finish_iteration = _finish_iteration
+FusedAdam.prepare_graph_safe = _prepare_graph_safe

@@ -979,3 +979,42 @@ def test_first_pass_of_the_next_draw_rides_on_the_step(n, world):
     got_after = p2.draw(per, graph_safe=True, pass1_done=True, **kw)
     torch.cuda.synchronize()
     assert torch.equal(got_after, want_after) and not torch.equal(want_after, want[K - 1][0])
+
+
+@pytest.mark.gpu
+def test_graphed_iteration_without_the_eager_first_iteration():
+    """loop.GraphedIteration(eager_first=False): nothing runs in the constructor (the optimiser's device state is created
+    explicitly, the graph captured straight away) and run(K) does all K iterations — same batches, same step count, same
+    parameters (deterministic mode) as the default form, whose constructor runs iteration 1 eagerly."""
+    from shine_mapping_amd import StepOptions
+    from shine_mapping_amd.loop import GraphedIteration
+    from shine_mapping_amd.optim import setup_optimizer
+    from shine_mapping_amd.sampler import SortedPool
+
+    def make():
+        fx = load_golden("ncd_reg_L3")
+        cfg, octree, dec = product_from_golden(fx)
+        dec = dec.cuda()
+        cfg.lr, cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio, cfg.weight_decay = 0.01, True, 1e-15, 1.0, 1e-7
+        octree._reg_grad_on = [True] * cfg.tree_level_feat
+        opt = setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())
+        octree._require_tables(with_ranks=True)
+        pool = SortedPool(octree, fx["coord"].cuda().repeat(8, 1), fx["sdf_label"].cuda().repeat(8),
+                          fx["weight"].cuda().repeat(8), seed=5, canonical=True)
+        return octree, dec, opt, pool, StepOptions(sigma=fx["sigma"], loss_reduction="sum", deterministic=True)
+
+    K, N = 7, 4096
+    o1, d1, opt1, p1, s1 = make()
+    a = GraphedIteration(o1, d1, p1, opt1, s1, N, lambda_forget=1e3)  # (also makes the device "warmed" for the second form)
+    assert a.ran_eager
+    a.run(K - 1)
+    o2, d2, opt2, p2, s2 = make()
+    b = GraphedIteration(o2, d2, p2, opt2, s2, N, lambda_forget=1e3, eager_first=False)
+    assert not b.ran_eager and opt2.steps_taken() == 0
+    b.run(K)
+    torch.cuda.synchronize()
+    assert opt1.steps_taken() == opt2.steps_taken() == K
+    assert torch.equal(a._idx, b._idx)  # the batch iteration K + 1 would use
+    assert abs(float(a.loss) - float(b.loss)) <= 1e-6 * abs(float(a.loss))
+    for x, y in zip(list(o1.hier_features) + d1.fused_params(), list(o2.hier_features) + d2.fused_params()):
+        assert rel_err(y.detach(), x.detach()) <= 1e-6
