@@ -880,10 +880,10 @@ def main():
     ap.add_argument("--levels", type=int, default=0, help="tree_level_feat (default: the workload's)")
     ap.add_argument("--frames", type=int, default=0, help="scans the synthetic map is built from")
     ap.add_argument("--iters", type=int, default=50, help="ncd-incre: iterations per frame (config iters)")
-    ap.add_argument("--unroll", type=int, default=1,
-                    help="ncd-incre: iterations captured per HIP graph (measured: 1 -> 4.70 ms, 7 -> 5.15 ms, 12 -> 5.62 ms per "
-                         "frame of 50 iterations: the graph is re-captured every frame, and capturing 7x the nodes costs "
-                         "more than 43 saved replays)")
+    ap.add_argument("--unroll", type=int, default=2,
+                    help="ncd-incre: iterations captured per HIP graph.  The graph is re-captured every frame, so captured nodes "
+                         "are paid for per frame against the ~8 us of idle GPU per graph boundary they save: measured 3.98 / "
+                         "3.93 / 4.11 / 4.54 ms per frame of 50 iterations at 1 / 2 / 5 / 10 (lab book block 15)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default invocation: skip the abbreviated kitti / ncd-incre legs")

@@ -95,13 +95,21 @@ class GraphedIteration:
                        and self.opt.device_state() is not None and self.n + 1 <= 16 * 1024)
         if self._ahead:
             self.pool.draw(self.n, out=self._idx, graph_safe=True, surf_parts=self._surf)
-        self.graph, (self.loss, self.reg) = _capture(self._body)
-        # `unroll` iterations in ONE graph: at the reference's batch size an iteration is ~8 small launches, and a graph
-        # replay costs ~10-16 us of host time whatever it holds — run(n) replays the long graph n // unroll times.  It pays
-        # only when the graph lives for many replays: capture cost grows with the node count (bench.py --unroll)
+        # `unroll` iterations in ONE graph: an iteration is two small launches, and every graph boundary leaves the GPU idle
+        # for ~8 us — run(n) replays the long graph n // unroll times.  A captured node costs ~16 us, so it pays when the
+        # boundaries saved outweigh the nodes captured (a frame of 50 iterations: unroll 5, bench.py --unroll).  Both graphs
+        # are captured when first needed: a frame whose length is a multiple of `unroll` never captures the one-iteration graph.
         self.unroll = max(1, int(unroll))
-        self.graph_k = None
-        if self.unroll > 1:
+        self.graph = self.graph_k = None
+        self.loss_k = self.reg_k = None
+
+    def _graph_1(self):
+        if self.graph is None:
+            self.graph, (self.loss, self.reg) = _capture(self._body)
+        return self.graph
+
+    def _graph_unrolled(self):
+        if self.graph_k is None:
             def body_k():
                 out = None
                 for _ in range(self.unroll):
@@ -109,6 +117,7 @@ class GraphedIteration:
                 return out
 
             self.graph_k, (self.loss_k, self.reg_k) = _capture(body_k)
+        return self.graph_k
 
     def _body(self):
         idx = self._idx if self._ahead else self.pool.draw(self.n, out=self._idx, graph_safe=True, surf_parts=self._surf)
@@ -147,7 +156,7 @@ class GraphedIteration:
         """Run one iteration; returns the loss of the fused terms as a 0-dim device tensor (no host sync)."""
         if self.octree._tables_epoch != self._epoch:
             raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
-        self.graph.replay()
+        self._graph_1().replay()
         return self.loss
 
     def run(self, n_iters: int):
@@ -155,12 +164,13 @@ class GraphedIteration:
         if self.octree._tables_epoch != self._epoch:
             raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
         loss = self.loss
-        k = self.unroll if self.graph_k is not None else 0
+        k = self.unroll if self.unroll > 1 else 0
         while k and n_iters >= k:
-            self.graph_k.replay()
+            self._graph_unrolled().replay()
             loss = self.loss_k
+            self.loss, self.reg = self.loss_k, self.reg_k
             n_iters -= k
         for _ in range(n_iters):
-            self.graph.replay()
+            self._graph_1().replay()
             loss = self.loss
         return loss
