@@ -53,3 +53,23 @@ def test_canonical_order_sorts_inside_nodes_only():
         shuffled[m] = base[m[torch.randperm(m.numel(), generator=g)]]
     assert not torch.equal(shuffled, base)
     assert torch.equal(shuffled[canonical_order(shuffled, slots)], p2)
+
+
+def test_workload_cache_round_trips_the_built_workload(tmp_path, monkeypatch):
+    """synth.build_workload with SHINE_WORKLOAD_CACHE set (tools/collect_profiles.sh: one process per counter group) must hand
+    back the same octree tables, features and pool from the file as from the build."""
+    from shine_mapping_amd import synth
+
+    monkeypatch.setenv("SHINE_WORKLOAD_CACHE", str(tmp_path))
+    kw = dict(frames=2, device="cpu", azimuths=60, tree_level_feat=3)
+    a = synth.build_workload("maicity", **kw)
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1
+    b = synth.build_workload("maicity", **kw)  # loaded
+    assert len(list(tmp_path.iterdir())) == 1
+    assert all(torch.equal(x, y) for x, y in zip(a.octree.hier_features, b.octree.hier_features))
+    assert torch.equal(a.pool.coord, b.pool.coord) and torch.equal(a.pool.weight, b.pool.weight)
+    for s in range(3):
+        assert (a.octree._node_keys[s] == b.octree._node_keys[s]).all() and (a.octree._node_ids[s] == b.octree._node_ids[s]).all()
+    synth.build_workload("maicity", **dict(kw, frames=3))  # another key: another file
+    assert len(list(tmp_path.iterdir())) == 2
