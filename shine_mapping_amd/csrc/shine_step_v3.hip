@@ -42,9 +42,6 @@ constexpr int V3_BIG = SHINE_V3_BIG;           // waves per workgroup of the ful
 #define SHINE_V3_GB 4
 #endif
 constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch (register budget: 8 floats each)
-#ifndef SHINE_V3_DEDUP
-#define SHINE_V3_DEDUP 0
-#endif
 #ifndef SHINE_V3_PROFBUILD  // 1: also instantiate the kernels with per-wave phase cycle counters (AB_PROF of tools/ab_build.py)
 #define SHINE_V3_PROFBUILD 0
 #endif
@@ -71,16 +68,11 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_v3(V1Args a) {
   static_assert(!(EXT && EIK), "the external-delta build backpropagates one scalar per point (no eikonal chain)");
-  static_assert(!(EIK && SHINE_V3_DEDUP), "the eikonal build gathers directly");
   constexpr int NT = WAVES * 64;
   __shared__ float s_opA[V3_OPTOTAL];
   __shared__ float s_bias[100];
   __shared__ double s_loss[4];
   __shared__ float s_wave[WAVES][V3_WAVE_FLOATS];
-#if SHINE_V3_DEDUP
-  constexpr int ROWCAP = WAVES <= 8 ? 32 : 12;  // node slots per wave (what the 160 KB of LDS leave room for)
-  __shared__ float s_rows[WAVES][ROWCAP * V3_SLOT];
-#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pt = lane & 15, g = lane >> 4;
@@ -136,9 +128,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
   int* U_ids = reinterpret_cast<int*>(U);  // [LCAP][8][16]
   float* U_w = U + V3_IDS;                 // [LCAP][8][16]
   float* R2 = U + V3_IDS + V3_W;
-#if SHINE_V3_DEDUP
-  float* const U_rows = s_rows[wv];
-#endif
 
   // Per-lane LDS base addresses: every staging access below is one of these + a compile-time offset (DS instructions
   // carry a 16-bit immediate).  They are re-derived from an opaque lane value at the top of every tile, which keeps
@@ -341,75 +330,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
     float Ag[EIK ? 8 : 1][3];  // eikonal build: this level's part of d f_q / d x_e
 #pragma unroll
     for (int q = 0; q < (EIK ? 8 : 1); ++q) Ag[q][0] = Ag[q][1] = Ag[q][2] = 0.f;
-#if SHINE_V3_DEDUP
-    // ---- node-run reuse: the points of a tile sit in a handful of nodes per level (the stream is node-ordered), so only
-    // the FIRST lane of each node run ("leader": its slot differs from its left neighbour's, or it opens the tile) loads
-    // the node's 8 corner ids and 8 x 32-B rows — into an LDS slot — and every lane of the run reads them back from
-    // there (conflict-free: slot pitch 68 floats).  The vector L1 is what this kernel saturates (TCP busy ~94 % of the
-    // time at one access per lane and 16 B, profiles/r02_pmc2_*): ~8 runs instead of 64 (point, level) pairs per tile
-    // cut its accesses for the gathers ~5x.  Slot index = rank of the leader in lane order (level-major); tiles with
-    // more runs than slots take another round.
-    {
-      const bool leader = hit && (slot != prev || pt == 0);
-      const unsigned long long lead64 = __ballot(leader);
-      const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(lead64 >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo((unsigned int)lead64, 0u));
-      const int ridx = below + (leader ? 1 : 0) - 1;  // hit lanes: the slot of this lane's node
-      const int n_runs = __popcll(lead64);
-      for (int r0 = 0; r0 < n_runs; r0 += ROWCAP) {
-        const int rl = ridx - r0;
-        const bool mine = hit && rl >= 0 && rl < ROWCAP;
-        float* const slotp = U_rows + (mine ? rl : 0) * V3_SLOT;
-        if (leader && mine) {
-          const unsigned int sl = (unsigned int)slot;
-          const int4 ia = lv_vals[2u * sl], ib = lv_vals[2u * sl + 1u];  // the eight corner ids: two 16-B loads
-          const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-          // ids staged for the scatter, which reads them at run starts only (lanes that are not leaders never stage)
-#pragma unroll
-          for (int c = 0; c < 8; ++c) st_ids[c * V3_WP] = ids[c];
-#pragma unroll
-          for (int cb = 0; cb < 8; cb += V3_GB) {
-            float4 r0v[V3_GB], r1v[V3_GB];
-#pragma unroll
-            for (int c = 0; c < V3_GB; ++c) {
-              const float* row = lv_feat + (size_t)(unsigned int)ids[cb + c] * F;
-#if SHINE_V3_ABL & 8
-              r0v[c] = make_float4((float)ids[cb + c], 1.f, 2.f, 3.f);
-              r1v[c] = r0v[c];
-              (void)row;
-#else
-              r0v[c] = *reinterpret_cast<const float4*>(row);
-              r1v[c] = *reinterpret_cast<const float4*>(row + 4);
-#endif
-            }
-#pragma unroll
-            for (int c = 0; c < V3_GB; ++c) {
-              *reinterpret_cast<float4*>(slotp + (cb + c) * F) = r0v[c];
-              *reinterpret_cast<float4*>(slotp + (cb + c) * F + 4) = r1v[c];
-            }
-          }
-        }
-        wave_lds_fence();
-        if (mine) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            const float4 ra = *reinterpret_cast<const float4*>(slotp + c * F);
-            const float4 rb = *reinterpret_cast<const float4*>(slotp + c * F + 4);
-            const float wc = w[c];
-            pf[0] = fmaf(wc, ra.x, pf[0]);
-            pf[1] = fmaf(wc, ra.y, pf[1]);
-            pf[2] = fmaf(wc, ra.z, pf[2]);
-            pf[3] = fmaf(wc, ra.w, pf[3]);
-            pf[4] = fmaf(wc, rb.x, pf[4]);
-            pf[5] = fmaf(wc, rb.y, pf[5]);
-            pf[6] = fmaf(wc, rb.z, pf[6]);
-            pf[7] = fmaf(wc, rb.w, pf[7]);
-          }
-        }
-        wave_lds_fence();
-      }
-    }
-#else
     {  // every lane gathers the 8 ids and the 8 x 32-B rows of its own (point, level)
 #if SHINE_V3_IDPF
       const int4 ia = nia, ib = nib;  // requested during the previous tile
@@ -463,7 +383,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
         if (V3_GB < 8) __builtin_amdgcn_sched_barrier(0);
       }
     }
-#endif
     // prefetch of tile t+1's point data, issued after every gather of this tile (vmcnt counts in order)
     {
 #if SHINE_V3_CH > 0
@@ -1007,8 +926,7 @@ V2Geometry v3_geometry(long long n) {
 }
 
 long long v3_lds_bytes(int wg_waves) {
-  const int rowcap = SHINE_V3_DEDUP ? (wg_waves <= 8 ? 32 : 12) : 0;
-  return (long long)sizeof(float) * (V3_OPTOTAL + 100 + (long long)wg_waves * (V3_WAVE_FLOATS + rowcap * V3_SLOT)) +
+  return (long long)sizeof(float) * (V3_OPTOTAL + 100 + (long long)wg_waves * V3_WAVE_FLOATS) +
          4 * sizeof(double);
 }
 

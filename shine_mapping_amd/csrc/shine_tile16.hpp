@@ -17,7 +17,6 @@ constexpr int V3_W = LCAP * 8 * V3_WP;         // w   [LCAP][8][16]
 constexpr int V3_R2 = 2 * 32 * V3_TT;          // two transpose tiles [32][20]; second life: df
 constexpr int V3_DF = 0, V3_DL = 8 * V3_DFP;    // df / J rows [8][20], then delta[16] (eikonal build)
 constexpr int V3_WAVE_FLOATS = V3_IDS + V3_W + V3_R2;  // 2304 floats = 9216 B per wave
-constexpr int V3_SLOT = 68;                    // pitch of one node's 8 x 8 corner rows in LDS (floats): conflict-free b128 reads
 constexpr int V3_OPA1 = 0, V3_OPA2 = 4 * 64, V3_OPA2T = 20 * 64, V3_OPA1T = 36 * 64, V3_OPTOTAL = 44 * 64;
 static_assert(V3_DFP == V3_TT, "f_wr addresses both the transpose rows and the df rows");
 static_assert(PART_STRIDE <= V3_WAVE_FLOATS, "each wave's partial vector aliases its staging region at the end");
