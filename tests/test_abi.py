@@ -126,3 +126,30 @@ def test_product_library_holds_the_fused_step_only_and_the_check_library_the_res
         rc = lib.shine_train_step(None, ctypes.byref(cfg), None, None, None, None, None, None, 16, None, None, None, None,
                                   None, None, None, None, None, None, 0, None)
         assert rc == -1 and word in lib.shine_error_string(rc), (variant, lib.shine_error_string(rc))
+
+
+def test_committed_counter_files_belong_to_the_kernels_of_this_build():
+    """bench.py reports PMC-derived roofline fields only while the loaded library still contains the kernel the counters were
+    measured on (tools/kernel_hash.py: sha256 of the kernel's machine code inside the .so).  The counter files committed under
+    profiles/ for this round must name the fused kernels of THIS source tree — a kernel change without a fresh collection
+    (tools/collect_profiles.sh) shows up here instead of silently dropping the measured fields from the bench line."""
+    import json
+    import sys
+
+    from shine_mapping_amd import build
+
+    build.build(verbose=False)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_hash
+
+    seen = 0
+    for workload, points, levels in (("maicity", 262144, 4), ("kitti", 1048576, 3), ("kitti-large", 1048576, 3)):
+        path = os.path.join(ROOT, "profiles", "r03_pmc_%s_%d_L%d.json" % (workload, points, levels))
+        assert os.path.isfile(path), path
+        rec = json.load(open(path))
+        have = kernel_hash.step_kernel_sha256(workload, levels, build.LIB)
+        assert have is not None and rec["kernel_code_sha256"] == have, (workload, rec["kernel_code_sha256"][:16], (have or "")[:16])
+        assert rec["workload"] == workload and int(rec["points"]) == points and int(rec["levels"]) == levels
+        assert rec["hbm_bytes_per_launch"] > 0 and 0 < rec["mfma_util"] < 1 and 0 < rec["fp32_datapath_util"] < 1
+        seen += 1
+    assert seen == 3
