@@ -351,14 +351,16 @@ int shine_touched_unpack(int32_t n_levels, float* const* grads, const int32_t* c
  *        a measured step, and check overflow_out).  workspace == NULL returns the required bytes.
  *      shine_rows_unpack_add: msgs = world messages back to back (the all-gather's output, this rank's included): every row
  *        is added into the bucket, one launch per rank in rank order (bit-identical results on every rank), the tails are
- *        summed in rank order and stored; *overflow_out (device
+ *        summed in rank order and — tail_add == 0 — stored (the first exchange of a step: shine_rows_pack left zeros there) or
+ *        — tail_add != 0 — added to what the bucket holds (the later micro-batches of the same step).  tail_n is the tail
+ *        length the messages were packed with in either case: it is part of the message stride.  *overflow_out (device
  *        int32, optional) is set to 1 if any rank overflowed. */
 int64_t shine_rows_message_words(int64_t cap, int64_t tail_n);
 int shine_rows_pack(uint8_t* flags, int64_t n_rows, const int64_t* keep_rows, int32_t n_keep, float* bucket,
                     int64_t tail_off, int64_t tail_n, int64_t cap, int32_t* msg, void* workspace, size_t* workspace_bytes,
                     void* stream);
 int shine_rows_unpack_add(const int32_t* msgs, int32_t world, int64_t cap, float* bucket, int64_t tail_off, int64_t tail_n,
-                          int32_t* overflow_out, void* stream);
+                          int32_t tail_add, int32_t* overflow_out, void* stream);
 
 /* ---- Mesher.query_points (utils/mesher.py:33-108): query_feature(coord, faster=True) (model/feature_octree.py:237-244,
  *      :267-286) + Decoder.sdf (model/decoder.py:49-63) for n grid points in one launch.

@@ -8,8 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libshine_hip.so")
-# the product's objects + the lane-per-point reference step (kernel_variant 1) + the experimental role-specialised step
-# (kernel_variant 5): loaded by tests / tools only, never by the product path
+# the product's objects + the training build of the lane-per-point reference step (kernel_variant 1): loaded by tests /
+# tools only, never by the product path
 CHECK_LIB_PATH = os.path.join(_HERE, "lib", "libshine_check.so")
 
 MAX_LEVELS = 8
@@ -119,7 +119,7 @@ _SIGNATURES = {
     "shine_rows_message_words": (C.c_int64, [C.c_int64, C.c_int64]),
     "shine_rows_pack": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.c_int32, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P,
                                   C.POINTER(C.c_size_t), _P]),
-    "shine_rows_unpack_add": (C.c_int, [_P, C.c_int32, C.c_int64, _P, C.c_int64, C.c_int64, _P, _P]),
+    "shine_rows_unpack_add": (C.c_int, [_P, C.c_int32, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int32, _P, _P]),
     "shine_touched_unpack": (C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int64), C.POINTER(_P), _P, _P]),
     "shine_train_step_workspace_bytes": (C.c_size_t, [C.POINTER(StepConfig), C.c_int64]),
@@ -179,7 +179,7 @@ def lib():
 
 
 def check_lib():
-    """The CHECK library (tests / tools only): same ABI, plus the kernels behind StepOptions.kernel_variant 1 and 5.  Table
+    """The CHECK library (tests / tools only): same ABI, plus the kernel behind StepOptions.kernel_variant 1.  Table
     handles are plain process memory with one layout in both libraries, so a handle made by one works in the other."""
     global _check
     if _check is not None:
@@ -196,9 +196,11 @@ def check_lib():
     return h
 
 
-def check(code: int, what: str = ""):
+def check(code: int, what: str = "", library=None):
+    """`library`: the handle whose call returned `code` (default: the product library) — the message lives in THAT library's
+    thread-local buffer."""
     if code != 0:
-        msg = lib().shine_error_string(code)
+        msg = (library if library is not None else lib()).shine_error_string(code)
         raise ShineHipError("%s failed (%d): %s" % (what or "libshine_hip call", code, (msg or b"").decode()))
 
 

@@ -3,10 +3,9 @@
     python -m shine_mapping_amd.build [--force]
 
   lib/libshine_hip.so    the PRODUCT: csrc/*.hip — the fused step (shine_step_v3.hip) and everything around it
-  lib/libshine_check.so  the product's objects + csrc/check/*.hip (the role-specialised experimental step) + the training
-                         instantiations of the lane-per-point kernel (shine_step_v0.hip -DSHINE_V0_TRAIN=1): the on-device
-                         cross-check of the GPU tests and the step for trees with more than 4 featured levels.  Only
-                         tests / tools load it (StepOptions.kernel_variant 1 / 5).
+  lib/libshine_check.so  the product's objects with shine_step_v0.hip compiled -DSHINE_V0_TRAIN=1 (the training
+                         instantiations of the lane-per-point kernel): the on-device cross-check of the GPU tests.  Only
+                         tests / tools load it (StepOptions.kernel_variant 1).
 
 Both land in shine_mapping_amd/lib/ (git-ignored, but they travel with the gpurun snapshot).
 """
@@ -22,7 +21,6 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libshine_hip.so")
 CHECK_LIB = os.path.join(LIBDIR, "libshine_check.so")
-CHECK_DIR = os.path.join(CSRC, "check")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(os.path.dirname(HERE), "include")]
@@ -34,7 +32,7 @@ def sources():
 
 def _digest():
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + ["check/" + g for g in sorted(os.listdir(CHECK_DIR))] + ["../../include/shine_hip.h"]:
+    for f in sorted(os.listdir(CSRC)) + ["../../include/shine_hip.h"]:
         p = os.path.join(CSRC, f)
         if os.path.isfile(p):
             h.update(f.encode())
@@ -66,12 +64,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return obj
 
     product = [(os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace(".hip", ".o")), []) for src in sources()]
-    check_only = [(os.path.join(CHECK_DIR, src), os.path.join(OBJDIR, "check_" + src.replace(".hip", ".o")), [])
-                  for src in sorted(f for f in os.listdir(CHECK_DIR) if f.endswith(".hip"))]
     v0_train = (os.path.join(CSRC, "shine_step_v0.hip"), os.path.join(OBJDIR, "check_shine_step_v0_train.o"),
                 ["-DSHINE_V0_TRAIN=1"])
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, product + check_only + [v0_train]))
+        objs = list(ex.map(compile_one, product + [v0_train]))
     n = len(product)
     product_objs, check_objs = objs[:n], objs[n:]
 

@@ -24,8 +24,8 @@ int set_hip_error(hipError_t e, const char* what) {
 
 }  // namespace shine
 
-// the lane-per-point reference kernel and the role-specialised experimental kernel live in the CHECK library only
-// (libshine_check.so = this library + csrc/check/*.hip + the training instantiations of shine_step_v0.hip): weak here
+// the lane-per-point reference kernel's TRAINING instantiations live in the CHECK library only
+// (libshine_check.so = this library with shine_step_v0.hip compiled -DSHINE_V0_TRAIN=1): weak here
 extern "C" int shine_train_step_v0(const shine_tables*, const shine_step_config*, const float*, const float*,
                                    const float*, const int32_t*, const int64_t*, int64_t, const float* const*,
                                    const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
@@ -36,12 +36,6 @@ extern "C" int shine_train_step_v3(const shine_tables*, const shine_step_config*
                                    const float* const*,
                                    const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
                                    double*, unsigned char* const*, void*, size_t, void*);
-
-extern "C" int shine_train_step_v5(const shine_tables*, const shine_step_config*, const float*, const float*,
-                                   const float*, const int32_t*, const int32_t*, const int64_t*, int64_t,
-                                   const float* const*,
-                                   const int64_t*, const float* const*, float*, float*, float* const*, float* const*,
-                                   double*, unsigned char* const*, void*, size_t, void*) __attribute__((weak));
 
 extern "C" int shine_version(void) { return 200; }
 
@@ -71,18 +65,14 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
   }
   // kernel_variant (low byte): 0 the product kernel (shine_step_v3.hip: planned / pool batches, <= 4 featured levels — every
   // shipped yaml).  The check library adds 1 = the lane-per-point reference kernel (any batch, up to 8 levels; the
-  // on-device cross-check of the tests) and 5 = the role-specialised experimental kernel (check/shine_step_v5.hip).
+  // on-device cross-check of the tests).
   const int variant = cfg->kernel_variant & 0xff;
-  if (cfg->defer_reduce && (variant == 1 || variant == 5 || cfg->n_levels > shine::LCAP || !slots))
+  if (variant != 0 && variant != 1 && variant != 4)
+    return shine::set_error(SHINE_E_INVALID, "shine_train_step: unknown kernel_variant (0 / 4: fused step, 1: check library)");
+  if (cfg->defer_reduce && (variant == 1 || cfg->n_levels > shine::LCAP || !slots))
     return shine::set_error(SHINE_E_INVALID, "shine_train_step: defer_reduce is for the product kernel on a planned batch");
-  if (cfg->n_surf_parts > 1 && (variant == 1 || variant == 5 || cfg->n_levels > shine::LCAP || !slots))
+  if (cfg->n_surf_parts > 1 && (variant == 1 || cfg->n_levels > shine::LCAP || !slots))
     return shine::set_error(SHINE_E_INVALID, "shine_train_step: n_surf_parts > 1 is for the product kernel (sum the parts first)");
-  if (variant == 5) {
-    if (!shine_train_step_v5)
-      return shine::set_error(SHINE_E_INVALID, "shine_train_step: kernel_variant 5 is part of the check library (libshine_check.so)");
-    return shine_train_step_v5(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
-                               grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes, stream);
-  }
   if (variant == 1 || cfg->n_levels > shine::LCAP || !slots) {
     if (!shine_train_step_v0)
       return shine::set_error(SHINE_E_INVALID,
@@ -93,8 +83,6 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
     return shine_train_step_v0(t, cfg, coord, sdf_label, weight, perm, n_surf, n, feats, rows, mlp, pred_out, grad_x_out,
                                grad_feats, grad_mlp, loss_parts, stream);
   }
-  if (variant != 0 && variant != 4)
-    return shine::set_error(SHINE_E_INVALID, "shine_train_step: unknown kernel_variant (0 / 4: fused step, 1 / 5: check library)");
   return shine_train_step_v3(t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out, grad_x_out,
                              grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes, stream);
 }

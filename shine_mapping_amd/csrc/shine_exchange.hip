@@ -203,12 +203,12 @@ __global__ void k_rows_unpack_add(const int* m, long long cap, float* bucket, in
 }
 
 __global__ void k_rows_unpack_tail(const int* msgs, long long msg_words, long long tail_off_words, int world,
-                                   float* bucket_tail, long long n) {
+                                   float* bucket_tail, long long n, int add) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
   for (int r = 0; r < world; ++r) s += reinterpret_cast<const float*>(msgs + (long long)r * msg_words)[tail_off_words + i];
-  bucket_tail[i] = s;
+  bucket_tail[i] = add ? bucket_tail[i] + s : s;  // (the ranks' sum first, then the bucket: the same order on every rank)
 }
 
 }  // namespace shine
@@ -254,7 +254,7 @@ extern "C" int shine_rows_pack(uint8_t* flags, int64_t n_rows, const int64_t* ke
 }
 
 extern "C" int shine_rows_unpack_add(const int32_t* msgs, int32_t world, int64_t cap, float* bucket, int64_t tail_off,
-                                     int64_t tail_n, int32_t* overflow_out, void* stream) {
+                                     int64_t tail_n, int32_t tail_add, int32_t* overflow_out, void* stream) {
   if (!msgs || world < 1 || cap < 1 || !bucket || tail_n < 0)
     return set_error(SHINE_E_INVALID, "shine_rows_unpack_add: bad argument");
   hipStream_t st = (hipStream_t)stream;
@@ -266,7 +266,7 @@ extern "C" int shine_rows_unpack_add(const int32_t* msgs, int32_t world, int64_t
   }
   if (tail_n > 0) {
     hipLaunchKernelGGL(k_rows_unpack_tail, dim3((unsigned)((tail_n + 255) / 256)), dim3(256), 0, st, (const int*)msgs, words,
-                       (long long)(ROWS_HDR + cap + cap * F), (int)world, bucket + tail_off, (long long)tail_n);
+                       (long long)(ROWS_HDR + cap + cap * F), (int)world, bucket + tail_off, (long long)tail_n, (int)(tail_add != 0));
     SHINE_HIP_CHECK(hipGetLastError());
   }
   return SHINE_OK;

@@ -202,11 +202,10 @@ __global__ __launch_bounds__(256) void k_finish(const FinArgs a, int fb, int db)
     ls = wave_sum_d(ls);
     cs = wave_sum_d(cs);
     es = wave_sum_d(es);
-    int c = (a.n_surf && a.n_surf_parts > 1 && lane < a.n_surf_parts) ? (int)a.n_surf[lane] : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if (lane == 0) {
-      const long long ns = a.n_surf ? (a.n_surf_parts > 1 ? (long long)c : *a.n_surf) : 0;
+      // the surface count the fused kernel used (left by its workgroup 0 next to the loss terms): the sampler blocks of THIS
+      // launch are already counting the next batch's surface samples into a.n_surf
+      const long long ns = a.n_surf ? (long long)reinterpret_cast<const double*>(a.partials + PART_LOSS)[3] : 0;
       const double bce = a.reduction_sum ? ls : ls * (double)a.inv_n;
       const double eik = ns > 0 ? es * (double)(1.0f / (float)ns) : 0.0;
       a.loss_parts[0] = bce;

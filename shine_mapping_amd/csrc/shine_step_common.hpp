@@ -1,4 +1,4 @@
-// shine_step_common.hpp — what the fused-step kernels (shine_step_v3.hip; check/shine_step_v5.hip) and their support kernels
+// shine_step_common.hpp — what the fused-step kernel (shine_step_v3.hip) and its support kernels
 // (shine_step_support.hip) share: the kernel argument block, the layout of the per-workgroup partial vector that
 // k_reduce_partials adds up, and a few wave-level device helpers.
 #pragma once
@@ -100,8 +100,6 @@ struct V2Geometry {
 };
 V2Geometry v3_geometry(long long n);  // shine_step_v3.hip: tiles dealt evenly to every resident wave slot
 long long v3_lds_bytes(int wg_waves);
-V2Geometry v5_geometry(long long n, bool eik);  // shine_step_v5.hip: 16-wave workgroups of 4 role-specialised pipelines
-long long v5_lds_bytes(bool eik);
 
 // measurement aid (shine_debug_set_profile_buffer): per-wave phase cycle counters or null
 extern long long* g_prof_buffer;

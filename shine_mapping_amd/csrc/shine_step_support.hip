@@ -70,7 +70,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks,
     }
     return;
   }
-  __shared__ long long s_ns;  // the batch's surface count (eikonal): the sum of the <= 64 parts of cfg->n_surf_parts
+  __shared__ long long s_ns;  // the batch's surface count (eikonal)
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
   const int L = a.n_levels;
@@ -136,12 +136,10 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks,
       d += reinterpret_cast<const double*>(a.partials + (long long)b * PART_STRIDE + PART_LOSS)[lane];
     s_dred[part][lane] = d;
   }
-  if (blockIdx.x == 0 && part == 15) {  // one wave adds up the surface-count parts: one load per lane
-    int c = (a.n_surf && lane < a.n_surf_parts && a.n_surf_parts > 1) ? (int)a.n_surf[lane] : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if (lane == 0) s_ns = a.n_surf ? (a.n_surf_parts > 1 ? (long long)c : *a.n_surf) : 0;
-  }
+  // the surface count the fused kernel normalised the eikonal term with: workgroup 0 left it next to its loss terms (the
+  // sampler's parts in a.n_surf may already belong to the NEXT batch: the pass-1 rider above clears them)
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    s_ns = a.n_surf ? (long long)reinterpret_cast<const double*>(a.partials + PART_LOSS)[3] : 0;
   __syncthreads();
   if (dst) {
     float tot = 0.f;

@@ -30,878 +30,15 @@
 // tile range holds 4-6 x the mean number of node runs (tools/run_stats.py).
 // Planned or pool batches only (the hash slots come with the batch): the Python layer plans every batch that arrives without
 // an order (shine_plan_batch), the C entry point refuses one.
-#include "shine_tile16.hpp"
+#include "shine_step_body.hpp"
 
 namespace shine {
 
-#ifndef SHINE_V3_BIG
-#define SHINE_V3_BIG 8
-#endif
-constexpr int V3_BIG = SHINE_V3_BIG;           // waves per workgroup of the full-chip launch (V3_BIG / 4 per SIMD)
-#ifndef SHINE_V3_GB
-#define SHINE_V3_GB 4
-#endif
-constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch (register budget: 8 floats each)
-#ifndef SHINE_V3_PROFBUILD  // 1: also instantiate the kernels with per-wave phase cycle counters (AB_PROF of tools/ab_build.py)
-#define SHINE_V3_PROFBUILD 0
-#endif
-#ifndef SHINE_V3_CH  // measurement builds: > 0 = the stream is cut into chunks of this many tiles dealt round-robin to ALL waves of
-#define SHINE_V3_CH 0  // the launch (node runs restart at chunk borders); 0 = one contiguous range per wave
-#endif
-#ifndef SHINE_V3_IDPF  // 1: the corner ids of tile t + 1 are requested during tile t (perm three tiles ahead -> slot two ahead -> ids
-#define SHINE_V3_IDPF 0  // one ahead): one dependent round trip less in front of a tile's row gathers, 8 more live VGPRs
-#endif
-#ifndef SHINE_V3_PREFIX  // 1: prefix-sum scatter (scatter_level_prefix, shine_tile16.hpp) instead of the serial walk
-#define SHINE_V3_PREFIX 0
-#endif
-#ifndef SHINE_V3_ABL  // measurement builds only (tools/mk_variant.py): 1 no atomics, 2 no weight-grad phase, 4 no scatter
-#define SHINE_V3_ABL 0  // phase, 8 no row gathers; the product build compiles none of it
-#endif
-
-// EXT: the backward half of Tier A's fused node (autograd_ops.FusedInterpSdf): d loss / d pred comes from autograd
-// (a.ext_delta) instead of the kernel's own BCE — query, decoder forward, decoder backward, weight grads and scatter are the
-// same code.
-// MARK: the touched-row flags (for shine_regularize) are set by the scatter at the run start of every hit node instead of by a
-// k_mark_touched launch in front of the step — a build of its own, because the flag code costs the kernel ~10 % at 2^18
-// points even when there are no flags to set (profiles/r03_ab_experiments.txt block 3), and pays at the incremental
-// configuration's 4096 points, where the extra launch is half the step (ncd-incre 172 -> 179 frames/s).
+// one launch = one step: every workgroup runs its share of the batch (shine_step_body.hpp)
 template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_v3(V1Args a) {
-  static_assert(!(EXT && EIK), "the external-delta build backpropagates one scalar per point (no eikonal chain)");
-  constexpr int NT = WAVES * 64;
-  __shared__ float s_opA[V3_OPTOTAL];
-  __shared__ float s_bias[100];
-  __shared__ double s_loss[4];
-  __shared__ float s_wave[WAVES][V3_WAVE_FLOATS];
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int pt = lane & 15, g = lane >> 4;
-  const bool poly = a.poly != 0;
-  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tk = PROF ? clk() : 0;
-#define SHINE_STAMP(k)            \
-  if (PROF) {                     \
-    long long now__ = clk();      \
-    pc[k] += now__ - tk;          \
-    tk = now__;                   \
-  }
-
-  // ---- per-workgroup setup: A operands in 16x16x4 lane order (lane l: row i = l & 15, k = l >> 4), biases.
-  // Branch-free source select and a fully unrolled loop: the (up to 11) loads of a thread are all in flight together —
-  // one L2 round trip instead of one per pass (the setup was ~10 k cycles of a wave's ~130 k).
-#pragma unroll
-  for (int it = 0; it < (V3_OPTOTAL + NT - 1) / NT; ++it) {
-    const int idx = it * NT + tid;
-    if (idx < V3_OPTOTAL) {
-      const int t = idx >> 6, l = idx & 63, i = l & 15, kg = l >> 4;
-      const float* src;
-      bool zero = false;
-      if (t < 4) {  // W1: M-block mb = t >> 1, k-step tt = t & 1 contracts over features 2 kg + tt
-        src = a.mlp[0] + (16 * (t >> 1) + i) * F + 2 * kg + (t & 1);
-      } else if (t < 20) {  // W2: mb, k-step (m', r) contracts over channels 16 m' + 4 kg + r
-        const int u = t - 4, mb = u >> 3, ks = u & 7;
-        src = a.mlp[2] + (16 * mb + i) * H + 16 * (ks >> 2) + 4 * kg + (ks & 3);
-      } else if (t < 36) {  // W2^T
-        const int u = t - 20, mb = u >> 3, ks = u & 7;
-        src = a.mlp[2] + (16 * (ks >> 2) + 4 * kg + (ks & 3)) * H + 16 * mb + i;
-      } else {  // W1^T, output rows permuted: row 4 g' + r' = feature 2 g' + r' for r' < 2, zero otherwise
-        const int ks = t - 36, gp = i >> 2, rp = i & 3;
-        src = a.mlp[0] + (16 * (ks >> 2) + 4 * kg + (ks & 3)) * F + 2 * gp + (rp & 1);
-        zero = rp >= 2;
-      }
-      const float v = *src;
-      s_opA[idx] = zero ? 0.f : v;
-    }
-  }
-  if (tid < 32) {
-    s_bias[tid] = a.mlp[1][tid];
-    s_bias[32 + tid] = a.mlp[3][tid];
-    s_bias[64 + tid] = a.mlp[4][tid];
-  }
-  if (tid == 0) {
-    s_bias[96] = a.mlp[5][0];
-    s_loss[0] = s_loss[1] = s_loss[2] = s_loss[3] = 0.0;
-  }
-  __syncthreads();
-
-  float* U = s_wave[wv];
-  int* U_ids = reinterpret_cast<int*>(U);  // [LCAP][8][16]
-  float* U_w = U + V3_IDS;                 // [LCAP][8][16]
-  float* R2 = U + V3_IDS + V3_W;
-
-  // Per-lane LDS base addresses: every staging access below is one of these + a compile-time offset (DS instructions
-  // carry a 16-bit immediate).  They are re-derived from an opaque lane value at the top of every tile, which keeps
-  // LLVM's loop-invariant code motion from parking pre-added address variants in VGPRs across the whole loop.
-  int lane_o = lane;
-  const float b3 = s_bias[96];
-  const float inv_sigma = 1.0f / a.sigma;
-  const float4* sb4 = reinterpret_cast<const float4*>(s_bias);
-
-  // this lane's level (query role): table pointers and resolution of level g (lanes of a level the tree does not have
-  // borrow the leaf level's pointers and never hit)
-  const bool lvl_on = g < L;
-  const int gs = lvl_on ? g : L - 1;
-  const float* lv_feat = a.lv[0].feat;
-  const int4* lv_vals = a.lv[0].vals;
-  float lv_res = a.lv[0].res;
-#pragma unroll
-  for (int s = 1; s < L; ++s)
-    if (gs == s) {
-      lv_feat = a.lv[s].feat;
-      lv_vals = a.lv[s].vals;
-      lv_res = a.lv[s].res;
-    }
-
-  f32x4 accW2[2][2], accW1[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    accW1[m] = zero4();
-#pragma unroll
-    for (int n = 0; n < 2; ++n) accW2[m][n] = zero4();
-  }
-  float dw3c[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) dw3c[r] = 0.f;
-  float db2acc[2] = {0.f, 0.f};  // BCE build: db2 rides on the transposed operands of the dW2 pass
-  float db2c[EIK ? 8 : 1], db1c[EIK ? 8 : 1];  // eikonal build: sum_p delta_p v2 / v1 for this lane's channels
-#pragma unroll
-  for (int r = 0; r < (EIK ? 8 : 1); ++r) db2c[r] = db1c[r] = 0.f;
-  float eik_acc = 0.f;
-  float inv_nsurf = 0.f;
-  if (EIK) {  // the batch's surface count: one number, or the sampler's per-block parts (cfg->n_surf_parts) added up here
-    long long ns = 0;
-    if (a.n_surf) {
-      if (a.n_surf_parts <= 1) {
-        ns = *a.n_surf;
-      } else {
-        int c = lane < a.n_surf_parts ? (int)a.n_surf[lane] : 0;  // (<= 64 parts: one load per lane)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        ns = c;
-      }
-    }
-    inv_nsurf = ns > 0 ? 1.0f / (float)ns : 0.f;
-  }
-  float db3 = 0.f;
-  float loss_acc = 0.f;  // per-lane sum over this wave's <= a few dozen tiles; widened to double at the flush
-  int cnt_acc = 0;
-  int run_id[LCAP], run_hit[LCAP];
-  float run_acc[LCAP];
-  float trash_sum = 0.f;
-#pragma unroll
-  for (int s = 0; s < LCAP; ++s) {
-    run_id[s] = -1;
-    run_acc[s] = 0.f;
-    run_hit[s] = 0;
-  }
-  int last_slot = -2;  // this lane's level: the node of the previous tile's last point (carries runs across tiles)
-  const int sc = lane >> 3, sq = lane & 7;  // scatter role: corner, feature
-
-  // Tiles: workgroup b owns tiles [b T / B, (b + 1) T / B) of the ordered stream, its waves contiguous parts of that.
-  // The two waves of a SIMD are not served equally (issue arbitration prefers the older one: the per-wave cycle counters
-  // show waves 0-3 of an 8-wave workgroup finishing ~20 % before waves 4-7 on equal shares), so the first half of the
-  // waves takes OLD_SHARE / 256 of the workgroup's tiles where the wave's run is long enough for it to matter (A/B at
-  // 2^20 points x 3 levels with the eikonal term, 32 tiles per wave: 140 -> -3.6 %; at 2^18 x 4 BCE, 8 tiles per wave,
-  // an even split is best).
-  constexpr int OLD_SHARE = EIK ? 140 : 128;
-  const long long wave_g = (long long)blockIdx.x * WAVES + wv;
-  long long begin, end_t;
-  {
-    const long long t0 = ((long long)blockIdx.x * a.tiles) / gridDim.x, t1 = ((long long)(blockIdx.x + 1) * a.tiles) / gridDim.x;
-    const long long nt = t1 - t0;
-    constexpr int HW = WAVES / 2;
-    const long long cut = (WAVES >= 8 && nt >= 4 * WAVES) ? (nt * OLD_SHARE) >> 8 : nt / 2;  // tiles of waves [0, HW)
-    long long lo = wv < HW ? (wv * cut) / HW : cut + ((wv - HW) * (nt - cut)) / HW;
-    long long hi = wv < HW ? ((wv + 1) * cut) / HW : cut + ((wv - HW + 1) * (nt - cut)) / HW;
-    if (a.ablate & 64) {  // deterministic accumulation (tests): ONE wave of the one-workgroup launch walks the whole stream,
-      lo = wv == 0 ? 0 : nt;  // so every feature-grad atomic is issued — and applied — in stream order
-      hi = nt;
-    }
-    begin = V3_TP * (t0 + lo);
-    end_t = V3_TP * (t0 + hi);
-  }
-#if SHINE_V3_CH > 0
-  // interleaved assignment: wave w of the launch owns chunks w, w + W, w + 2 W, ... (W waves, SHINE_V3_CH tiles per chunk)
-  const long long n_waves_all = (long long)gridDim.x * WAVES;
-  const long long n_chunks_all = (a.tiles + SHINE_V3_CH - 1) / SHINE_V3_CH;
-  int njobs = 0;
-  {
-    const long long mine = wave_g < n_chunks_all ? (n_chunks_all - wave_g + n_waves_all - 1) / n_waves_all : 0;
-    njobs = (int)(mine * SHINE_V3_CH);
-    if (mine > 0) {
-      const long long left = a.tiles - (wave_g + (mine - 1) * n_waves_all) * SHINE_V3_CH;
-      if (left < SHINE_V3_CH) njobs -= (int)(SHINE_V3_CH - left);
-    }
-  }
-  auto tile_base = [&](int j) -> long long {
-    return j < njobs ? V3_TP * ((wave_g + (long long)(j / SHINE_V3_CH) * n_waves_all) * SHINE_V3_CH + (j % SHINE_V3_CH)) : a.n;
-  };
-  begin = tile_base(0);
-  const long long end = a.n;
-  const long long second = tile_base(1);
-#else
-  const long long end = end_t < a.n ? end_t : a.n;
-  const long long second = begin + V3_TP;
-#endif
-
-  // software prefetch of the {perm -> coord, label, slot} chain, index two tiles ahead
-  long long np = 0;
-  float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, nlabel = 0.f, nweight = 0.f;
-  int nslot = -1;
-  bool nvalid = begin + pt < end;
-  int np2 = 0;
-  if (a.perm && second + pt < end) np2 = a.perm[second + pt];
-#if SHINE_V3_IDPF
-  int np3 = 0, nslot2 = -1;
-  int4 nia = make_int4(0, 0, 0, 0), nib = nia;
-  if (a.perm && second + V3_TP + pt < end) np3 = a.perm[second + V3_TP + pt];
-#endif
-  if (nvalid) {
-    np = a.perm ? (long long)a.perm[begin + pt] : begin + pt;
-    const long long si = a.pool_mode ? np : begin + pt;
-    if (lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
-    nx0 = a.coord[3 * np];
-    nx1 = a.coord[3 * np + 1];
-    nx2 = a.coord[3 * np + 2];
-    nlabel = a.label[np];
-    if (EIK || a.weighted) nweight = a.weight[np];
-#if SHINE_V3_IDPF
-    const unsigned int sl0 = nslot >= 0 ? (unsigned int)nslot : 0u;
-    nia = lv_vals[2u * sl0];
-    nib = lv_vals[2u * sl0 + 1u];
-#endif
-  }
-#if SHINE_V3_IDPF
-  if (second + pt < end && lvl_on) {
-    const long long p1 = a.perm ? (long long)np2 : second + pt;
-    nslot2 = __builtin_nontemporal_load(a.slots + (a.pool_mode ? p1 : second + pt) * L + g);
-  }
-#endif
-  SHINE_STAMP(0)  // setup
-
-#if SHINE_V3_CH > 0
-  for (int jt = 0; jt < njobs; ++jt) {
-    const long long base = tile_base(jt);
-    if (jt % SHINE_V3_CH == 0) last_slot = -2;  // a new chunk: no node carries over
-#else
-  for (long long base = begin; base < end; base += V3_TP) {
-#endif
-    asm volatile("" : "+v"(lane_o));  // opaque per tile (see above)
-    const int o_pt = lane_o & 15, o_g = lane_o >> 4;
-    int* const st_ids = U_ids + (8 * o_g) * V3_WP + o_pt;   // staging writes (level o_g): + c * V3_WP
-    float* const st_w = U_w + (8 * o_g) * V3_WP + o_pt;
-    const int* const sc_ids = U_ids + (lane_o >> 3) * V3_WP;  // scatter reads: + s * 8 * V3_WP + point
-    const float* const sc_w = U_w + (lane_o >> 3) * V3_WP;
-    const float* const sc_df = R2 + V3_DF + (lane_o & 7) * V3_DFP;
-    float* const t_wr = R2 + (4 * o_g) * V3_TT + o_pt;       // transpose writes: + (16 m + r) * V3_TT [+ 32 * V3_TT]
-    const float* const t_rd = R2 + o_pt * V3_TT + 4 * o_g;   // operand reads (i16 = lane & 15, kk = lane >> 4)
-    float* const f_wr = R2 + (2 * o_g) * V3_TT + o_pt;       // [feature 2g (+1)][pt] rows (V3_DFP == V3_TT)
-    const float* const opa = s_opA + lane_o;
-    const bool valid = nvalid;
-    const long long p = np;
-    const long long po = a.pool_mode ? base + pt : p;  // where this point's outputs go
-    const float x0 = nx0, x1 = nx1, x2 = nx2, label = nlabel, wgt = nweight;
-    // ================================================================ phase 1: query (this lane: level g of point pt)
-    const int slot = valid ? nslot : -1;
-    const bool hit = slot >= 0;
-    const unsigned int validmask = (unsigned int)__ballot(valid) & 0xFFFFu;
-    // node-run boundaries of the ordered stream, all levels at once: bit 16 g + pt of one 64-bit ballot
-    const int prev = row_prev(slot, last_slot);
-    const bool chg = valid && lvl_on && slot != prev;
-    const unsigned long long chg64 = __ballot(chg);
-    const unsigned long long hit64 = __ballot(hit);
-    last_slot = row_last(slot);
-    // smooth-step weights of this level, in the reference's association (model/feature_octree.py:186-193)
-    float w[8];
-    Axis X = axis_weight_rt(poly, x0, lv_res), Y = axis_weight_rt(poly, x1, lv_res), Z = axis_weight_rt(poly, x2, lv_res);
-    if (EIK && !hit) X.dt = Y.dt = Z.dt = 0.f;  // a miss: every d w_c / d x carries exactly one of these factors
-    corner_weights(X.t, Y.t, Z.t, w);
-    if (!hit) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) w[c] = 0.f;  // padding lanes and misses contribute nothing to f or to the scatter
-    }
-    if (!EIK) {  // staging for the scatter: [level][corner][point] (the eikonal build stages its weights after the decoder)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) st_w[c * V3_WP] = w[c];
-    }
-    float pf[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) pf[q] = 0.f;
-    float Ag[EIK ? 8 : 1][3];  // eikonal build: this level's part of d f_q / d x_e
-#pragma unroll
-    for (int q = 0; q < (EIK ? 8 : 1); ++q) Ag[q][0] = Ag[q][1] = Ag[q][2] = 0.f;
-    {  // every lane gathers the 8 ids and the 8 x 32-B rows of its own (point, level)
-#if SHINE_V3_IDPF
-      const int4 ia = nia, ib = nib;  // requested during the previous tile
-#else
-      const unsigned int sl = hit ? (unsigned int)slot : 0u;
-      const int4 ia = lv_vals[2u * sl], ib = lv_vals[2u * sl + 1u];  // the eight corner ids: two 16-B loads
-#endif
-      const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-      // staging for the scatter: a miss stages -1 (trash row), never the speculative ids
-      const int mneg = hit ? 0 : -1;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) st_ids[c * V3_WP] = ids[c] | mneg;
-      // V3_GB corners (2 V3_GB 16-B loads) in flight at a time
-#pragma unroll
-      for (int cb = 0; cb < 8; cb += V3_GB) {
-        float4 r0[V3_GB], r1[V3_GB];
-#pragma unroll
-        for (int c = 0; c < V3_GB; ++c) {  // a miss reads row 0 with weight 0 (no branches)
-          const float* row = lv_feat + (size_t)(hit ? (unsigned int)ids[cb + c] : 0u) * F;
-#if SHINE_V3_ABL & 8
-          r0[c] = make_float4((float)ids[cb + c], 1.f, 2.f, 3.f);
-          r1[c] = r0[c];
-          (void)row;
-#else
-          r0[c] = *reinterpret_cast<const float4*>(row);
-          r1[c] = *reinterpret_cast<const float4*>(row + 4);
-#endif
-        }
-#pragma unroll
-        for (int c = 0; c < V3_GB; ++c) {
-          const float wc = w[cb + c];
-          pf[0] = fmaf(wc, r0[c].x, pf[0]);
-          pf[1] = fmaf(wc, r0[c].y, pf[1]);
-          pf[2] = fmaf(wc, r0[c].z, pf[2]);
-          pf[3] = fmaf(wc, r0[c].w, pf[3]);
-          pf[4] = fmaf(wc, r1[c].x, pf[4]);
-          pf[5] = fmaf(wc, r1[c].y, pf[5]);
-          pf[6] = fmaf(wc, r1[c].z, pf[6]);
-          pf[7] = fmaf(wc, r1[c].w, pf[7]);
-          if (EIK) {
-            float dwc[3];
-            corner_dw(X, Y, Z, cb + c, dwc);
-            const float rr[8] = {r0[c].x, r0[c].y, r0[c].z, r0[c].w, r1[c].x, r1[c].y, r1[c].z, r1[c].w};
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-#pragma unroll
-              for (int q = 0; q < 8; ++q) Ag[q][e] = fmaf(dwc[e], rr[q], Ag[q][e]);  // (zero for a miss: dt = 0 above)
-            }
-          }
-        }
-        if (V3_GB < 8) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // prefetch of tile t+1's point data, issued after every gather of this tile (vmcnt counts in order)
-    {
-#if SHINE_V3_CH > 0
-      const long long ni = tile_base(jt + 1) + pt, ni2 = tile_base(jt + 2) + pt;
-#else
-      const long long ni = base + V3_TP + pt, ni2 = ni + V3_TP;
-#endif
-      nvalid = ni < end;
-      np = 0;
-      nx0 = nx1 = nx2 = nlabel = nweight = 0.f;
-      nslot = -1;
-#if SHINE_V3_IDPF
-      int4 tia = make_int4(0, 0, 0, 0), tib = tia;
-      if (nvalid) {
-        np = a.perm ? (long long)np2 : ni;
-        nslot = nslot2;  // requested one tile ago
-        const unsigned int sl1 = nslot >= 0 ? (unsigned int)nslot : 0u;
-        tia = lv_vals[2u * sl1];  // the next tile's corner ids: its row gathers will not wait for them
-        tib = lv_vals[2u * sl1 + 1u];
-        nx0 = __builtin_nontemporal_load(a.coord + 3 * np);
-        nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
-        nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
-        nlabel = __builtin_nontemporal_load(a.label + np);
-        if (EIK || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
-      }
-      nia = tia;
-      nib = tib;
-      nslot2 = -1;
-      if (ni2 < end && lvl_on) {
-        const long long p2 = a.perm ? (long long)np3 : ni2;
-        nslot2 = __builtin_nontemporal_load(a.slots + (a.pool_mode ? p2 : ni2) * L + g);
-      }
-      np2 = np3;
-      if (a.perm && ni2 + V3_TP < end) np3 = __builtin_nontemporal_load(a.perm + ni2 + V3_TP);
-#else
-      if (nvalid) {
-        np = a.perm ? (long long)np2 : ni;
-        const long long si = a.pool_mode ? np : ni;
-        if (lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
-        nx0 = __builtin_nontemporal_load(a.coord + 3 * np);
-        nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
-        nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
-        nlabel = __builtin_nontemporal_load(a.label + np);
-        if (EIK || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
-      }
-      if (a.perm && ni2 < end) np2 = __builtin_nontemporal_load(a.perm + ni2);
-#endif
-    }
-    // reduce-scatter of the per-level sums over the point's four lanes: lane g ends with features (2g, 2g+1)
-    float f2[2];
-    {
-      float h4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) h4[q] = xsum32(pf[q], pf[4 + q]);  // g < 2: features q, g >= 2: features 4 + q
-#pragma unroll
-      for (int t = 0; t < 2; ++t) f2[t] = xsum16(h4[t], h4[2 + t]);  // even g: t, odd g: 2 + t
-    }
-    float A2[2][3];  // eikonal build: d f_{2g + t} / d x_e of this lane's point (all levels summed)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) A2[t][0] = A2[t][1] = A2[t][2] = 0.f;
-    if (EIK) {
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        float h4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) h4[q] = xsum32(Ag[q][e], Ag[4 + q][e]);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) A2[t][e] = xsum16(h4[t], h4[2 + t]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
-    SHINE_STAMP(1)  // query
-
-    // ================================================================ phase 2: decoder forward (MFMA chain)
-    f32x4 c1[2], c2[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const float4 v1b = sb4[4 * m + g], v2b = sb4[8 + 4 * m + g];
-      c1[m][0] = v1b.x, c1[m][1] = v1b.y, c1[m][2] = v1b.z, c1[m][3] = v1b.w;
-      c2[m][0] = v2b.x, c2[m][1] = v2b.y, c2[m][2] = v2b.z, c2[m][3] = v2b.w;
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) c1[m] = mfma16(opa[V3_OPA1 + (2 * m + t) * 64], f2[t], c1[m]);
-    float h1[8], h2[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) h1[r] = fmaxf(c1[r >> 2][r & 3], 0.f);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) c2[m] = mfma16(opa[V3_OPA2 + (8 * m + ks) * 64], h1[ks], c2[m]);
-    float yp = 0.f;
-    float w3r[8];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const float4 v = sb4[16 + 4 * m + g];
-      w3r[4 * m] = v.x, w3r[4 * m + 1] = v.y, w3r[4 * m + 2] = v.z, w3r[4 * m + 3] = v.w;
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      h2[r] = fmaxf(c2[r >> 2][r & 3], 0.f);
-      yp = fmaf(w3r[r], h2[r], yp);
-    }
-    yp += __shfl_xor(yp, 16, 64);
-    const float y = yp + __shfl_xor(yp, 32, 64) + b3;
-    if (!EXT && valid && g == 0 && a.pred) __builtin_nontemporal_store(y, a.pred + po);
-    __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
-    SHINE_STAMP(2)  // decoder forward
-
-    // ================================================================ phase 3: loss
-    // BCEWithLogits(y, z) = max(y, 0) - y z + log1p(e), e = exp(-|y|); sigmoid(y) = 1 / (1 + e) or e / (1 + e) shares e.
-    // Hardware transcendentals (v_exp_f32, v_rcp_f32, v_log_f32: ~1 ulp) — errors ~1e-7, the contract is 1e-4.
-    float delta = 0.f;
-    if (EXT) {
-      if (valid) delta = a.ext_delta[po];
-    } else {
-      const float zt = fast_sigmoid(label * inv_sigma);
-      const float e = __builtin_amdgcn_exp2f(-1.44269504088896f * fabsf(y));
-      const float r = __builtin_amdgcn_rcpf(1.0f + e);
-      const float sg = y >= 0.f ? r : e * r;
-      if (valid) {
-        const float lw = a.weighted ? fabsf(wgt) : 1.0f;  // BCEWithLogitsLoss(weight=|weight|), utils/loss.py:18-19
-        if (g == 0) {
-          loss_acc += lw * (fmaxf(y, 0.f) - y * zt + 0.693147180559945f * __builtin_amdgcn_logf(1.0f + e));
-          cnt_acc += 1;
-        }
-        delta = lw * (sg - zt) * a.inv_n;
-      }
-    }
-    float sdf2[2];  // what the scatter multiplies the staged weights with: d loss / d f (BCE build), d y / d f (eikonal build)
-    if (!EIK) {
-    // ================================================================ phase 4: backward through the decoder
-    float d2[8], d1[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      d2[r] = h2[r] > 0.f ? delta * w3r[r] : 0.f;
-      dw3c[r] = fmaf(delta, h2[r], dw3c[r]);
-    }
-    if (g == 0) db3 += delta;
-    f32x4 e1[2] = {zero4(), zero4()}, e0 = zero4();
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) e1[m] = mfma16(opa[V3_OPA2T + (8 * m + ks) * 64], d2[ks], e1[m]);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) d1[r] = h1[r] > 0.f ? e1[r >> 2][r & 3] : 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) e0 = mfma16(opa[V3_OPA1T + ks * 64], d1[ks], e0);
-    sdf2[0] = e0[0], sdf2[1] = e0[1];  // d loss / d f for features 2g, 2g+1 of this lane's point
-    __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
-    SHINE_STAMP(3)  // loss + decoder backward
-
-    // ================================================================ phase 5: decoder weight grads (transposed MFMA)
-    if (a.decoder_grad_on && !(SHINE_V3_ABL & 2)) {
-      const int i16 = lane & 15;  // operand role: row / column i16 = lane & 15, points 4 kk .. 4 kk + 3 (kk = lane >> 4)
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {  // channel 16 (r >> 2) + 4 g + (r & 3)
-        t_wr[(16 * (r >> 2) + (r & 3)) * V3_TT] = d2[r];
-        t_wr[(32 + 16 * (r >> 2) + (r & 3)) * V3_TT] = h1[r];
-      }
-      wave_lds_fence();
-      {
-        float4 la[2], lb[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          la[m] = *reinterpret_cast<const float4*>(t_rd + (16 * m) * V3_TT);
-          lb[m] = *reinterpret_cast<const float4*>(t_rd + (32 + 16 * m) * V3_TT);
-          db2acc[m] += (la[m].x + la[m].y) + (la[m].z + la[m].w);  // db2 rides on the transposed operands
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 2; ++n) {  // dW2[out][in] += d2[out][k] h1[in][k]
-            accW2[m][n] = mfma16(la[m].x, lb[n].x, accW2[m][n]);
-            accW2[m][n] = mfma16(la[m].y, lb[n].y, accW2[m][n]);
-            accW2[m][n] = mfma16(la[m].z, lb[n].z, accW2[m][n]);
-            accW2[m][n] = mfma16(la[m].w, lb[n].w, accW2[m][n]);
-          }
-      }
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < 8; ++r) t_wr[(16 * (r >> 2) + (r & 3)) * V3_TT] = d1[r];
-      f_wr[32 * V3_TT] = f2[0];
-      f_wr[33 * V3_TT] = f2[1];
-      wave_lds_fence();
-      {
-        float4 la[2];
-        // B columns 0..7 = f, column 8 = ones: accW1[:, 8] accumulates db1 = sum_k d1[ch][k] in the spare MFMA lanes
-        float4 lb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i16 < F) lb = *reinterpret_cast<const float4*>(t_rd + 32 * V3_TT);
-        if (i16 == F) lb = make_float4(1.f, 1.f, 1.f, 1.f);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) la[m] = *reinterpret_cast<const float4*>(t_rd + (16 * m) * V3_TT);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {  // dW1[ch][feat] += d1[ch][k] f[feat][k]
-          accW1[m] = mfma16(la[m].x, lb.x, accW1[m]);
-          accW1[m] = mfma16(la[m].y, lb.y, accW1[m]);
-          accW1[m] = mfma16(la[m].z, lb.z, accW1[m]);
-          accW1[m] = mfma16(la[m].w, lb.w, accW1[m]);
-        }
-      }
-      wave_lds_fence();
-    }
-    __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
-    SHINE_STAMP(5)  // weight grads
-
-    } else {
-    // ================================================================ phase 4 (eikonal build): closed form, SURVEY.md §8a
-    // The decoder has ONE output, so everything the loss sends back is the eikonal chain scaled by the point's delta:
-    //   d2 = delta v2, d1 = delta v1, d loss_bce / d f = delta J     (v2 = m2 .* w3, v1 = m1 .* W2^T v2, J = W1^T v1 = dy/df)
-    // and the weight grads of both terms contract in ONE pass per matrix:
-    //   dW2 += v2 (x) (delta h1 + a1),  dW1 += v1 (x) (delta f + r),  db2 += sum delta v2,  db1 += sum delta v1.
-    if (g == 0) db3 += delta;
-    float v2[8], v1[8], a1[8], J2[2], r2[2], qv[3] = {0.f, 0.f, 0.f};
-    {
-      f32x4 ev[2] = {zero4(), zero4()}, ej = zero4();
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v2[r] = h2[r] > 0.f ? w3r[r] : 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) ev[m] = mfma16(opa[V3_OPA2T + (8 * m + ks) * 64], v2[ks], ev[m]);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v1[r] = h1[r] > 0.f ? ev[r >> 2][r & 3] : 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) ej = mfma16(opa[V3_OPA1T + ks * 64], v1[ks], ej);
-      J2[0] = ej[0], J2[1] = ej[1];  // d y / d f_{2g}, d y / d f_{2g+1}
-    }
-    float gx[3];
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {  // get_gradient(coord, pred) * sigma   (utils/tools.py:175-185, shine_batch.py:141-142)
-      float sm = fmaf(J2[1], A2[1][e], J2[0] * A2[0][e]);
-      sm = xsum32(sm, sm);  // all-reduce over the point's four lanes
-      sm = xsum16(sm, sm);
-      gx[e] = a.sigma * sm;
-    }
-    if (valid && g == 0 && a.grad_x) {
-      a.grad_x[3 * po] = gx[0];
-      a.grad_x[3 * po + 1] = gx[1];
-      a.grad_x[3 * po + 2] = gx[2];
-    }
-    if (valid && wgt > 0.f) {  // surface samples only (shine_batch.py:137,183)
-      const float gn = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
-      const float ee = 1.0f - gn;
-      if (g == 0) eik_acc += ee * ee;
-      const float coef = gn > 0.f ? (-2.0f * ee / gn) * (a.weight_e * inv_nsurf) : 0.f;  // norm's sub-gradient 0 at 0
-      qv[0] = coef * gx[0];
-      qv[1] = coef * gx[1];
-      qv[2] = coef * gx[2];
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) r2[t] = a.sigma * (A2[t][0] * qv[0] + A2[t][1] * qv[1] + A2[t][2] * qv[2]);
-    {
-      f32x4 t1[2] = {zero4(), zero4()}, t2[2] = {zero4(), zero4()};
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) t1[m] = mfma16(opa[V3_OPA1 + (2 * m + t) * 64], r2[t], t1[m]);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) a1[r] = h1[r] > 0.f ? t1[r >> 2][r & 3] : 0.f;  // (W1 r) .* m1
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) t2[m] = mfma16(opa[V3_OPA2 + (8 * m + ks) * 64], a1[ks], t2[m]);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float a2 = h2[r] > 0.f ? t2[r >> 2][r & 3] : 0.f;  // (W2 a1) .* m2
-        dw3c[r] += fmaf(delta, h2[r], a2);
-        db2c[r] = fmaf(delta, v2[r], db2c[r]);
-        db1c[r] = fmaf(delta, v1[r], db1c[r]);
-      }
-    }
-    sdf2[0] = J2[0], sdf2[1] = J2[1];
-    __builtin_amdgcn_sched_barrier(0);  // phase boundary
-    SHINE_STAMP(3)  // loss + decoder backward (eikonal chain)
-
-    // ================================================================ phase 5 (eikonal build): decoder weight grads
-    if (a.decoder_grad_on && !(SHINE_V3_ABL & 2)) {
-      const int i16 = lane & 15;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {  // channel 16 (r >> 2) + 4 g + (r & 3)
-        t_wr[(16 * (r >> 2) + (r & 3)) * V3_TT] = v2[r];
-        t_wr[(32 + 16 * (r >> 2) + (r & 3)) * V3_TT] = fmaf(delta, h1[r], a1[r]);
-      }
-      wave_lds_fence();
-      {
-        float4 la[2], lb[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          la[m] = *reinterpret_cast<const float4*>(t_rd + (16 * m) * V3_TT);
-          lb[m] = *reinterpret_cast<const float4*>(t_rd + (32 + 16 * m) * V3_TT);
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 2; ++n) {  // dW2[out][in] += v2[out][k] (delta h1 + a1)[in][k]
-            accW2[m][n] = mfma16(la[m].x, lb[n].x, accW2[m][n]);
-            accW2[m][n] = mfma16(la[m].y, lb[n].y, accW2[m][n]);
-            accW2[m][n] = mfma16(la[m].z, lb[n].z, accW2[m][n]);
-            accW2[m][n] = mfma16(la[m].w, lb[n].w, accW2[m][n]);
-          }
-      }
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < 8; ++r) t_wr[(16 * (r >> 2) + (r & 3)) * V3_TT] = v1[r];
-      f_wr[32 * V3_TT] = fmaf(delta, f2[0], r2[0]);
-      f_wr[33 * V3_TT] = fmaf(delta, f2[1], r2[1]);
-      wave_lds_fence();
-      {
-        float4 la[2];
-        float4 lb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i16 < F) lb = *reinterpret_cast<const float4*>(t_rd + 32 * V3_TT);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) la[m] = *reinterpret_cast<const float4*>(t_rd + (16 * m) * V3_TT);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {  // dW1[ch][feat] += v1[ch][k] (delta f + r)[feat][k]
-          accW1[m] = mfma16(la[m].x, lb.x, accW1[m]);
-          accW1[m] = mfma16(la[m].y, lb.y, accW1[m]);
-          accW1[m] = mfma16(la[m].z, lb.z, accW1[m]);
-          accW1[m] = mfma16(la[m].w, lb.w, accW1[m]);
-        }
-      }
-      wave_lds_fence();
-    }
-    // weights for the scatter, staged now that delta and q are known: row (level, corner) of this point receives
-    //   (delta w_c + sigma (d w_c / d x . q)) J      (BCE part delta J w_c, eikonal part sigma (dw_c/dx . q) J);
-    // a miss stages 0 (its eikonal terms would all land on the trash row, where they cancel: sum_c dw_c/dx = 0)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float dwc[3];
-      corner_dw(X, Y, Z, c, dwc);
-      const float cq = a.sigma * (dwc[0] * qv[0] + dwc[1] * qv[1] + dwc[2] * qv[2]);
-      st_w[c * V3_WP] = fmaf(delta, w[c], cq);  // a miss stages 0: w = 0 and dt = 0
-    }
-    if (g == 0) R2[V3_DL + o_pt] = delta;  // the trash rows need delta J (their weights sum to 1)
-    __builtin_amdgcn_sched_barrier(0);  // phase boundary
-    SHINE_STAMP(5)  // weight grads
-    }
-    // ================================================================ phase 6: feature-grad scatter (run-length)
-    f_wr[V3_DF] = sdf2[0];
-    f_wr[V3_DF + V3_DFP] = sdf2[1];
-    wave_lds_fence();
-    if (!(SHINE_V3_ABL & 4)) {
-      // this lane's trash level: the points that miss level sc
-      const unsigned int mymiss = sc < L ? (~(unsigned int)(hit64 >> (16 * (sc & 3))) & validmask) : 0u;
-      float dfr[V3_TP];
-#pragma unroll
-      for (int j = 0; j < V3_TP / 4; ++j) {
-        const float4 v = *reinterpret_cast<const float4*>(sc_df + 4 * j);
-        dfr[4 * j] = v.x;
-        dfr[4 * j + 1] = v.y;
-        dfr[4 * j + 2] = v.z;
-        dfr[4 * j + 3] = v.w;
-      }
-      // staged operands of one level: weights and ids of this lane's corner for the 16 points (8 x 16-B LDS reads).
-      // Level s + 1's are requested BEFORE level s is walked: the walk is a chain of scalar branches (basic blocks the
-      // scheduler cannot move loads across), and an LDS round trip per level was exposed (~150 cycles, 8 x per tile).
-      float4 wq[2][V3_TP / 4];
-      int4 iq[2][V3_TP / 4];
-#pragma unroll
-      for (int j = 0; j < V3_TP / 4; ++j) {
-        wq[0][j] = *reinterpret_cast<const float4*>(sc_w + 4 * j);
-        iq[0][j] = *reinterpret_cast<const int4*>(sc_ids + 4 * j);
-      }
-      {  // trash rows: the plain sum of d loss_bce / d f over the misses (the 8 corner weights of a missed node sum to 1)
-        float dl[EIK ? V3_TP : 1];
-        if (EIK) {  // the staged vector is J: d loss_bce / d f = delta J
-#pragma unroll
-          for (int j = 0; j < V3_TP / 4; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(R2 + V3_DL + 4 * j);
-            dl[4 * j] = v.x, dl[4 * j + 1] = v.y, dl[4 * j + 2] = v.z, dl[4 * j + 3] = v.w;
-          }
-        }
-#pragma unroll
-        for (int p2 = 0; p2 < V3_TP; ++p2) {
-          const unsigned int keep = 0u - ((mymiss >> p2) & 1u);
-          const float t = EIK ? dfr[p2] * dl[p2] : dfr[p2];
-          trash_sum += __uint_as_float(__float_as_uint(t) & keep);
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < L; ++s) {
-        if (s + 1 < L) {
-#pragma unroll
-          for (int j = 0; j < V3_TP / 4; ++j) {
-            wq[(s + 1) & 1][j] = *reinterpret_cast<const float4*>(sc_w + ((s + 1) * 8) * V3_WP + 4 * j);
-            iq[(s + 1) & 1][j] = *reinterpret_cast<const int4*>(sc_ids + ((s + 1) * 8) * V3_WP + 4 * j);
-          }
-        }
-        float* gbase = a.lv[s].grad;
-        if (gbase) {
-          float wr[V3_TP];
-          int idr[V3_TP];
-#pragma unroll
-          for (int j = 0; j < V3_TP / 4; ++j) {
-            const float4 v = wq[s & 1][j];
-            const int4 u = iq[s & 1][j];
-            wr[4 * j] = v.x, wr[4 * j + 1] = v.y, wr[4 * j + 2] = v.z, wr[4 * j + 3] = v.w;
-            idr[4 * j] = u.x, idr[4 * j + 1] = u.y, idr[4 * j + 2] = u.z, idr[4 * j + 3] = u.w;
-          }
-          int rid = run_id[s], rhit = run_hit[s];
-          float racc = run_acc[s];
-          const unsigned int cm = (unsigned int)(chg64 >> (16 * s)) & 0xFFFFu;
-          const unsigned int hm = (unsigned int)(hit64 >> (16 * s)) & 0xFFFFu;
-#if SHINE_V3_PREFIX
-          {
-            f32x16 wv, dv;
-            i32x16 iv;
-#pragma unroll
-            for (int p2 = 0; p2 < V3_TP; ++p2) wv[p2] = wr[p2], dv[p2] = dfr[p2], iv[p2] = idr[p2];
-            scatter_level_prefix<!(SHINE_V3_ABL & 1)>(wv, iv, dv, cm, hm, sq, gbase, MARK ? a.touched[s] : nullptr, rid, rhit, racc);
-          }
-#else
-#pragma unroll
-          for (int p2 = 0; p2 < V3_TP; ++p2) {
-            if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
-              if (rhit && !(SHINE_V3_ABL & 1)) atomic_add_f32(gbase + (unsigned int)rid, racc);  // scalar branch
-              racc = 0.f;
-              rid = (idr[p2] << 3) | sq;  // float offset of this lane's (corner row, feature)
-              rhit = (int)((hm >> p2) & 1u);
-              // the touched-row flags (unique(hierarchical_indices) without -1, for shine_regularize) are set here, at the run
-              // start of every hit node, by one lane per corner
-              if (MARK && rhit && a.touched[s] && sq == 0) a.touched[s][idr[p2]] = 1;
-            }
-            racc = fmaf(wr[p2], dfr[p2], racc);  // misses and padding lanes staged w = 0
-          }
-#endif
-          run_id[s] = rid;
-          run_hit[s] = rhit;
-          run_acc[s] = racc;
-        }
-      }
-    }
-    wave_lds_fence();
-    SHINE_STAMP(4)  // scatter
-  }
-
-  // ---- end of the wave's run: flush the open node runs
-#pragma unroll
-  for (int s = 0; s < L; ++s) {
-    float* gbase = a.lv[s].grad;
-    if (gbase && run_hit[s]) atomic_add_f32(gbase + (unsigned int)run_id[s], run_acc[s]);
-  }
-  __syncthreads();  // every wave is done with its staging region: it now holds the wave's partial vector
-  float* wvec = s_wave[wv];
-  if (sc < L) wvec[PART_TRASH + sc * 8 + sq] = trash_sum;
-  if (a.decoder_grad_on) {
-    const int jc = lane & 15, rr = lane >> 4;  // accumulator role: column jc, rows 4 rr + r
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * m + 4 * rr + r;
-        wvec[MLP_W2 + row * H + jc] = accW2[m][0][r];
-        wvec[MLP_W2 + row * H + 16 + jc] = accW2[m][1][r];
-        if (jc < F || (!EIK && jc == F)) wvec[jc < F ? MLP_W1 + row * F + jc : MLP_B1 + row] = accW1[m][r];  // BCE: column 8 of accW1 is db1
-        const float w3v = row16_sum(dw3c[4 * m + r]);  // channel 16 m + 4 g + r over the 16 points of the DPP row
-        if (pt == 0) wvec[MLP_W3 + 16 * m + 4 * g + r] = w3v;
-        if (EIK) {
-          const float b2v = row16_sum(db2c[4 * m + r]), b1v = row16_sum(db1c[4 * m + r]);
-          if (pt == 0) {
-            wvec[MLP_B2 + 16 * m + 4 * g + r] = b2v;
-            wvec[MLP_B1 + 16 * m + 4 * g + r] = b1v;
-          }
-        }
-      }
-    if (!EIK) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {  // channel 16 m + (lane & 15), the four point groups kk
-        float v = db2acc[m];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (lane < 16) wvec[MLP_B2 + 16 * m + lane] = v;
-      }
-    }
-    const float b3v = wave_sum(db3);
-    if (lane == 0) wvec[MLP_B3] = b3v;
-  }
-  {
-    const double ls = wave_sum_d((double)loss_acc), cs = wave_sum_d((double)cnt_acc);
-    const double es = EIK ? wave_sum_d((double)eik_acc) : 0.0;
-    if (lane == 0) {
-      atomicAdd(&s_loss[0], ls);
-      atomicAdd(&s_loss[1], cs);
-      if (EIK) atomicAdd(&s_loss[2], es);
-    }
-  }
-  SHINE_STAMP(6)  // flush
-  __syncthreads();
-  SHINE_STAMP(7)  // wait for the workgroup
-  if (PROF && lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a.prof[wave_g * 8 + k] = pc[k];
-  }
-  const int mlp_lo = a.decoder_grad_on ? 0 : SHINE_MLP_PARAMS;  // a frozen decoder has no sums to move
-  float* dst = a.partials + (long long)blockIdx.x * PART_STRIDE;
-  for (int idx = tid; idx < PART_TRASH + L * 8; idx += NT) {
-    float v = 0.f;
-    if (idx >= mlp_lo) {
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) v += s_wave[w][idx];
-    }
-    dst[idx] = v;
-  }
-  for (int idx = PART_TRASH + L * 8 + tid; idx < PART_FLOATS; idx += NT) dst[idx] = 0.f;
-  if (tid == 0) {
-    double* dl = reinterpret_cast<double*>(dst + PART_LOSS);
-    dl[0] = s_loss[0];
-    dl[1] = s_loss[1];
-    dl[2] = s_loss[2];
-  }
-  // cfg->defer_reduce: no reduction launch follows, so the iteration hooks (optimiser step count, regulariser accumulator)
-  // ride here — nothing in this launch reads either
-  if (a.defer_reduce && blockIdx.x == 0) {
-    if (tid == 0 && a.adam_state) adam_advance(a.adam_state, a.adam_b1, a.adam_b2);
-    if (tid == 64 && a.zero_f64) *a.zero_f64 = 0.0;
-  }
-#undef SHINE_STAMP
+  __shared__ StepShared<WAVES> sm;
+  step_body<L, WAVES, EIK, PROF, EXT, MARK>(a, sm, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // x[l] + y[l ^ 32] style exchanges through v_permlane32_swap / v_permlane16_swap: pins the lane maps xsum32 / xsum16 assume

@@ -1,6 +1,6 @@
-// shine_tile16.hpp — what the 16-point-tile fused-step kernels share (shine_step_v3.hip: one wave does every phase of a
-// tile; shine_step_v5.hip: role-specialised waves around per-SIMD LDS rings): the staging geometry, the pre-permuted
-// decoder operand image, and the cross-lane helpers (v_permlane{16,32}_swap reduce-scatter, DPP row moves).
+// shine_tile16.hpp — the 16-point-tile geometry of the fused step (shine_step_v3.hip: one wave does every phase of a tile):
+// the staging layout, the pre-permuted decoder operand image, and the cross-lane helpers (v_permlane{16,32}_swap
+// reduce-scatter, DPP row moves).
 #pragma once
 #include "shine_step_common.hpp"
 
@@ -51,14 +51,33 @@ __device__ __forceinline__ float xsum16(float x, float y) {
 __device__ __forceinline__ int row_last(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xF, 0xF, false); }
 __device__ __forceinline__ int row_prev(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x111, 0xF, 0xF, false); }
 
-// Per-workgroup setup shared by the 16-point-tile kernels: the decoder's A operands pre-permuted into 16x16x4 lane order
-// (lane l: row i = l & 15, k-group kg = l >> 4) and the bias / w3 vectors.  Branch-free source select, fully unrolled: the
-// loads of a thread are all in flight together (one L2 round trip).  s_opA: V3_OPTOTAL floats, s_bias: 100 floats.
+// LDS of one workgroup of the fused step: the decoder operand image, biases / w3 / b3, the loss accumulators and one staging
+// region per wave (which ends its life as the wave's partial vector).
+template <int WAVES>
+struct StepShared {
+  float opA[V3_OPTOTAL];
+  float bias[100];
+  double loss[4];
+  float wave[WAVES][V3_WAVE_FLOATS];
+};
+
+// Per-workgroup setup: the decoder's A operands pre-permuted into 16x16x4 lane order (lane l: row i = l & 15, k-group
+// kg = l >> 4) and the bias / w3 vectors.  Branch-free source select, fully unrolled: the loads of a thread are all in flight
+// together (one L2 round trip).  s_opA: V3_OPTOTAL floats, s_bias: 100 floats.  The values are loaded into registers by
+// decoder_operands_issue (so that the caller can put other loads in flight behind them) and stored by decoder_operands_store.
 template <int NT>
-__device__ __forceinline__ void load_decoder_operands(const V1Args& a, float* s_opA, float* s_bias, int tid) {
+struct OperandRegs {
+  float v[(V3_OPTOTAL + NT - 1) / NT];
+  float b[3];
+  float b3;
+};
+
+template <int NT>
+__device__ __forceinline__ void decoder_operands_issue(const V1Args& a, OperandRegs<NT>& R, int tid) {
 #pragma unroll
   for (int it = 0; it < (V3_OPTOTAL + NT - 1) / NT; ++it) {
     const int idx = it * NT + tid;
+    R.v[it] = 0.f;
     if (idx < V3_OPTOTAL) {
       const int t = idx >> 6, l = idx & 63, i = l & 15, kg = l >> 4;
       const float* src;
@@ -77,60 +96,31 @@ __device__ __forceinline__ void load_decoder_operands(const V1Args& a, float* s_
         zero = rp >= 2;
       }
       const float v = *src;
-      s_opA[idx] = zero ? 0.f : v;
+      R.v[it] = zero ? 0.f : v;
     }
   }
+  R.b[0] = R.b[1] = R.b[2] = R.b3 = 0.f;
   if (tid < 32) {
-    s_bias[tid] = a.mlp[1][tid];
-    s_bias[32 + tid] = a.mlp[3][tid];
-    s_bias[64 + tid] = a.mlp[4][tid];
+    R.b[0] = a.mlp[1][tid];
+    R.b[1] = a.mlp[3][tid];
+    R.b[2] = a.mlp[4][tid];
   }
-  if (tid == 0) s_bias[96] = a.mlp[5][0];
+  if (tid == 0) R.b3 = a.mlp[5][0];
 }
 
-// ---- feature-grad scatter of ONE level of ONE 16-point tile, lane = (corner, feature): prefix-sum form of the run-length walk.
-// The serial walk (test a run-start bit, branch, v_fmac — 16 times per level) is a chain of scalar compare -> taken branch ->
-// dependent VALU: ~60 cycles per point in the role-specialised kernel's scatter wave (profiles/r03_ab_experiments.txt block 3).
-// Here the 16 products are accumulated unconditionally into 16 REGISTERS P[p] = sum_{p' <= p} w[p'] df[p'] (16 v_fma, no
-// scalar work), and only the node runs that END inside the tile are visited — a wave-uniform loop over the set bits of the
-// run-start mask — taking  sum(run) = P[end - 1] - P[start - 1]  with a uniform dynamic register index (s_set_gpr_idx: no
-// LDS, no scratch).  A tile without a run start (the usual case at the coarse levels) is 16 fma and one add.
-// Rounding: a run's sum is a difference of two prefix sums of at most 16 terms — ~1e-6 of the largest term, against the
-// 1e-4-of-max-abs contract; the run's first partial (carried in from earlier tiles) is added exactly as before.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-
-template <bool ATOMICS>
-__device__ __forceinline__ void scatter_level_prefix(const f32x16& wr, const i32x16& idr, const f32x16& dfr, unsigned int cm,
-                                                     unsigned int hm, int sq, float* gbase, unsigned char* tb, int& rid,
-                                                     int& rhit, float& racc) {
-  f32x16 P;
-  P[0] = wr[0] * dfr[0];
+template <int NT>
+__device__ __forceinline__ void decoder_operands_store(const OperandRegs<NT>& R, float* s_opA, float* s_bias, int tid) {
 #pragma unroll
-  for (int p = 1; p < V3_TP; ++p) P[p] = fmaf(wr[p], dfr[p], P[p - 1]);  // misses and padding lanes staged w = 0
-  if (cm == 0u) {  // the open run covers the whole tile
-    racc += P[V3_TP - 1];
-    return;
+  for (int it = 0; it < (V3_OPTOTAL + NT - 1) / NT; ++it) {
+    const int idx = it * NT + tid;
+    if (idx < V3_OPTOTAL) s_opA[idx] = R.v[it];
   }
-  unsigned int m = cm;
-  float prev = 0.f;
-  do {
-    const int st = __builtin_ctz(m);  // wave-uniform: a new node (or a run of misses) starts at point st
-    m &= m - 1u;
-    // (the index is forced into an SGPR: behind a VALU-derived select the compiler emits a waterfall loop around the move)
-    const int i0 = __builtin_amdgcn_readfirstlane(st > 0 ? st - 1 : 0);
-    float pv = P[i0];
-    if (st == 0) pv = 0.f;
-    if (rhit && ATOMICS) atomic_add_f32(gbase + (unsigned int)rid, racc + (pv - prev));  // close the open run
-    racc = 0.f;
-    prev = pv;
-    const int id = idr[st];
-    rid = (id << 3) | sq;  // float offset of this lane's (corner row, feature)
-    rhit = (int)((hm >> st) & 1u);
-    // touched-row flags (unique(hierarchical_indices) without -1): set at the run start of every hit node, one lane per corner
-    if (tb && rhit && sq == 0) tb[id] = 1;
-  } while (m);
-  racc = P[V3_TP - 1] - prev;  // the partial of the run that stays open
+  if (tid < 32) {
+    s_bias[tid] = R.b[0];
+    s_bias[32 + tid] = R.b[1];
+    s_bias[64 + tid] = R.b[2];
+  }
+  if (tid == 0) s_bias[96] = R.b3;
 }
 
 }  // namespace shine

@@ -396,13 +396,10 @@ class RowGatherReducer(GradReducer):
             if work is not None:
                 work.wait()  # the current stream waits for the collective (no host block on the NCCL / RCCL backend)
             if flat.is_cuda:
+                # tail_n is part of the message stride for EVERY message; the later micro-batches of a step add their tails
                 _lib.check(_lib.lib().shine_rows_unpack_add(gathered.data_ptr(), world, self.capacity, flat.data_ptr(), tail_off,
-                                                            self.tail_n if first else 0, self._overflow.data_ptr(),
+                                                            self.tail_n, 0 if first else 1, self._overflow.data_ptr(),
                                                             _lib.current_stream_handle()), "shine_rows_unpack_add")
-                if not first and self.tail_n:  # later micro-batches ADD their tails
-                    words = self._words()
-                    g = gathered.view(world, words)[:, words - self.tail_n:].view(torch.float32)
-                    flat[tail_off: tail_off + self.tail_n] += g.sum(dim=0)
             else:
                 self._unpack_torch(flat, gathered, world, tail_off, first)
             first = False

@@ -85,7 +85,8 @@ class GraphedIteration:
         dev_key = str(pool.coord.device)
         self.ran_eager = bool(eager_first) or dev_key not in _WARMED or not (self.fold and hasattr(opt, "prepare_graph_safe"))
         if self.ran_eager:
-            self._body()  # eager warm-up: allocates workspaces, optimiser state and device counters outside the capture
+            # eager warm-up: allocates workspaces, optimiser state and device counters outside the capture
+            self.loss, self.reg = self._body()
             _WARMED.add(dev_key)
         else:
             self.opt.prepare_graph_safe()
@@ -100,12 +101,14 @@ class GraphedIteration:
         # boundaries saved outweigh the nodes captured (a frame of 50 iterations: unroll 5, bench.py --unroll).  Both graphs
         # are captured when first needed: a frame whose length is a multiple of `unroll` never captures the one-iteration graph.
         self.unroll = max(1, int(unroll))
+        # `loss` / `reg` always name the outputs of the launch that ran LAST (eager, one-iteration graph or unrolled graph:
+        # each capture has its own output tensors)
         self.graph = self.graph_k = None
-        self.loss_k = self.reg_k = None
+        self._out_1 = self._out_k = None
 
     def _graph_1(self):
         if self.graph is None:
-            self.graph, (self.loss, self.reg) = _capture(self._body)
+            self.graph, self._out_1 = _capture(self._body)
         return self.graph
 
     def _graph_unrolled(self):
@@ -116,7 +119,7 @@ class GraphedIteration:
                     out = self._body()
                 return out
 
-            self.graph_k, (self.loss_k, self.reg_k) = _capture(body_k)
+            self.graph_k, self._out_k = _capture(body_k)
         return self.graph_k
 
     def _body(self):
@@ -157,20 +160,19 @@ class GraphedIteration:
         if self.octree._tables_epoch != self._epoch:
             raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
         self._graph_1().replay()
+        self.loss, self.reg = self._out_1
         return self.loss
 
     def run(self, n_iters: int):
         """n_iters iterations: replays of the `unroll`-iteration graph, the remainder one by one.  Returns the last loss."""
         if self.octree._tables_epoch != self._epoch:
             raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
-        loss = self.loss
         k = self.unroll if self.unroll > 1 else 0
         while k and n_iters >= k:
             self._graph_unrolled().replay()
-            loss = self.loss_k
-            self.loss, self.reg = self.loss_k, self.reg_k
+            self.loss, self.reg = self._out_k
             n_iters -= k
         for _ in range(n_iters):
             self._graph_1().replay()
-            loss = self.loss
-        return loss
+            self.loss, self.reg = self._out_1
+        return self.loss

@@ -39,8 +39,8 @@ class StepOptions:
     zero_f64: Optional[torch.Tensor] = None     # one float64 element cleared by the step (the regulariser's accumulator)
     next_draw: Optional[object] = None          # SortedPool.next_draw(...): the first pass of the NEXT large sorted draw rides on
                                                 # the step's reduction launch; complete it with pool.draw(..., pass1_done=True)
-    kernel_variant: int = 0           # 0 the fused step; tests / tools: 1 the lane-per-point reference kernel, 5 the
-                                      # role-specialised experimental kernel (both in libshine_check.so)
+    kernel_variant: int = 0           # 0 the fused step; tests / tools: 1 the lane-per-point reference kernel
+                                      # (libshine_check.so)
 
 
 def eik_needs_count(opts) -> bool:
@@ -153,7 +153,7 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
     n = idx.numel() if pool_mode else coord.shape[0]
     dev = coord.device
     variant = int(opts.kernel_variant) & 0xff
-    if not pool_mode and slots is None and variant != 1 and octree.featured_level_num <= 4:
+    if not pool_mode and slots is None and variant != 1:
         # a batch without a plan (what the reference's get_batch hands over): neighbouring lanes would hit unrelated nodes and
         # the fused kernel takes the hash slots from the plan — order it by octree node and look the slots up first
         # (shine_plan_batch: 3 small launches; measured at 2^18 points x 4 levels 320 -> 143 us for the whole call against
@@ -196,7 +196,7 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
     if eik and n_surf.numel() > 1:  # the sampler's per-block partial counts (SortedPool.draw(surf_parts=...))
         if n_surf.dtype != torch.int64 or not n_surf.is_contiguous():
             raise ValueError("n_surf parts must be a contiguous int64 tensor")
-        if (int(opts.kernel_variant) & 0xff) in (1, 5) or slots is None:
+        if (int(opts.kernel_variant) & 0xff) == 1 or slots is None:
             n_surf = n_surf.sum()  # the check library's kernels take one count
         else:
             cfg.n_surf_parts = int(n_surf.numel())
@@ -220,9 +220,12 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         pending.clear()
         pending.update(cfg=cfg, n=n, workspace=ws, n_surf=n_surf, loss_parts=loss_parts, dec_grad=bool(dec_grad),
                        octree=octree, decoder=decoder)
-    # the product library serves kernel_variant 0 / 4 on <= 4 levels; the reference kernel (1), the experimental kernel (5)
-    # and deeper trees need the check library (tests / tools)
-    library = _lib.check_lib() if (variant in (1, 5) or octree.featured_level_num > 4) else _lib.lib()
+    # the product library trains on <= 4 featured levels (every shipped yaml: 3 or 4) with kernel_variant 0 / 4; the
+    # lane-per-point reference kernel (1: any batch, <= 8 levels) is the check library's — tests / tools ask for it by name
+    if variant != 1 and octree.featured_level_num > 4:
+        raise NotImplementedError("the fused step handles tree_level_feat <= 4 (every shipped config); deeper trees only run "
+                                  "on the check library's reference kernel (StepOptions.kernel_variant = 1, tests / tools)")
+    library = _lib.check_lib() if variant == 1 else _lib.lib()
     _lib.check(
         library.shine_train_step(
             t.handle, C.byref(cfg), coord.data_ptr(), sdf_label.data_ptr(),
@@ -239,7 +242,7 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
             _lib.ptr_array([x.data_ptr() for x in touched]) if touched is not None else None,
             ws.data_ptr(), ws.numel(), _stream(),
         ),
-        "shine_train_step",
+        "shine_train_step", library,
     )
     if opts.next_draw is not None and pending is None and getattr(opts.next_draw, "_pool", None) is not None:
         opts.next_draw._pool._rider_for = int(opts.next_draw.n)  # its reduction launch carried that draw's first pass

@@ -29,6 +29,7 @@ class FusedAdam:
         self.state = {}
         self._age = {}  # per-tensor step count, like torch.optim.Adam's state[p]["step"] (bias correction is per tensor)
         self._dev = None  # (step_state int64[8], lr float[n]) for graph-replayable steps
+        self._dev_params = []  # the tensors those steps update (the set the device-side counter counts for)
 
     def _tensors(self):
         out = []
@@ -64,7 +65,6 @@ class FusedAdam:
         """Optimiser steps so far (host counter, or the device counter once graph-replayable steps were used)."""
         return int(self._dev[0][0].item()) if self._dev is not None else self.step_count
 
-    @torch.no_grad()
     def device_state(self):
         """The device-side step state of graph-replayable steps (int64[8]; None before the first such step): hand it to the
         fused step (StepOptions.adam_state) and the step's reduction launch advances it — then call step(..., advanced=True)."""
@@ -79,6 +79,18 @@ class FusedAdam:
         return torch.tensor([t, 0, bits(float(self.betas[0]) ** t), bits(float(self.betas[1]) ** t), 0, 0, 0, 0],
                             dtype=torch.int64, device=dev)
 
+    def _fold_device_steps(self):
+        """Fold the steps a graph took on the device back into the host counters (before the device state is dropped or
+        re-made): only the tensors that were part of the device-state set took those steps — a tensor that was frozen
+        meanwhile keeps its age, like torch.optim.Adam's per-parameter state["step"]."""
+        taken = self.steps_taken()
+        for p in self._dev_params:
+            self._age[p] = self._age.get(p, 0) + (taken - self.step_count)
+        self.step_count = taken
+        self._dev = None
+        self._dev_params = []
+
+    @torch.no_grad()
     def step(self, zero_grad=False, graph_safe=False, advanced=False):
         """`graph_safe`: step counter and learning rates are read from device memory (shine_adam_step_dev), so a captured
         HIP graph of this call performs step t, t+1, ... on successive replays.  Do not mix with eager steps afterwards
@@ -98,11 +110,7 @@ class FusedAdam:
                 # the set of tensors that receive grads changed while the device-side counter was live (e.g. the decoder was
                 # frozen / unfrozen): fold the steps the graph took back into the host counters before the state is re-made,
                 # or the bias correction would silently restart from the stale host count
-                taken = self.steps_taken()
-                for p in list(self._age):
-                    self._age[p] += taken - self.step_count
-                self.step_count = taken
-                self._dev = None
+                self._fold_device_steps()
                 ages = [self._age.get(t[0], 0) for t in ts]
                 if len(set(ages)) != 1 or ages[0] != self.step_count:
                     raise NotImplementedError("graph-replayable FusedAdam steps need all tensors to have the same age "
@@ -110,6 +118,7 @@ class FusedAdam:
             if self._dev is None:
                 # int64[8]: [0] steps taken, [1] the step's bias corrections; the rest is reserved (zeros)
                 self._dev = (self._make_dev_state(dev), torch.tensor([t[3] for t in ts], dtype=torch.float32, device=dev))
+                self._dev_params = [t[0] for t in ts]
             for p, m, v, _, _ in ts:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
                     raise ValueError("FusedAdam needs contiguous CUDA float32 parameters and grads")
@@ -126,11 +135,7 @@ class FusedAdam:
             )
             return
         if self._dev is not None:  # continue the count a graph advanced on the device
-            taken = self.steps_taken()
-            for t in ts:
-                self._age[t[0]] = self._age.get(t[0], 0) + (taken - self.step_count)
-            self.step_count = taken
-            self._dev = None
+            self._fold_device_steps()
             ages = [self._age.get(t[0], 0) for t in ts]
         self.step_count += 1
         if len(set(ages)) > 1:  # torch.optim.Adam semantics: one launch per distinct age (normally there is one)
@@ -191,12 +196,10 @@ def _prepare_graph_safe(self):
         raise NotImplementedError("graph-replayable FusedAdam steps need all tensors to have the same age")
     if self._dev is None or self._dev[1].numel() != len(ts):
         if self._dev is not None:
-            taken = self.steps_taken()
-            for p in list(self._age):
-                self._age[p] += taken - self.step_count
-            self.step_count = taken
+            self._fold_device_steps()
         dev = ts[0][0].device
         self._dev = (self._make_dev_state(dev), torch.tensor([t[3] for t in ts], dtype=torch.float32, device=dev))
+        self._dev_params = [t[0] for t in ts]
     return self._dev[0]
 
 

@@ -108,20 +108,21 @@ def test_dropin_registers_the_reference_import_paths():
 
 def test_product_library_holds_the_fused_step_only_and_the_check_library_the_rest():
     """the product library ships ONE fused-step kernel generation.  The lane-per-point reference kernel
-    (kernel_variant 1) and the experimental role-specialised kernel (5) live in libshine_check.so, which tests / tools load
-    explicitly; the product's dispatcher refuses those variants (and unplanned batches) instead of silently falling back."""
+    (kernel_variant 1) lives in libshine_check.so, which tests / tools load explicitly; the product's dispatcher refuses that
+    variant (and unplanned batches) instead of silently falling back.  Round 4 deleted the role-specialised experiment
+    (kernel_variant 5, a losing A/B of round 3) from the tree."""
     from shine_mapping_amd import _lib, build
 
     build.build(verbose=False)
     prod, chk = ctypes.CDLL(build.LIB), ctypes.CDLL(build.CHECK_LIB)
-    assert hasattr(prod, "shine_train_step_v3") and not hasattr(prod, "shine_train_step_v0") and not hasattr(prod, "shine_train_step_v5")
-    assert hasattr(chk, "shine_train_step_v0") and hasattr(chk, "shine_train_step_v5") and hasattr(chk, "shine_train_step_v3")
-    for gone in ("shine_train_step_v1", "shine_train_step_v2"):
+    assert hasattr(prod, "shine_train_step_v3") and not hasattr(prod, "shine_train_step_v0")
+    assert hasattr(chk, "shine_train_step_v0") and hasattr(chk, "shine_train_step_v3")
+    for gone in ("shine_train_step_v1", "shine_train_step_v2", "shine_train_step_v5"):
         assert not hasattr(prod, gone) and not hasattr(chk, gone)
     cfg = _lib.StepConfig()
     cfg.n_levels, cfg.max_level = 3, 12
     lib = _lib.lib()
-    for variant, word in ((1, b"check library"), (5, b"check library"), (0, b"plan")):
+    for variant, word in ((1, b"check library"), (5, b"unknown kernel_variant"), (0, b"plan")):
         cfg.kernel_variant = variant
         rc = lib.shine_train_step(None, ctypes.byref(cfg), None, None, None, None, None, None, 16, None, None, None, None,
                                   None, None, None, None, None, None, 0, None)

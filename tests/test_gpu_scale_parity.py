@@ -27,8 +27,7 @@ def _workload(kind, levels, frames=8, seed=21, **over):
 # BASELINE.json config 2 (2^18 points, 4-level octree, BCE) and config 3 (2^20 points, L=3, eikonal), each with a ragged
 # tail (+37 / +1) so that the last tile is partial.  Reference: shine_batch.py:115-209.
 @pytest.mark.parametrize("kind,levels,n,variant", [("maicity", 4, (1 << 18) + 37, 0), ("maicity", 3, (1 << 16) + 5, 0),
-                                                   ("kitti", 3, (1 << 20) + 1, 0),
-                                                   ("maicity", 4, (1 << 18) + 37, 5), ("kitti", 3, (1 << 20) + 1, 5)])
+                                                   ("kitti", 3, (1 << 20) + 1, 0)])
 def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n, variant):
     from oracle import shine_oracle as so
     from shine_mapping_amd import StepOptions, fused_train_step
@@ -92,11 +91,10 @@ def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n, variant
     assert all(float(p[-1].abs().max()) == 0.0 for p in octree.hier_features)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5])
+@pytest.mark.parametrize("variant", [0, 1])
 def test_every_kernel_is_pinned_to_the_goldens(golden, variant):
     """kernel_variant 1 (the check library's lane-per-point kernel) is the on-device cross-check of other tests: it must itself
-    match the reference's recorded outputs, like the fused step (0: the product kernel, the batch planned automatically) and
-    the experimental role-specialised kernel (5, check library)."""
+    match the reference's recorded outputs, like the fused step (0: the product kernel, the batch planned automatically)."""
     from shine_mapping_amd import fused_train_step
 
     cfg, octree, dec = product_from_golden(golden)
@@ -152,7 +150,7 @@ def test_sharded_hip_steps_sum_to_the_full_batch_golden(name, shards):
         assert rel_err(p.grad, r) <= TOL
 
 
-@pytest.mark.parametrize("variant", [0, 5])
+@pytest.mark.parametrize("variant", [0])
 def test_pool_mode_regulariser_marks_the_drawn_rows(variant):
     """FeatureOctree.cal_regularization (model/feature_octree.py:246-255) after a POOL-mode step: the touched-row flags
     must be those of the drawn batch (the pool's slot table is indexed by sample id), so value and gradient of the
@@ -170,7 +168,7 @@ def test_pool_mode_regulariser_marks_the_drawn_rows(variant):
     idx = sp.draw(300)  # a sparse draw: the first 300 pool entries touch other rows than these
     touched = touched_flags(octree)
     sopts = step_options(fx)
-    sopts.kernel_variant = variant  # 0: k_mark_touched pass in front of the step; 5: flags set by the scatter waves
+    sopts.kernel_variant = variant  # 0: flags set by the scatter of the MARK build (BCE) / a marking pass in front (eikonal)
     fused_train_step(octree, dec, None, None, None, sopts, pool=sp, idx=idx, touched=touched)
     L = cfg.tree_level_feat
     c, _, _ = sp.get_batch(idx)
@@ -459,7 +457,7 @@ def test_ragged_unplanned_batches_are_planned_and_match_the_oracle(n, variant):
         assert rel_err(p.grad, r) <= TOL
 
 
-@pytest.mark.parametrize("mode", ["planned", "plain", "pool", "planned-v5", "pool-v5"])
+@pytest.mark.parametrize("mode", ["planned", "plain", "pool"])
 @pytest.mark.parametrize("name", ["maicity_bce_L4", "kitti_eik_L3"])
 def test_weighted_bce_matches_oracle(name, mode):
     """loss_weight_on (utils/loss.py:18-19, shine_batch.py:172-174): BCEWithLogitsLoss(weight=|weight|).  Planned and pool
@@ -477,8 +475,6 @@ def test_weighted_bce_matches_oracle(name, mode):
     w = fx["weight"] * (0.25 + 1.5 * torch.rand_like(fx["weight"]))  # keeps the sign (surface / free space), varies |w|
     opts = step_options(fx)
     opts.loss_weight_on = True
-    if mode.endswith("-v5"):
-        mode, opts.kernel_variant = mode[:-3], 5
     if mode == "pool":
         octree._require_tables(with_ranks=True)
         sp = SortedPool(octree, c.cuda(), l.cuda(), w.cuda(), seed=4)
@@ -500,14 +496,13 @@ def test_weighted_bce_matches_oracle(name, mode):
         assert rel_err(p.grad, r) <= TOL
 
 
-@pytest.mark.parametrize("variant", [0, 5])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("levels", [1, 2, 3, 4])
 @pytest.mark.parametrize("eik", [False, True])
 @pytest.mark.parametrize("n", [1, 17, 300, 4099, 40000])
 def test_planned_ragged_batches_on_the_point_level_kernel(n, eik, levels, variant):
-    """kernel_variant 0 (shine_step_v3.hip: one wave per tile) and 5 (check/shine_step_v5.hip: role-specialised waves) on planned
-    batches of awkward sizes and every level count: partial tiles, waves / pipelines without tiles, every workgroup shape,
-    lanes of levels the tree does not have."""
+    """The fused step (shine_step_v3.hip: one wave per tile) on planned batches of awkward sizes and every level count: partial
+    tiles, waves without tiles, every workgroup shape, lanes of levels the tree does not have."""
     from oracle import shine_oracle as so
     from shine_mapping_amd import Decoder, FeatureOctree, StepOptions, dp, fused_train_step, synth
 
@@ -778,8 +773,6 @@ def test_step_adds_up_the_surface_count_parts(n):
     else:
         assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0])
         assert all(rel_err(x, y) <= TOL for x, y in zip(a[3], b[3]))
-    c = run(parts, variant=5)  # the check library's kernel takes one count: the Python layer adds the parts up for it
-    assert abs_err(c[1], b[1]) <= TOL and abs(c[0] - b[0]) <= TOL * max(1.0, abs(b[0]))
 
 
 @pytest.mark.gpu
@@ -858,6 +851,60 @@ def test_own_rows_all_gather_device_path(cap):
     assert torch.equal(a[4 + 9 * capr:], b[4 + 9 * capr:])                   # tail
     for p, q in zip(feats + mlp, cpu_feats + cpu_mlp):
         assert torch.equal(p.grad.cpu(), q.grad)
+
+
+@pytest.mark.gpu
+def test_own_rows_all_gather_two_micro_batches_on_the_device():
+    """dp.RowGatherReducer on CUDA tensors with an unfrozen decoder (tail_n > 0) and TWO micro-batches of one step —
+    exchange(finish=False), then exchange() — between two ranks whose messages DIFFER (rank 1 = rank 0's rows and tail x 3).
+    Every message, also the second micro-batch's, carries its tail, so the per-rank stride of shine_rows_unpack_add is the
+    same for all of them (round 3 passed tail_n = 0 for the later ones: rank 1 was then read inside rank 0's tail)."""
+    from shine_mapping_amd import dp
+
+    class TwoRanks:
+        class ReduceOp:
+            MAX = "max"
+
+        def get_world_size(self, group=None):
+            return 2
+
+        def all_reduce(self, t, op=None, group=None):
+            pass
+
+        def all_gather_into_tensor(self, out, inp, group=None):
+            o = out.view(2, -1)
+            o[0].copy_(inp)
+            o[1].copy_(inp)
+            pay = o[1][4 + self.cap:].view(torch.float32)  # values and tail of "rank 1"
+            pay.mul_(3.0)
+
+    torch.manual_seed(1)
+    rows = [37, 1000, 20001]
+    feats = [torch.nn.Parameter(torch.zeros(r + 1, 8, device="cuda")) for r in rows]
+    mlp = [torch.nn.Parameter(torch.zeros(s, device="cuda")) for s in (256, 32, 1024, 32, 32, 1)]
+    for q in feats + mlp:
+        q.grad = torch.zeros_like(q)
+    fake = TwoRanks()
+    red = dp.RowGatherReducer(feats, mlp, fake, capacity_rows=8192)
+    fake.cap = red.capacity
+    want = [torch.zeros_like(q) for q in feats + mlp]
+    for mb, frac in enumerate((0.2, 0.1)):
+        for k, (q, f, r) in enumerate(zip(feats, red.flags, rows)):
+            m = torch.rand(r + 1, device="cuda") < frac
+            m[r] = True
+            g = torch.randn_like(q) * m[:, None]
+            q.grad += g
+            want[k] += 4.0 * g
+            f[m] = 1
+        for k, q in enumerate(mlp):
+            g = torch.randn_like(q)
+            q.grad += g
+            want[3 + k] += 4.0 * g
+        red.exchange(finish=(mb == 1))
+    torch.cuda.synchronize()
+    assert not red.overflowed()
+    for q, w in zip(feats + mlp, want):
+        assert float((q.grad - w).abs().max()) <= 1e-5 * float(w.abs().max())
 
 
 @pytest.mark.gpu

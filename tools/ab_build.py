@@ -37,6 +37,8 @@ if only:
     CASES = tuple(c for c in CASES if (c[0], str(c[2])) in want)
 else:
     CASES = CASES[:2]
+if os.environ.get("AB_POINTS"):  # e.g. AB_POINTS=4096: the reference's own batch size (every shipped yaml)
+    CASES = tuple((k, int(os.environ["AB_POINTS"]), lv) for k, _, lv in CASES)
 for kind, pts, lv in CASES:
     wl = synth.build_workload(kind, frames=60, device="cuda", seed=42, tree_level_feat=lv)
     octree, dec, cfg = wl.octree, wl.decoder, wl.cfg

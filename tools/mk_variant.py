@@ -3,7 +3,7 @@
 
     python tools/mk_variant.py NAME [-DMACRO=1 ...] [shine_step_v3.hip ...]
 
-recompiles the named sources (default: shine_step_v3.hip; files of csrc/check/ by their bare name) with the extra flags,
+recompiles the named sources (default: shine_step_v3.hip) with the extra flags,
 links them with the other objects of the current build (shine_mapping_amd/build/*.o) and writes tools/ab/lib_NAME.so
 (git-ignored; it travels with the gpurun snapshot)."""
 import os
@@ -20,12 +20,10 @@ srcs = [a for a in sys.argv[2:] if a.endswith(".hip")] or ["shine_step_v3.hip"]
 b.build(verbose=False)
 out_dir = os.path.join(ROOT, "tools", "ab")
 os.makedirs(out_dir, exist_ok=True)
-# a variant has the composition of the CHECK library (product objects + csrc/check/*.hip + the training build of
-# shine_step_v0.hip), so kernel_variant 1 / 5 work against it too
+# a variant has the composition of the CHECK library (product objects, shine_step_v0.hip in its training build), so
+# kernel_variant 1 works against it too
 jobs = [(os.path.join(b.CSRC, f), os.path.join(b.OBJDIR, f.replace(".hip", ".o")), [], f) for f in b.sources()
         if f != "shine_step_v0.hip"]
-jobs += [(os.path.join(b.CHECK_DIR, f), os.path.join(b.OBJDIR, "check_" + f.replace(".hip", ".o")), [], f)
-         for f in sorted(os.listdir(b.CHECK_DIR)) if f.endswith(".hip")]
 jobs.append((os.path.join(b.CSRC, "shine_step_v0.hip"), os.path.join(b.OBJDIR, "check_shine_step_v0_train.o"),
              ["-DSHINE_V0_TRAIN=1"], "shine_step_v0.hip"))
 objs = []
