@@ -179,9 +179,12 @@ def cpu_baseline(wl, seconds=12.0, n=4096, max_iters=400):
     }
 
 
-def gpu_iteration_n4096(wl, spool_seed, iters=300, n=4096):
-    """The same iteration definition on the GPU at the same N: one captured HIP graph {sorted draw, fused step, fused
-    dense Adam (clears the grads)} replayed (loop.GraphedIteration) — the like-for-like partner of cpu_baseline."""
+def gpu_iteration_n4096(wl, spool_seed, iters=300, n=4096, active_rows=True):
+    """The same iteration definition on the GPU at the same N: one captured HIP graph {fused step, {partial sums, Adam, grads
+    cleared, next sorted draw}} replayed (loop.GraphedIteration) — the like-for-like partner of cpu_baseline.  Adam is torch's
+    dense Adam in exact arithmetic: rows that have had no gradient since the optimiser was created are skipped unread
+    (m = v = g = 0 leaves them bit for bit unchanged), so the time depends on how much of the map the iterations so far have
+    touched — reported for the first and the last third of the window, with the fraction of rows still untouched."""
     from shine_mapping_amd import StepOptions
     from shine_mapping_amd.loop import GraphedIteration
     from shine_mapping_amd.optim import setup_optimizer
@@ -198,20 +201,28 @@ def gpu_iteration_n4096(wl, spool_seed, iters=300, n=4096):
     opts = StepOptions(sigma=cfg.sigma_sigmoid, loss_reduction=cfg.loss_reduction, ekional_loss_on=cfg.ekional_loss_on,
                        weight_e=cfg.weight_e)
     unroll = 4  # iterations per HIP graph: the graph lives for hundreds of replays here, so its ~8 us boundary gap is worth folding
-    it = GraphedIteration(octree, decoder, spool, adam, opts, n, unroll=unroll)
+    it = GraphedIteration(octree, decoder, spool, adam, opts, n, unroll=unroll, active_rows=active_rows)
     it.run(20)
     torch.cuda.synchronize()
-    iters = iters // unroll * unroll
-    t0 = time.perf_counter()
-    it.run(iters)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    third = max(unroll, iters // 3 // unroll * unroll)
+    windows = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        it.run(third)
+        torch.cuda.synchronize()
+        windows.append((time.perf_counter() - t0) / third)
+    dt = sum(windows) / 3
+    untouched = None
+    if it.active_rows:
+        untouched = float(sum(int((f[:-1] == 0).sum()) for f in it.touched)) / max(1, sum(f.numel() - 1 for f in it.touched))
     with torch.no_grad():  # leave the workload as it was
         for p, s in zip(params, saved):
             p.copy_(s)
     return {"n": n, "us_per_iteration": dt * 1e6, "samples_per_s": n / dt,
-            "what": "fused step + {partial sums, fused dense Adam, grads cleared, next sorted draw}: two launches per iteration, "
-                    "%d iterations per HIP graph" % unroll}
+            "us_per_iteration_first_third": windows[0] * 1e6, "us_per_iteration_last_third": windows[2] * 1e6,
+            "iterations_timed": 3 * third, "active_row_adam": bool(it.active_rows), "rows_never_touched_frac": untouched,
+            "what": "fused step + {partial sums, Adam (exact, untouched rows skipped), grads cleared, next sorted draw}: two "
+                    "launches per iteration, %d iterations per HIP graph" % unroll}
 
 
 def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_seconds=12.0):

@@ -243,14 +243,16 @@ int shine_morton_sort(const shine_step_config* cfg, const float* coord, int64_t 
  *      shine_regularize = FeatureOctree.cal_regularization (model/feature_octree.py:246-255) on the rows flagged by the
  *      last shine_train_step: *reg_out = sum importance*(F - F_last)^2 (unweighted; overwritten), and, for levels with
  *      grad_on[s] != 0, grad_feats[s] += 2*lambda*importance*(F - F_last).  grad_on[s] = 0 is the reference's
- *      attached-clone quirk (:160): value only.  Clears the flags.  out_zeroed != 0: *reg_out was already cleared (by the
+ *      attached-clone quirk (:160): value only.  Clears the flags — unless keep_flags != 0: the flags are then the optimiser's
+ *      sticky active-row flags (shine_adam_step row_flags), only rows with bit 0 set (touched by THIS iteration's step) count,
+ *      and the optimiser's launch turns them into "touched earlier".  out_zeroed != 0: *reg_out was already cleared (by the
  *      step's reduction launch, cfg->zero_f64) — no memset launch here.
  *      shine_importance_accumulate = the per-chunk epilogue of cal_feature_importance (utils/incre_learning.py:36-40):
  *      importance += |grad|, grad = 0, importance[trash row] = 0, for one level ([rows+1, 8] tensors). ------------- */
 int shine_regularize(int32_t n_levels, const float* const* feats, const float* const* feats_last,
                      const float* const* importance, float* const* grad_feats, unsigned char* const* touched,
                      const int64_t* rows, const int32_t* grad_on, float lambda_forget, double* reg_out,
-                     int32_t out_zeroed, void* stream);
+                     int32_t out_zeroed, int32_t keep_flags, void* stream);
 int shine_importance_accumulate(float* importance, float* grad, int64_t rows, void* stream);
 /*      shine_importance_sweep = the whole of cal_feature_importance's chunk loop (utils/incre_learning.py:27-40) in one
  *      call.  coord / sdf_label / weight (or NULL) / slots: a node-ordered pool as for pool-mode shine_train_step
@@ -259,7 +261,8 @@ int shine_importance_accumulate(float* importance, float* grad, int64_t rows, vo
  *      with inv_n = 1 / chunk size (or 1 under reduction_sum) accumulating into grad_feats, then importance[s] +=
  *      |grad_feats[s]|, grad_feats[s] = 0, importance[s][trash row] = 0 for every level.  grad_feats must be zero on
  *      entry (and are zero on return); pred_scratch: device float[max chunk size]; workspace as for shine_train_step of
- *      the largest chunk. */
+ *      the largest chunk.  Like the query_feature of every chunk (set_zero, model/feature_octree.py:78-81,238) the call
+ *      re-zeroes the trash row of every feats[s] — the one write through the `feats` pointers. */
 int shine_importance_sweep(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                            const float* sdf_label, const float* weight, const int32_t* idx, const int32_t* slots,
                            const int64_t* chunk_begin, int32_t n_chunks, const float* const* feats, const int64_t* rows,
@@ -270,10 +273,16 @@ int shine_importance_sweep(const shine_tables* t, const shine_step_config* cfg, 
 /* ---- fused dense Adam (next row f-1): opt.step() [+ opt.zero_grad()] of shine_batch.py:208-210 for the optimiser of
  *      setup_optimizer (utils/tools.py:57-83): torch.optim.Adam semantics (betas, eps, L2 weight decay added to the
  *      grad, bias correction with the 1-based `step`), one lr / weight_decay per tensor, every element updated
- *      (dense, like the reference).  n_tensors <= 16; all arrays are host arrays of n_tensors entries. ------------- */
+ *      (dense, like the reference).  n_tensors <= 16; all arrays are host arrays of n_tensors entries.
+ *      row_flags (NULL, or a host array of n_tensors device pointers with NULL entries for dense tensors): EXACT active rows
+ *      for [rows, 8] feature tables without weight decay — one byte per row, 0 = the row has had no gradient since the
+ *      optimiser state was created (m = v = g = 0: torch's Adam leaves it bit for bit unchanged, so it is skipped unread),
+ *      bit 0 = touched by this iteration's step (shine_train_step `touched`; this launch rewrites it as 2), 2 = touched
+ *      earlier.  The caller clears flags and state together. ---------------------------------------------------------- */
 int shine_adam_step(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const int64_t* numel, const float* lr, const float* weight_decay,
-                    float beta1, float beta2, float eps, int64_t step, int32_t zero_grad, void* stream);
+                    float beta1, float beta2, float eps, int64_t step, int32_t zero_grad,
+                    unsigned char* const* row_flags, void* stream);
 
 /* ---- Batch plan: order a batch by octree node (counting sort) and remember every point's hash slots.
  *      shine_tables_set_ranks: per level, the rank of every node in ONE Z-order over all featured levels (a parent's
@@ -386,7 +395,8 @@ int shine_sample_sorted_dev(int64_t pool_size, int64_t n, uint64_t seed, uint64_
                             size_t* workspace_bytes, void* stream);
 int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const float* weight_decay,
-                        float beta1, float beta2, float eps, int64_t* step_state, int32_t zero_grad, void* stream);
+                        float beta1, float beta2, float eps, int64_t* step_state, int32_t zero_grad,
+                        unsigned char* const* row_flags, void* stream);
 
 /* ---- the tail of a training iteration in ONE launch (shine_batch.py:208-210, shine_incre.py:152-181): after a
  *      shine_train_step with cfg->defer_reduce = 1 (same cfg and n; workspace = that call's workspace, n_surf as given there)
@@ -401,14 +411,21 @@ int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* g
  *      tables when the decoder is frozen).  next_draw (optional): the sorted draw of the NEXT iteration — what
  *      shine_sample_sorted_dev(pool_size, n, seed, stream_state, idx_out, NULL, 0, surf_bits, surf_parts, ...) would launch, for
  *      n < 16 K draws — done by a few extra blocks of this launch (the fused kernel is done with the index buffer by then),
- *      so an iteration at the reference's batch size is {fused step, this}: two launches (shine_next_draw: above). */
+ *      so an iteration at the reference's batch size is {fused step, this}: two launches (shine_next_draw: above).
+ *      touched[s] (byte per row incl. the trash row, required with lambda_forget != 0 or active_rows): bit 0 = the row received
+ *      gradient from THIS iteration's step (set by the step: its `touched` argument).  active_rows == 0: the flags are cleared
+ *      here (as shine_regularize does).  active_rows != 0 — EXACT active-row Adam: the flags are sticky (1 becomes 2 = "touched
+ *      earlier") and a row whose flag is 0 is skipped without being read: it has had no gradient since the caller cleared
+ *      flags, m and v together (a new optimiser, utils/tools.py:57-83 — every frame in shine_incre.py:107-109), so m = v = g = 0
+ *      and torch's Adam leaves it bit for bit unchanged (p -= lr * 0 / (0 + eps)).  Needs weight_decay == 0 on the feature
+ *      tables (the reference's groups, utils/tools.py:68-72) and grads that are zero on unflagged rows. */
 int shine_finish_iteration(const shine_step_config* cfg, int64_t n, const void* workspace, const int64_t* n_surf,
                            double* loss_parts, const float* const* feats_last, const float* const* importance,
                            unsigned char* const* touched, const int32_t* grad_on, float lambda_forget, double* reg_out,
                            int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                            float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const int32_t* lr_index,
                            const float* weight_decay, float beta1, float beta2, float eps, const int64_t* step_state,
-                           const shine_next_draw* next_draw, void* stream);
+                           const shine_next_draw* next_draw, int32_t active_rows, void* stream);
 
 /* ---- measurement aid (tools/ab_build.py AB_PROF): per-wave phase cycle counters of the fused kernel.  buffer = device
  *      int64 [waves][8] (setup, query, decoder forward, loss+backward, scatter, weight grads, flush, block wait) that

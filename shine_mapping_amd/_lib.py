@@ -90,22 +90,22 @@ _SIGNATURES = {
     ),
     "shine_regularize": (
         C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
-                  C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_float, _P, C.c_int32, _P]),
+                  C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_float, _P, C.c_int32, C.c_int32, _P]),
     "shine_importance_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
     "shine_importance_sweep": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P,
                                          C.c_size_t, _P]),
     "shine_adam_step": (
         C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_int64, C.c_int32,
-                  _P]),
+                  C.POINTER(_P), _P]),
     "shine_adam_step_dev": (
         C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
-                  _P, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _P, C.c_int32, _P]),
+                  _P, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _P, C.c_int32, C.POINTER(_P), _P]),
     "shine_finish_iteration": (
         C.c_int, [C.POINTER(StepConfig), C.c_int64, _P, _P, _P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                   C.POINTER(C.c_int32), C.c_float, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                   C.POINTER(C.c_int64), _P, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _P,
-                  C.POINTER(NextDraw), _P]),
+                  C.POINTER(NextDraw), C.c_int32, _P]),
     "shine_sample_sorted_finish": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, _P, _P, _P, C.c_size_t, _P,
                                              _P, _P, C.c_size_t, _P]),
     "shine_sample_sorted_dev": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, _P, _P, _P, C.c_size_t, _P, _P, _P,

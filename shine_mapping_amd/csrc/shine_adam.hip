@@ -22,6 +22,7 @@ struct AdamSeg {
   long long n;      // elements
   long long start;  // prefix in float4 units
   float lr, wd;
+  unsigned char* flags;  // [n / 8] sticky touched-row flags of a [rows, 8] table (active rows: shine_hip.h), or null: dense
 };
 struct AdamArgs {
   AdamSeg seg[ADAM_MAX_SEG];
@@ -67,6 +68,11 @@ __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
     const AdamSeg& S = a.seg[s];
     const float lr_s = a.step_state ? s_lr[s] : S.lr;
     const long long e = (i - S.start) * 4;
+    if (S.flags) {  // exact active rows: a row that never had a gradient has m = v = g = 0 and is left as it is (not read)
+      const unsigned char f = S.flags[e >> 3];
+      if (f == 0) continue;
+      if ((f & 1) && (e & 7) == 0) S.flags[e >> 3] = 2;  // "touched by this iteration" becomes "touched earlier"
+    }
     if (e + 4 <= S.n && ((((size_t)S.p | (size_t)S.g | (size_t)S.m | (size_t)S.v) & 15) == 0)) {
       float4 p = *reinterpret_cast<float4*>(S.p + e), g = *reinterpret_cast<float4*>(S.g + e),
              m = *reinterpret_cast<float4*>(S.m + e), v = *reinterpret_cast<float4*>(S.v + e);
@@ -98,7 +104,7 @@ using namespace shine;
 static int adam_impl(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const int64_t* numel, const float* lr, const float* lr_dev,
                      const float* weight_decay, float beta1, float beta2, float eps, int64_t step, long long* step_state,
-                     int32_t zero_grad, void* stream) {
+                     int32_t zero_grad, unsigned char* const* row_flags, void* stream) {
   if (n_tensors < 1 || n_tensors > ADAM_MAX_SEG || !params || !grads || !exp_avg || !exp_avg_sq || !numel ||
       (!lr && !lr_dev) || !weight_decay || (step < 1 && !step_state))
     return set_error(SHINE_E_INVALID, "shine_adam_step: bad argument");
@@ -115,6 +121,9 @@ static int adam_impl(int32_t n_tensors, float* const* params, float* const* grad
     a.seg[s].start = start;
     a.seg[s].lr = lr ? lr[s] : 0.f;
     a.seg[s].wd = weight_decay[s];
+    a.seg[s].flags = row_flags ? row_flags[s] : nullptr;
+    if (a.seg[s].flags && (numel[s] % 8 != 0 || weight_decay[s] != 0.f))
+      return set_error(SHINE_E_INVALID, "shine_adam_step: row_flags are for [rows, 8] feature tables without weight decay");
     start += (numel[s] + 3) / 4;
   }
   a.n_seg = n_tensors;
@@ -140,16 +149,16 @@ static int adam_impl(int32_t n_tensors, float* const* params, float* const* grad
 extern "C" int shine_adam_step(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                                float* const* exp_avg_sq, const int64_t* numel, const float* lr,
                                const float* weight_decay, float beta1, float beta2, float eps, int64_t step,
-                               int32_t zero_grad, void* stream) {
+                               int32_t zero_grad, unsigned char* const* row_flags, void* stream) {
   return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr, nullptr, weight_decay, beta1, beta2, eps, step,
-                   nullptr, zero_grad, stream);
+                   nullptr, zero_grad, row_flags, stream);
 }
 
 extern "C" int shine_adam_step_dev(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                                    float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev,
                                    const float* weight_decay, float beta1, float beta2, float eps, int64_t* step_state,
-                                   int32_t zero_grad, void* stream) {
+                                   int32_t zero_grad, unsigned char* const* row_flags, void* stream) {
   if (!lr_dev || !step_state) return set_error(SHINE_E_INVALID, "shine_adam_step_dev: null lr_dev/step_state");
   return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, nullptr, lr_dev, weight_decay, beta1, beta2, eps, 0,
-                   (long long*)step_state, zero_grad, stream);
+                   (long long*)step_state, zero_grad, row_flags, stream);
 }

@@ -51,6 +51,11 @@ struct FinArgs {
   int grad_on[SHINE_MAX_LEVELS];
   float lambda;
   double* reg_out;
+  // active rows (exact): touched[s][r] == 0 means "no gradient since the optimiser was created" — then m = v = g = 0 and torch's
+  // Adam (no weight decay on the feature tables) computes p -= lr * 0 / (0 + eps): the row is left bit for bit as it is, so it is
+  // not even read.  The step's scatter sets 1 on the rows of THIS iteration (what the regulariser applies to), this launch turns
+  // 1 into 2 ("touched earlier"): the flags are sticky until the caller clears them together with the optimiser state.
+  int active;
   // Adam
   float b1, b2, eps;
   const long long* step_state;  // already advanced for this step (by the fused kernel, cfg->adam_state)
@@ -95,51 +100,73 @@ __global__ __launch_bounds__(256) void k_finish(const FinArgs a, int fb, int db)
   const int lane = threadIdx.x & 63;
   if ((int)blockIdx.x < fb) {
     double acc = 0.0;
-    for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < a.feat_units; u += (long long)fb * 256) {
-      int s = 0;
-      while (s + 1 < a.n_levels && u >= a.seg[s + 1].ustart) ++s;
-      const FinSeg& S = a.seg[s];
-      const long long r = u - S.ustart, rows = S.n / F - 1;  // (the trash row is the last one)
-      float4* pp = reinterpret_cast<float4*>(S.p + r * F);
-      float4* gp = reinterpret_cast<float4*>(S.g + r * F);
-      float4* mp = reinterpret_cast<float4*>(S.m + r * F);
-      float4* vp = reinterpret_cast<float4*>(S.v + r * F);
-      const float4 p0 = pp[0], p1 = pp[1], g0 = gp[0], g1 = gp[1], m0 = mp[0], m1 = mp[1], v0 = vp[0], v1 = vp[1];
-      float p[F] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-      float g[F] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-      float m[F] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-      float v[F] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      if (r == rows) continue;  // the trash row: with the decoder units below (its gradient is a sum over the workgroups)
-      if (a.lambda != 0.f && a.touched[s][r]) {
-        // FeatureOctree.cal_regularization (:246-255) on a row the step touched: value, gradient, flag cleared
-        a.touched[s][r] = 0;
-        const float4* lp = reinterpret_cast<const float4*>(a.last[s] + r * F);
-        const float4* ip = reinterpret_cast<const float4*>(a.imp[s] + r * F);
-        const float4 l0 = lp[0], l1 = lp[1], w0 = ip[0], w1 = ip[1];
-        const float l[F] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-        const float w[F] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-        const float k = a.grad_on[s] ? 2.0f * a.lambda : 0.f;
+    // Rows are dealt round-robin to the launch's threads; a thread's (up to 4) flag bytes of one pass are requested together,
+    // before any row is touched: on a map of 10^7 rows a thread walks ~10 rows, and flag -> row is a dependent round trip each.
+    const long long stride = (long long)fb * 256;
+    for (long long u0 = (long long)blockIdx.x * 256 + threadIdx.x; u0 < a.feat_units; u0 += 4 * stride) {
+      int sv[4];
+      long long rv[4];
+      unsigned char tv[4];
+      bool live[4];
 #pragma unroll
-        for (int q = 0; q < F; ++q) {
-          const float d = p[q] - l[q];
-          acc += (double)(w[q] * d * d);
-          g[q] += k * w[q] * d;
-        }
+      for (int k = 0; k < 4; ++k) {
+        const long long u = u0 + k * stride;
+        int s = 0;
+        while (s + 1 < a.n_levels && u >= a.seg[s + 1].ustart) ++s;
+        sv[k] = s;
+        rv[k] = u - a.seg[s].ustart;
+        // (the trash row, the last one, goes with the decoder units below: its gradient is a sum over the workgroups)
+        live[k] = u < a.feat_units && rv[k] != a.seg[s].n / F - 1;
+        tv[k] = (live[k] && a.touched[s]) ? a.touched[s][rv[k]] : (unsigned char)0;
       }
-      const float lr = s_lr[s];
 #pragma unroll
-      for (int q = 0; q < F; ++q) fin_adam1(p[q], g[q], m[q], v[q], sc, lr, S.wd);
-      pp[0] = make_float4(p[0], p[1], p[2], p[3]);
-      pp[1] = make_float4(p[4], p[5], p[6], p[7]);
-      mp[0] = make_float4(m[0], m[1], m[2], m[3]);
-      mp[1] = make_float4(m[4], m[5], m[6], m[7]);
-      vp[0] = make_float4(v[0], v[1], v[2], v[3]);
-      vp[1] = make_float4(v[4], v[5], v[6], v[7]);
-      // most rows of a map were not touched by a 4096-point batch: their gradient is already zero and is not rewritten
-      // (1/8 of this launch's traffic)
-      if ((g0.x != 0.f) | (g0.y != 0.f) | (g0.z != 0.f) | (g0.w != 0.f) | (g1.x != 0.f) | (g1.y != 0.f) | (g1.z != 0.f) |
-          (g1.w != 0.f))
-        gp[0] = gp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < 4; ++k) {
+        if (!live[k] || (a.active && tv[k] == 0)) continue;
+        const int s = sv[k];
+        const long long r = rv[k];
+        const FinSeg& S = a.seg[s];
+        float4* pp = reinterpret_cast<float4*>(S.p + r * F);
+        float4* gp = reinterpret_cast<float4*>(S.g + r * F);
+        float4* mp = reinterpret_cast<float4*>(S.m + r * F);
+        float4* vp = reinterpret_cast<float4*>(S.v + r * F);
+        const float4 p0 = pp[0], p1 = pp[1], g0 = gp[0], g1 = gp[1], m0 = mp[0], m1 = mp[1], v0 = vp[0], v1 = vp[1];
+        float p[F] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        float g[F] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        float m[F] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        float v[F] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (tv[k] & 1) {  // a row the step of THIS iteration touched
+          a.touched[s][r] = a.active ? (unsigned char)2 : (unsigned char)0;
+          if (a.lambda != 0.f) {
+            // FeatureOctree.cal_regularization (:246-255) on a row the step touched: value, gradient
+            const float4* lp = reinterpret_cast<const float4*>(a.last[s] + r * F);
+            const float4* ip = reinterpret_cast<const float4*>(a.imp[s] + r * F);
+            const float4 l0 = lp[0], l1 = lp[1], w0 = ip[0], w1 = ip[1];
+            const float l[F] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+            const float w[F] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const float kk = a.grad_on[s] ? 2.0f * a.lambda : 0.f;
+#pragma unroll
+            for (int q = 0; q < F; ++q) {
+              const float d = p[q] - l[q];
+              acc += (double)(w[q] * d * d);
+              g[q] += kk * w[q] * d;
+            }
+          }
+        }
+        const float lr = s_lr[s];
+#pragma unroll
+        for (int q = 0; q < F; ++q) fin_adam1(p[q], g[q], m[q], v[q], sc, lr, S.wd);
+        pp[0] = make_float4(p[0], p[1], p[2], p[3]);
+        pp[1] = make_float4(p[4], p[5], p[6], p[7]);
+        mp[0] = make_float4(m[0], m[1], m[2], m[3]);
+        mp[1] = make_float4(m[4], m[5], m[6], m[7]);
+        vp[0] = make_float4(v[0], v[1], v[2], v[3]);
+        vp[1] = make_float4(v[4], v[5], v[6], v[7]);
+        // most rows of a map were not touched by a 4096-point batch: their gradient is already zero and is not rewritten
+        // (1/8 of this launch's traffic)
+        if ((g0.x != 0.f) | (g0.y != 0.f) | (g0.z != 0.f) | (g0.w != 0.f) | (g1.x != 0.f) | (g1.y != 0.f) | (g1.z != 0.f) |
+            (g1.w != 0.f))
+          gp[0] = gp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     if (a.lambda != 0.f) {
       acc = wave_sum_d(acc);
@@ -227,7 +254,7 @@ extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, c
                                       float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                                       const float* lr_dev, const int32_t* lr_index, const float* weight_decay, float beta1,
                                       float beta2, float eps, const int64_t* step_state, const shine_next_draw* next_draw,
-                                      void* stream) {
+                                      int32_t active_rows, void* stream) {
   if (!cfg || n < 1 || !workspace || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr_dev || !lr_index ||
       !weight_decay || !step_state)
     return set_error(SHINE_E_INVALID, "shine_finish_iteration: null argument");
@@ -240,6 +267,8 @@ extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, c
   if (cfg->eikonal_on && !n_surf) return set_error(SHINE_E_INVALID, "shine_finish_iteration: eikonal needs n_surf");
   if (lambda_forget != 0.f && (!feats_last || !importance || !touched || !reg_out))
     return set_error(SHINE_E_INVALID, "shine_finish_iteration: the regulariser needs feats_last, importance, touched, reg_out");
+  if (active_rows && !touched)
+    return set_error(SHINE_E_INVALID, "shine_finish_iteration: active_rows needs the touched-row flags of every feature level");
   FinArgs a = {};
   a.n_seg = n_tensors;
   a.n_levels = L;
@@ -264,12 +293,19 @@ extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, c
         return set_error(SHINE_E_INVALID, "shine_finish_iteration: feature tables are [rows + 1][8] floats, 16-byte aligned");
       S.part_off = -1;
       u += numel[s] / F;
+      if (touched) a.touched[s] = touched[s];
+      if (active_rows) {
+        // exactness of the skip: a row without gradient since the optimiser was created has m = v = 0, and with g = 0 and no
+        // weight decay torch's Adam leaves p unchanged (0 / (0 + eps)); with weight decay every row moves every step
+        if (!touched[s]) return set_error(SHINE_E_INVALID, "shine_finish_iteration: active_rows needs flags for every level");
+        if (weight_decay[s] != 0.f)
+          return set_error(SHINE_E_INVALID, "shine_finish_iteration: active_rows is exact only without weight decay on the feature tables");
+      }
       if (lambda_forget != 0.f) {
         if (!feats_last[s] || !importance[s] || !touched[s] || (((size_t)feats_last[s] | (size_t)importance[s]) & 15))
           return set_error(SHINE_E_INVALID, "shine_finish_iteration: null or unaligned regulariser tensor");
         a.last[s] = feats_last[s];
         a.imp[s] = importance[s];
-        a.touched[s] = touched[s];
         a.grad_on[s] = grad_on ? grad_on[s] : 1;
       }
       if (s == L - 1) a.feat_units = u;
@@ -293,6 +329,7 @@ extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, c
   a.loss_parts = loss_parts;
   a.lambda = lambda_forget;
   a.reg_out = reg_out;
+  a.active = active_rows ? 1 : 0;
   a.b1 = beta1;
   a.b2 = beta2;
   a.eps = eps;

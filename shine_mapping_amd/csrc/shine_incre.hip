@@ -22,6 +22,7 @@ struct RegArgs {
   long long start[SHINE_MAX_LEVELS + 1];  // prefix of rows over levels (work partition)
   int grad_on[SHINE_MAX_LEVELS];
   int n_levels;
+  int keep_flags;  // 1: the flags are the optimiser's sticky active-row flags — bit 0 = this iteration; left as they are
   float lambda;
   double* out;  // out[0] += reg (unweighted)
 };
@@ -37,8 +38,8 @@ __global__ __launch_bounds__(256) void k_regularize(RegArgs a) {
     int s = 0;
     while (s + 1 < a.n_levels && row_g >= a.start[s + 1]) ++s;
     const long long r = row_g - a.start[s];
-    if (a.touched[s][r]) {
-      a.touched[s][r] = 0;
+    if (a.touched[s][r] & 1) {
+      if (!a.keep_flags) a.touched[s][r] = 0;
       const float4* fp = reinterpret_cast<const float4*>(a.feat[s] + r * F);
       const float4* lp = reinterpret_cast<const float4*>(a.last[s] + r * F);
       const float4* ip = reinterpret_cast<const float4*>(a.imp[s] + r * F);
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void k_importance(float* imp, float* grad, lon
 struct ImpArgs {
   float4* imp[SHINE_MAX_LEVELS];
   float4* grad[SHINE_MAX_LEVELS];
+  float4* feat[SHINE_MAX_LEVELS];      // the feature table: its trash row is re-zeroed (set_zero of the chunk's query_feature)
   long long n4[SHINE_MAX_LEVELS];      // (rows + 1) * F / 4
   long long trash4[SHINE_MAX_LEVELS];  // rows * F / 4: from here on the trash row
 };
@@ -88,6 +90,9 @@ __global__ __launch_bounds__(256) void k_importance_levels(ImpArgs a) {
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
     const float4 g = grad[e];
     grad[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // FeatureOctree.set_zero (model/feature_octree.py:78-81): every chunk's query_feature zeroes the trash row — after the
+    // training iterations it holds the last Adam step's move (the fused step itself never reads it)
+    if (e >= trash4) a.feat[s][e] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 v = imp[e];
     v = e >= trash4 ? make_float4(0.f, 0.f, 0.f, 0.f)
                     : make_float4(v.x + fabsf(g.x), v.y + fabsf(g.y), v.z + fabsf(g.z), v.w + fabsf(g.w));
@@ -102,7 +107,7 @@ using namespace shine;
 extern "C" int shine_regularize(int32_t n_levels, const float* const* feats, const float* const* feats_last,
                                 const float* const* importance, float* const* grad_feats,
                                 unsigned char* const* touched, const int64_t* rows, const int32_t* grad_on,
-                                float lambda_forget, double* reg_out, int32_t out_zeroed, void* stream) {
+                                float lambda_forget, double* reg_out, int32_t out_zeroed, int32_t keep_flags, void* stream) {
   if (n_levels < 1 || n_levels > SHINE_MAX_LEVELS || !feats || !feats_last || !importance || !touched || !rows ||
       !reg_out)
     return set_error(SHINE_E_INVALID, "shine_regularize: null argument");
@@ -110,6 +115,7 @@ extern "C" int shine_regularize(int32_t n_levels, const float* const* feats, con
   a.n_levels = n_levels;
   a.lambda = lambda_forget;
   a.out = reg_out;
+  a.keep_flags = keep_flags ? 1 : 0;
   a.start[0] = 0;
   for (int s = 0; s < n_levels; ++s) {
     if (!feats[s] || !feats_last[s] || !importance[s] || !touched[s])
@@ -169,8 +175,11 @@ extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_co
     if (!grad_feats[s] || !importance[s] || rows[s] < 0 ||
         (((size_t)grad_feats[s] | (size_t)importance[s]) & 15))
       return set_error(SHINE_E_INVALID, "shine_importance_sweep: null or unaligned level tensor");
+    if (!feats[s] || ((size_t)feats[s] & 15))
+      return set_error(SHINE_E_INVALID, "shine_importance_sweep: null or unaligned feature table");
     ia.imp[s] = (float4*)importance[s];
     ia.grad[s] = (float4*)grad_feats[s];
+    ia.feat[s] = (float4*)const_cast<float*>(feats[s]);
     ia.n4[s] = (rows[s] + 1) * F / 4;
     ia.trash4[s] = rows[s] * F / 4;
     if (ia.n4[s] > max4) max4 = ia.n4[s];

@@ -81,11 +81,11 @@ static void launch_v3(const V1Args& a, const V2Geometry& g, hipStream_t st) {
   else hipLaunchKernelGGL((k_step_v3<L, 4, EIK, false>), grid, dim3(256), 0, st, a);
 }
 
-template <int L>
-static void launch_v3_mark(const V1Args& a, const V2Geometry& g, hipStream_t st) {  // BCE build that sets the touched-row flags
+template <int L, bool EIK>
+static void launch_v3_mark(const V1Args& a, const V2Geometry& g, hipStream_t st) {  // the build that sets the touched-row flags
   const dim3 grid((unsigned)g.blocks);
-  if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, false, false, false, true>), grid, dim3(V3_BIG * 64), 0, st, a);
-  else hipLaunchKernelGGL((k_step_v3<L, 4, false, false, false, true>), grid, dim3(256), 0, st, a);
+  if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, EIK, false, false, true>), grid, dim3(V3_BIG * 64), 0, st, a);
+  else hipLaunchKernelGGL((k_step_v3<L, 4, EIK, false, false, true>), grid, dim3(256), 0, st, a);
 }
 
 template <int L>
@@ -134,20 +134,27 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
     return set_error(SHINE_E_INVALID, "shine_train_step_v3: workspace too small (shine_train_step_workspace_bytes)");
   a.partials = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  // touched-row flags: set by the scatter of the MARK build (BCE steps whose every level has a gradient table: a level
-  // without one is not walked), by a marking pass in front of the step otherwise
-  bool mark_in_kernel = touched && !cfg->eikonal_on && !a.prof;
+  // touched-row flags: set by the scatter of the MARK build (steps whose every level has a gradient table: a level without
+  // one is not walked), by a marking pass in front of the step otherwise
+  bool mark_in_kernel = touched && !a.prof;
   for (int s = 0; s < cfg->n_levels; ++s) mark_in_kernel = mark_in_kernel && a.lv[s].grad != nullptr;
   if (touched && !mark_in_kernel) {
     hipLaunchKernelGGL(k_mark_touched, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     SHINE_HIP_CHECK(hipGetLastError());
   }
-  if (mark_in_kernel) {
+  if (mark_in_kernel && cfg->eikonal_on) {
     switch (cfg->n_levels) {
-      case 1: launch_v3_mark<1>(a, g, st); break;
-      case 2: launch_v3_mark<2>(a, g, st); break;
-      case 3: launch_v3_mark<3>(a, g, st); break;
-      default: launch_v3_mark<4>(a, g, st); break;
+      case 1: launch_v3_mark<1, true>(a, g, st); break;
+      case 2: launch_v3_mark<2, true>(a, g, st); break;
+      case 3: launch_v3_mark<3, true>(a, g, st); break;
+      default: launch_v3_mark<4, true>(a, g, st); break;
+    }
+  } else if (mark_in_kernel) {
+    switch (cfg->n_levels) {
+      case 1: launch_v3_mark<1, false>(a, g, st); break;
+      case 2: launch_v3_mark<2, false>(a, g, st); break;
+      case 3: launch_v3_mark<3, false>(a, g, st); break;
+      default: launch_v3_mark<4, false>(a, g, st); break;
     }
   } else if (cfg->eikonal_on) {
     switch (cfg->n_levels) {

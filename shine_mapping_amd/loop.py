@@ -68,12 +68,22 @@ class GraphedIteration:
     object every frame: the eager iteration costs ~0.1 ms of launches that a replay does in a third of the time)."""
 
     def __init__(self, octree, decoder, pool, opt, opts: StepOptions, n: int, lambda_forget: float = 0.0, unroll: int = 1,
-                 fold: bool = True, eager_first: bool = True):
+                 fold: bool = True, eager_first: bool = True, active_rows: bool = True):
         self.octree, self.decoder, self.pool, self.opt, self.opts, self.n = octree, decoder, pool, opt, opts, int(n)
         self.lambda_forget = float(lambda_forget)
         self.fold = bool(fold)  # the iteration's tail as one launch (False: reduction, regulariser and Adam as three)
         self.regularize = self.lambda_forget != 0.0
-        self.touched = touched_flags(octree) if self.regularize else None
+        can_fold = self.fold and hasattr(opt, "finish_iteration") and hasattr(opt, "prepare_graph_safe")
+        # EXACT active-row Adam (FusedAdam.finish_iteration(active_flags=...)): rows that have had no gradient since `opt` was
+        # created are not read.  Valid for an optimiser that is new (this object creates the flags cleared, so it must be built
+        # together with the optimiser, as shine_incre.py:107-109 does every frame) and whose feature groups carry no weight decay
+        # (the reference's groups, utils/tools.py:68-72).
+        feat_ids = {id(p) for p in octree.hier_features}
+        feat_wd = [float(g.get("weight_decay", 0.0)) for g in getattr(opt, "param_groups", [])
+                   if any(id(p) in feat_ids for p in g["params"])]
+        fresh = getattr(opt, "steps_taken", lambda: 1)() == 0
+        self.active_rows = bool(active_rows and can_fold and fresh and feat_wd and all(w == 0.0 for w in feat_wd))
+        self.touched = touched_flags(octree) if (self.regularize or self.active_rows) else None
         self._epoch = octree._tables_epoch
         self._idx = torch.empty(self.n, dtype=torch.int32, device=pool.coord.device)
         # the eikonal term's surface count: per-block partial counts written by the draw itself, summed by the step's kernels
@@ -84,12 +94,14 @@ class GraphedIteration:
         self._ahead = False
         dev_key = str(pool.coord.device)
         self.ran_eager = bool(eager_first) or dev_key not in _WARMED or not (self.fold and hasattr(opt, "prepare_graph_safe"))
+        if can_fold:
+            # the optimiser's device-side step state up front: the eager warm-up iteration then runs the SAME two launches the
+            # graph replays (with active rows it has to: its rows must end up flagged "touched earlier")
+            self.opt.prepare_graph_safe()
         if self.ran_eager:
-            # eager warm-up: allocates workspaces, optimiser state and device counters outside the capture
+            # eager warm-up: allocates workspaces and optimiser state and loads the kernels outside the capture
             self.loss, self.reg = self._body()
             _WARMED.add(dev_key)
-        else:
-            self.opt.prepare_graph_safe()
         # From here on the optimiser's launch also draws the NEXT iteration's batch (a few extra blocks, no launch of its own):
         # an iteration is {fused kernel, tail}.  `_idx` then holds the batch of the iteration to come; it is primed here.
         self._ahead = (self.fold and hasattr(self.opt, "finish_iteration") and hasattr(self.opt, "device_state")
@@ -147,7 +159,8 @@ class GraphedIteration:
         if fold:
             self.opt.finish_iteration(pending, dict(lambda_forget=self.lambda_forget, touched=self.touched,
                                                     out=self._reg_out) if self.regularize else None,
-                                      next_draw=self.pool.next_draw(self.n, self._idx, self._surf) if self._ahead else None)
+                                      next_draw=self.pool.next_draw(self.n, self._idx, self._surf) if self._ahead else None,
+                                      active_flags=self.touched if self.active_rows else None)
             return loss, (self._reg_out[0] if self.regularize else None)
         reg = None
         if self.regularize:

@@ -309,12 +309,14 @@ def _dummy_mlp(dev):
     return _DUMMY[key]
 
 
-def fused_regularization(octree, lambda_forget: float, touched, out=None, out_zeroed=False):
+def fused_regularization(octree, lambda_forget: float, touched, out=None, out_zeroed=False, keep_flags=False):
     """FeatureOctree.cal_regularization (model/feature_octree.py:246-255) on the rows the last fused step touched.
 
     Returns the UNWEIGHTED regulariser as a 0-dim float64 device tensor and adds lambda * d(reg)/dF into the feature
     grads of the levels whose features_last_frame copy is detached (octree._reg_grad_on; the reference's attached
-    clone, :160, contributes value only).  `touched`: the per-level uint8 flag tensors passed to fused_train_step."""
+    clone, :160, contributes value only).  `touched`: the per-level uint8 flag tensors passed to fused_train_step.
+    `keep_flags`: the flags double as the optimiser's sticky active-row flags (FusedAdam.step(row_flags=touched)) — they are
+    left as they are, and only the rows flagged by THIS iteration's step (bit 0) enter the regulariser."""
     import ctypes as _C
 
     L = octree.featured_level_num
@@ -331,7 +333,7 @@ def fused_regularization(octree, lambda_forget: float, touched, out=None, out_ze
             L, _lib.ptr_array([t.data_ptr() for t in feats]), _lib.ptr_array([t.data_ptr() for t in last]),
             _lib.ptr_array([t.data_ptr() for t in imp]), _lib.ptr_array([g.data_ptr() for g in grads]),
             _lib.ptr_array([t.data_ptr() for t in touched]), octree.row_counts(), grad_on, float(lambda_forget),
-            out.data_ptr(), 1 if out_zeroed else 0, _stream(),
+            out.data_ptr(), 1 if out_zeroed else 0, 1 if keep_flags else 0, _stream(),
         ),
         "shine_regularize",
     )

@@ -91,8 +91,13 @@ class FusedAdam:
         self._dev_params = []
 
     @torch.no_grad()
-    def step(self, zero_grad=False, graph_safe=False, advanced=False):
-        """`graph_safe`: step counter and learning rates are read from device memory (shine_adam_step_dev), so a captured
+    def step(self, zero_grad=False, graph_safe=False, advanced=False, row_flags=None):
+        """`row_flags` — EXACT active-row Adam: {feature table Parameter: uint8 flags [rows + 1]} (ops.touched_flags, also
+        passed to fused_train_step as `touched`, cleared when this optimiser was created).  A row whose flag is 0 has had no
+        gradient since then: m = v = g = 0, which torch's Adam leaves bit for bit unchanged — it is skipped without being
+        read (a 4096-point batch touches ~10^4 of a large map's 10^7 rows).  Feature groups must carry no weight decay (the
+        reference's do not, utils/tools.py:68-72).
+        `graph_safe`: step counter and learning rates are read from device memory (shine_adam_step_dev), so a captured
         HIP graph of this call performs step t, t+1, ... on successive replays.  Do not mix with eager steps afterwards
         without reading steps_taken().  `advanced`: the fused step of this iteration already counted the step in
         device_state() (StepOptions.adam_state): no preparation launch."""
@@ -123,13 +128,14 @@ class FusedAdam:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
                     raise ValueError("FusedAdam needs contiguous CUDA float32 parameters and grads")
             wd = (C.c_float * n)(*[t[4] for t in ts])
+            flags = self._flag_array(ts, row_flags)
             _lib.check(
                 _lib.lib().shine_adam_step_dev(
                     n, _lib.ptr_array([t[0].data_ptr() for t in ts]), _lib.ptr_array([t[0].grad.data_ptr() for t in ts]),
                     _lib.ptr_array([t[1].data_ptr() for t in ts]), _lib.ptr_array([t[2].data_ptr() for t in ts]),
                     _lib.i64_array([t[0].numel() for t in ts]), self._dev[1].data_ptr(), wd, float(self.betas[0]),
                     float(self.betas[1]), float(self.eps), self._dev[0].data_ptr(),
-                    (1 if zero_grad else 0) | (2 if advanced else 0), _lib.current_stream_handle(),
+                    (1 if zero_grad else 0) | (2 if advanced else 0), flags, _lib.current_stream_handle(),
                 ),
                 "shine_adam_step_dev",
             )
@@ -140,13 +146,29 @@ class FusedAdam:
         self.step_count += 1
         if len(set(ages)) > 1:  # torch.optim.Adam semantics: one launch per distinct age (normally there is one)
             for age in sorted(set(ages)):
-                self._launch([t for t, a in zip(ts, ages) if a == age], age + 1, zero_grad)
+                self._launch([t for t, a in zip(ts, ages) if a == age], age + 1, zero_grad, row_flags)
         else:
-            self._launch(ts, ages[0] + 1, zero_grad)
+            self._launch(ts, ages[0] + 1, zero_grad, row_flags)
         for t in ts:
             self._age[t[0]] = self._age.get(t[0], 0) + 1
 
-    def _launch(self, ts, step, zero_grad):
+    @staticmethod
+    def _flag_array(ts, row_flags):
+        if not row_flags:
+            return None
+        by_id = {id(p): f for p, f in row_flags.items()} if isinstance(row_flags, dict) else None
+        if by_id is None:
+            raise ValueError("row_flags must be a dict {parameter: uint8 flag tensor}")
+        ptrs = []
+        for t in ts:
+            f = by_id.get(id(t[0]))
+            if f is not None and not (f.is_cuda and f.dtype == torch.uint8 and f.is_contiguous()
+                                      and f.numel() * 8 >= t[0].numel()):
+                raise ValueError("row_flags: one uint8 flag per row of the [rows, 8] table")
+            ptrs.append(f.data_ptr() if f is not None else None)
+        return _lib.ptr_array(ptrs)
+
+    def _launch(self, ts, step, zero_grad, row_flags=None):
         n = len(ts)
         if n > 16:
             raise NotImplementedError("FusedAdam handles up to 16 tensors (decoder 6 + feature levels)")
@@ -160,7 +182,8 @@ class FusedAdam:
                 n, _lib.ptr_array([t[0].data_ptr() for t in ts]), _lib.ptr_array([t[0].grad.data_ptr() for t in ts]),
                 _lib.ptr_array([t[1].data_ptr() for t in ts]), _lib.ptr_array([t[2].data_ptr() for t in ts]),
                 _lib.i64_array([t[0].numel() for t in ts]), lr, wd, float(self.betas[0]), float(self.betas[1]),
-                float(self.eps), int(step), 1 if zero_grad else 0, _lib.current_stream_handle(),
+                float(self.eps), int(step), 1 if zero_grad else 0, self._flag_array(ts, row_flags),
+                _lib.current_stream_handle(),
             ),
             "shine_adam_step",
         )
@@ -203,13 +226,16 @@ def _prepare_graph_safe(self):
     return self._dev[0]
 
 
-def _finish_iteration(self, pending, regulariser=None, next_draw=None):
+def _finish_iteration(self, pending, regulariser=None, next_draw=None, active_flags=None):
     """The tail of an iteration in ONE launch (shine_finish_iteration): `pending` is the dict a
     fused_train_step(..., pending=...) filled — its partial sums are added up where they are consumed, the regulariser
     (regulariser = dict(lambda_forget, touched, out) as for ops.fused_regularization) is evaluated on the touched rows, Adam
     is applied to every tensor and the grads are cleared; next_draw = SortedPool.next_draw(...) also draws the next
     iteration's batch in the same launch.  Graph-replayable only: the step must have counted the optimiser
-    step (StepOptions.adam_state = device_state())."""
+    step (StepOptions.adam_state = device_state()).
+    active_flags (the per-level uint8 flags the step was given as `touched`): EXACT active-row Adam — the flags are kept sticky
+    and rows whose flag is 0 (no gradient since this optimiser and the flags were created: m = v = g = 0, which torch's Adam
+    leaves bit for bit unchanged) are not read.  The caller zeroes the flags whenever it creates the optimiser."""
     if self._dev is None:
         raise RuntimeError("finish_iteration needs the device-side step state: run one step(graph_safe=True) first")
     octree, decoder = pending["octree"], pending["decoder"]
@@ -240,6 +266,10 @@ def _finish_iteration(self, pending, regulariser=None, next_draw=None):
         touched = _lib.ptr_array([t.data_ptr() for t in regulariser["touched"]])
         grad_on = (C.c_int32 * L)(*[1 if g else 0 for g in octree._reg_grad_on])
         reg_out = regulariser["out"].data_ptr()
+    if active_flags is not None:
+        if regulariser is not None and any(a is not b for a, b in zip(active_flags, regulariser["touched"])):
+            raise ValueError("finish_iteration: active_flags must be the regulariser's touched flags")
+        touched = _lib.ptr_array([t.data_ptr() for t in active_flags])
     ns = pending["n_surf"]
     _lib.check(
         _lib.lib().shine_finish_iteration(
@@ -249,7 +279,8 @@ def _finish_iteration(self, pending, regulariser=None, next_draw=None):
             _lib.ptr_array([t[1].data_ptr() for _, t in sel]), _lib.ptr_array([t[2].data_ptr() for _, t in sel]),
             _lib.i64_array([t[0].numel() for _, t in sel]), self._dev[1].data_ptr(), (C.c_int32 * n)(*[i for i, _ in sel]),
             (C.c_float * n)(*[t[4] for _, t in sel]), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-            self._dev[0].data_ptr(), C.byref(next_draw) if next_draw is not None else None, _lib.current_stream_handle()),
+            self._dev[0].data_ptr(), C.byref(next_draw) if next_draw is not None else None,
+            1 if active_flags is not None else 0, _lib.current_stream_handle()),
         "shine_finish_iteration")
 
 

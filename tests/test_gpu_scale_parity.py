@@ -949,8 +949,16 @@ def test_the_iteration_tail_as_one_launch_equals_the_three_launches(mode):
         torch.cuda.synchronize()
         params = list(octree.hier_features) + (dec.fused_params() if mode != "frozen-decoder" else [])
         assert all(float(p.grad.abs().max()) == 0.0 for p in params)  # the tail clears the grads either way
-        if incremental:
-            assert all(int(f.sum()) == 0 for f in it.touched)          # ... and the touched flags
+        if it.touched is not None:  # ... and no row is left flagged "touched by this iteration"; the one-launch tail keeps
+            assert all(int((f == 1).sum()) == 0 for f in it.touched)  # the flags sticky (exact active-row Adam): 0 / 2
+            assert fold == it.active_rows
+            if fold:
+                for p, f in zip(octree.hier_features, it.touched):
+                    never = f[:-1] == 0
+                    assert int(never.sum()) > 0 and int((~never).sum()) > 0
+                    assert float(opt.state[p][1][:-1][never].abs().max()) == 0.0  # exp_avg_sq == 0 <=> never touched
+            else:
+                assert all(int(f.sum()) == 0 for f in it.touched)
         return (losses, regs, [opt.state[p][0].clone() for p in params], [opt.state[p][1].clone() for p in params],
                 [p.detach().clone() for p in params], opt.steps_taken())
 
@@ -967,6 +975,54 @@ def test_the_iteration_tail_as_one_launch_equals_the_three_launches(mode):
     for k, (x, y) in enumerate(zip(a[4], b[4])):  # the trash rows: zeroed before their update in both forms
         frac = float(((x - y).abs() > 1e-6 * float(y.abs().max())).float().mean())
         assert frac <= 0.02, "parameters of tensor %d: %.4f of the elements differ" % (k, frac)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bce", "incremental", "eikonal"])
+def test_active_row_tail_is_bit_identical_to_the_dense_tail(mode):
+    """EXACT active-row Adam inside the iteration's one-launch tail (shine_finish_iteration active_rows): K iterations of
+    loop.GraphedIteration with active_rows=True against active_rows=False from the same start, both in the deterministic
+    accumulation mode — skipping the never-touched rows must not change a single bit of the parameters, exp_avg or exp_avg_sq
+    (m = v = g = 0 gives 0 / (0 + eps) = 0; DESIGN's "would change the dense-Adam numerics" was wrong
+    for rows never touched since the optimiser was created), and most rows of the map must indeed have been skipped."""
+    from shine_mapping_amd import StepOptions
+    from shine_mapping_amd.loop import GraphedIteration
+    from shine_mapping_amd.optim import setup_optimizer
+    from shine_mapping_amd.sampler import SortedPool
+
+    incremental = mode == "incremental"
+    K, N = 5, 512
+
+    def run(active):
+        fx = load_golden("ncd_reg_L3" if incremental else ("kitti_eik_L3" if mode == "eikonal" else "maicity_bce_L3"))
+        cfg, octree, dec = product_from_golden(fx)
+        dec = dec.cuda()
+        cfg.lr, cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio, cfg.weight_decay = 0.01, True, 1e-15, 0.5, 1e-7
+        if incremental:
+            octree._reg_grad_on = [True] * cfg.tree_level_feat
+        opt = setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())
+        octree._require_tables(with_ranks=True)
+        pool = SortedPool(octree, fx["coord"].cuda(), fx["sdf_label"].cuda(), fx["weight"].cuda(), seed=5, canonical=True)
+        opts = StepOptions(sigma=fx["sigma"], loss_reduction="sum" if incremental else "mean", deterministic=True,
+                           ekional_loss_on=mode == "eikonal", weight_e=0.1)
+        it = GraphedIteration(octree, dec, pool, opt, opts, N, lambda_forget=1e3 if incremental else 0.0, unroll=2,
+                              active_rows=active)
+        assert it.active_rows == active
+        it.run(K - 1)
+        torch.cuda.synchronize()
+        params = list(octree.hier_features) + dec.fused_params()
+        skipped = None
+        if active:
+            skipped = [float((f[:-1] == 0).float().mean()) for f in it.touched]
+        return ([p.detach().clone() for p in params], [opt.state[p][0].clone() for p in params],
+                [opt.state[p][1].clone() for p in params], float(it.loss), skipped)
+
+    a, b = run(True), run(False)
+    for k in range(3):
+        for x, y in zip(a[k], b[k]):
+            assert torch.equal(x, y)
+    assert a[3] == b[3]
+    assert max(a[4]) > 0.3, a[4]  # (the fixtures' maps are small; on a real map a 4096-point batch touches < 1 % of the rows)
 
 
 @pytest.mark.gpu
