@@ -427,6 +427,38 @@ int shine_finish_iteration(const shine_step_config* cfg, int64_t n, const void* 
                            const float* weight_decay, float beta1, float beta2, float eps, const int64_t* step_state,
                            const shine_next_draw* next_draw, int32_t active_rows, void* stream);
 
+/* ---- the training iteration as a HIP graph built and re-bound by the library (shine_batch.py:105-210, shine_incre.py:114-181:
+ *      the loop body the drivers run `iters` times per frame).  An iteration = { shine_train_step with cfg->defer_reduce = 1,
+ *      shine_finish_iteration }: two kernel launches.  The graph holds `unroll` copies of that pair as kernel nodes;
+ *      set_step / set_finish take exactly the arguments of the two entry points (minus the stream) and record the launches
+ *      they would make; commit builds and instantiates the graph the first time (and whenever a different kernel
+ *      instantiation is needed) and otherwise only rewrites the nodes' kernel parameters in the instantiated graph — so a new
+ *      frame of incremental mapping (new feature tables, new optimiser state: model/feature_octree.py:147-160,
+ *      shine_incre.py:107-109) costs no stream capture and no instantiation.  launch replays it `replays` times on the
+ *      stream (= replays * unroll iterations; the per-iteration scalars — sampler stream id, Adam step count — live in device
+ *      memory and are advanced by the kernels).  The argument arrays are read inside set_*; the DEVICE buffers they name
+ *      must stay alive while the graph is launched.  stats: commits so far, and how many of them built the graph. */
+typedef struct shine_iter_graph shine_iter_graph;
+int shine_iter_graph_create(int32_t unroll, shine_iter_graph** out);
+int shine_iter_graph_destroy(shine_iter_graph* g);
+int shine_iter_graph_set_step(shine_iter_graph* g, const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                              const float* sdf_label, const float* weight, const int32_t* perm, const int32_t* slots,
+                              const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,
+                              const float* const* mlp, float* pred_out, float* grad_x_out, float* const* grad_feats,
+                              float* const* grad_mlp, double* loss_parts, unsigned char* const* touched, void* workspace,
+                              size_t workspace_bytes);
+int shine_iter_graph_set_finish(shine_iter_graph* g, const shine_step_config* cfg, int64_t n, const void* workspace,
+                                const int64_t* n_surf, double* loss_parts, const float* const* feats_last,
+                                const float* const* importance, unsigned char* const* touched, const int32_t* grad_on,
+                                float lambda_forget, double* reg_out, int32_t n_tensors, float* const* params,
+                                float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                                const float* lr_dev, const int32_t* lr_index, const float* weight_decay, float beta1,
+                                float beta2, float eps, const int64_t* step_state, const shine_next_draw* next_draw,
+                                int32_t active_rows);
+int shine_iter_graph_commit(shine_iter_graph* g);
+int shine_iter_graph_launch(shine_iter_graph* g, int32_t replays, void* stream);
+int shine_iter_graph_stats(const shine_iter_graph* g, int64_t* commits, int64_t* builds);
+
 /* ---- measurement aid (tools/ab_build.py AB_PROF): per-wave phase cycle counters of the fused kernel.  buffer = device
  *      int64 [waves][8] (setup, query, decoder forward, loss+backward, scatter, weight grads, flush, block wait) that
  *      the next 4-level shine_train_step launches fill through s_memtime stamps; NULL switches it off again.

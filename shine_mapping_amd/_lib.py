@@ -144,6 +144,12 @@ _SIGNATURES = {
     "shine_interp_backward_backward": (
         C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P,
                   C.POINTER(_P), _P]),
+    # the iteration graph: set_step / set_finish take the arguments of shine_train_step / shine_finish_iteration minus the stream
+    "shine_iter_graph_create": (C.c_int, [C.c_int32, C.POINTER(_P)]),
+    "shine_iter_graph_destroy": (C.c_int, [_P]),
+    "shine_iter_graph_commit": (C.c_int, [_P]),
+    "shine_iter_graph_launch": (C.c_int, [_P, C.c_int32, _P]),
+    "shine_iter_graph_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -176,6 +182,10 @@ def lib():
         fn.argtypes = args
     _lib = h
     return h
+
+
+_SIGNATURES["shine_iter_graph_set_step"] = (C.c_int, [_P] + _SIGNATURES["shine_train_step"][1][:-1])
+_SIGNATURES["shine_iter_graph_set_finish"] = (C.c_int, [_P] + _SIGNATURES["shine_finish_iteration"][1][:-1])
 
 
 def check_lib():

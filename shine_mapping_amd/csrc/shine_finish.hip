@@ -12,63 +12,10 @@
 //   * optionally draws the NEXT iteration's sorted batch in a few extra blocks (the one-launch sampler as a device function),
 // one thread per feature row (8 floats), one wave per 8 elements whose gradient is a sum over the workgroups (trash rows,
 // decoder): the lanes split the partial vectors.
+#include "shine_finish_args.hpp"
 #include "shine_sampler_dev.hpp"
-#include "shine_step_common.hpp"
 
 namespace shine {
-
-constexpr int FIN_MAX_SEG = 16;
-
-struct FinSeg {
-  float* p;
-  float* g;
-  float* m;
-  float* v;
-  long long n;       // elements
-  long long ustart;  // first work unit (8 floats) of the segment
-  float wd;
-  int lr_idx;        // this tensor's entry of lr_dev
-  int part_off;      // decoder tensor: index of its element 0 in the partial vector; feature table: -1
-};
-
-struct FinArgs {
-  FinSeg seg[FIN_MAX_SEG];
-  int n_seg, n_levels;
-  long long feat_units;  // units of the feature tables (= rows incl. the trash rows); the decoder's units follow
-  long long dec_units;
-  // the pending step
-  const float* partials;
-  int nblocks;
-  const long long* n_surf;
-  int n_surf_parts;
-  int reduction_sum;
-  float inv_n, weight_e;
-  double* loss_parts;
-  // regulariser (lambda == 0: off)
-  const float* last[SHINE_MAX_LEVELS];
-  const float* imp[SHINE_MAX_LEVELS];
-  unsigned char* touched[SHINE_MAX_LEVELS];
-  int grad_on[SHINE_MAX_LEVELS];
-  float lambda;
-  double* reg_out;
-  // active rows (exact): touched[s][r] == 0 means "no gradient since the optimiser was created" — then m = v = g = 0 and torch's
-  // Adam (no weight decay on the feature tables) computes p -= lr * 0 / (0 + eps): the row is left bit for bit as it is, so it is
-  // not even read.  The step's scatter sets 1 on the rows of THIS iteration (what the regulariser applies to), this launch turns
-  // 1 into 2 ("touched earlier"): the flags are sticky until the caller clears them together with the optimiser state.
-  int active;
-  // Adam
-  float b1, b2, eps;
-  const long long* step_state;  // already advanced for this step (by the fused kernel, cfg->adam_state)
-  const float* lr_dev;
-  // the sorted draw of the NEXT iteration (shine_next_draw), by nd_blocks extra blocks; nd_blocks == 0: none
-  int nd_blocks;
-  long long nd_n, nd_pool;
-  unsigned long long nd_seed;
-  unsigned long long* nd_stream;
-  int* nd_idx;
-  const unsigned int* nd_bits;
-  long long* nd_surf;
-};
 
 struct FinScalars {
   float b1, b2, eps, bc1, bc2_sqrt;
@@ -247,14 +194,15 @@ __global__ __launch_bounds__(256) void k_finish(const FinArgs a, int fb, int db)
 
 using namespace shine;
 
-extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, const void* workspace, const int64_t* n_surf,
-                                      double* loss_parts, const float* const* feats_last, const float* const* importance,
-                                      unsigned char* const* touched, const int32_t* grad_on, float lambda_forget,
-                                      double* reg_out, int32_t n_tensors, float* const* params, float* const* grads,
-                                      float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
-                                      const float* lr_dev, const int32_t* lr_index, const float* weight_decay, float beta1,
-                                      float beta2, float eps, const int64_t* step_state, const shine_next_draw* next_draw,
-                                      int32_t active_rows, void* stream) {
+namespace shine {
+
+int prepare_finish(FinLaunch* out, const shine_step_config* cfg, int64_t n, const void* workspace, const int64_t* n_surf,
+                   double* loss_parts, const float* const* feats_last, const float* const* importance,
+                   unsigned char* const* touched, const int32_t* grad_on, float lambda_forget, double* reg_out,
+                   int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, const int32_t* lr_index,
+                   const float* weight_decay, float beta1, float beta2, float eps, const int64_t* step_state,
+                   const shine_next_draw* next_draw, int32_t active_rows) {
   if (!cfg || n < 1 || !workspace || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr_dev || !lr_index ||
       !weight_decay || !step_state)
     return set_error(SHINE_E_INVALID, "shine_finish_iteration: null argument");
@@ -269,7 +217,8 @@ extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, c
     return set_error(SHINE_E_INVALID, "shine_finish_iteration: the regulariser needs feats_last, importance, touched, reg_out");
   if (active_rows && !touched)
     return set_error(SHINE_E_INVALID, "shine_finish_iteration: active_rows needs the touched-row flags of every feature level");
-  FinArgs a = {};
+  FinArgs& a = out->a;
+  a = FinArgs{};
   a.n_seg = n_tensors;
   a.n_levels = L;
   static const int dec_off[6] = {MLP_W1, MLP_B1, MLP_W2, MLP_B2, MLP_W3, MLP_B3};
@@ -353,8 +302,30 @@ extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, c
   long long fb = (a.feat_units + 255) / 256;
   if (fb > 4096) fb = 4096;
   const long long db = (a.dec_units + 3) / 4;
-  hipLaunchKernelGGL(k_finish, dim3((unsigned)(fb + db + 1 + a.nd_blocks)), dim3(256), 0, (hipStream_t)stream, a, (int)fb,
-                     (int)db);
-  SHINE_HIP_CHECK(hipGetLastError());
+  out->fn = (const void*)k_finish;
+  out->grid = dim3((unsigned)(fb + db + 1 + a.nd_blocks));
+  out->block = dim3(256);
+  out->fb = (int)fb;
+  out->db = (int)db;
+  return SHINE_OK;
+}
+
+}  // namespace shine
+
+extern "C" int shine_finish_iteration(const shine_step_config* cfg, int64_t n, const void* workspace, const int64_t* n_surf,
+                                      double* loss_parts, const float* const* feats_last, const float* const* importance,
+                                      unsigned char* const* touched, const int32_t* grad_on, float lambda_forget,
+                                      double* reg_out, int32_t n_tensors, float* const* params, float* const* grads,
+                                      float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                                      const float* lr_dev, const int32_t* lr_index, const float* weight_decay, float beta1,
+                                      float beta2, float eps, const int64_t* step_state, const shine_next_draw* next_draw,
+                                      int32_t active_rows, void* stream) {
+  FinLaunch fl;
+  int rc = prepare_finish(&fl, cfg, n, workspace, n_surf, loss_parts, feats_last, importance, touched, grad_on, lambda_forget,
+                          reg_out, n_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr_dev, lr_index, weight_decay, beta1,
+                          beta2, eps, step_state, next_draw, active_rows);
+  if (rc != SHINE_OK) return rc;
+  void* kp[] = {&fl.a, &fl.fb, &fl.db};
+  SHINE_HIP_CHECK(hipLaunchKernel(fl.fn, fl.grid, fl.block, kp, 0, (hipStream_t)stream));
   return SHINE_OK;
 }

@@ -104,6 +104,21 @@ long long v3_lds_bytes(int wg_waves);
 // measurement aid (shine_debug_set_profile_buffer): per-wave phase cycle counters or null
 extern long long* g_prof_buffer;
 
+// a fused-step launch, prepared but not launched (shine_step_v3.hip prepare_step_v3): shine_train_step_v3 launches it, the
+// iteration graph (shine_graph.hip) makes it a kernel node
+struct StepLaunch {
+  const void* fn;   // the k_step_v3 instantiation; null: empty batch, nothing to launch
+  dim3 grid, block;
+  int blocks;       // workgroups = partial vectors the launch leaves in the workspace
+  bool mark_pass;   // the touched-row flags need k_mark_touched in front (a level without a gradient table, profiling build)
+  V1Args a;
+};
+int prepare_step_v3(StepLaunch* out, const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                    const float* sdf_label, const float* weight, const int32_t* perm, const int32_t* slots,
+                    const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows, const float* const* mlp,
+                    float* pred_out, float* grad_x_out, float* const* grad_feats, float* const* grad_mlp, double* loss_parts,
+                    unsigned char* const* touched, void* workspace, size_t workspace_bytes);
+
 // second stage of a fused step (shine_step_support.hip): add `nblocks` per-workgroup partial vectors [PART_STRIDE floats each]
 // into the gradient tensors / loss, re-zero the trash rows (set_zero, model/feature_octree.py:78-81)
 // cfg->next_draw: pass 1 of the NEXT sorted draw (two-launch form of the sampler: the block sums of its Exp(1) spacings) rides

@@ -67,32 +67,71 @@ long long v3_lds_bytes(int wg_waves) {
          4 * sizeof(double);
 }
 
-template <int L, bool EIK>
-static void launch_v3(const V1Args& a, const V2Geometry& g, hipStream_t st) {
-  const dim3 grid((unsigned)g.blocks);
+// the instantiation a launch uses: {levels, workgroup shape, eikonal term, profiling stamps, external delta, touched-row marks}
+template <int L, bool EIK, bool EXT, bool MARK>
+static const void* step_fn_l(int wg_waves, bool prof) {
 #if SHINE_V3_PROFBUILD  // measurement builds only (tools/mk_variant.py -DSHINE_V3_PROFBUILD=1): the per-wave phase counters
-  if (a.prof) {
-    if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, EIK, true>), grid, dim3(V3_BIG * 64), 0, st, a);
-    else hipLaunchKernelGGL((k_step_v3<L, 4, EIK, true>), grid, dim3(256), 0, st, a);
-    return;
-  }
+  if (prof && !EXT && !MARK)
+    return wg_waves == V3_BIG ? (const void*)k_step_v3<L, V3_BIG, EIK, true> : (const void*)k_step_v3<L, 4, EIK, true>;
 #endif
-  if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, EIK, false>), grid, dim3(V3_BIG * 64), 0, st, a);
-  else hipLaunchKernelGGL((k_step_v3<L, 4, EIK, false>), grid, dim3(256), 0, st, a);
+  (void)prof;
+  return wg_waves == V3_BIG ? (const void*)k_step_v3<L, V3_BIG, EIK, false, EXT, MARK>
+                            : (const void*)k_step_v3<L, 4, EIK, false, EXT, MARK>;
+}
+template <bool EIK, bool EXT, bool MARK>
+static const void* step_fn(int levels, int wg_waves, bool prof) {
+  switch (levels) {
+    case 1: return step_fn_l<1, EIK, EXT, MARK>(wg_waves, prof);
+    case 2: return step_fn_l<2, EIK, EXT, MARK>(wg_waves, prof);
+    case 3: return step_fn_l<3, EIK, EXT, MARK>(wg_waves, prof);
+    default: return step_fn_l<4, EIK, EXT, MARK>(wg_waves, prof);
+  }
 }
 
-template <int L, bool EIK>
-static void launch_v3_mark(const V1Args& a, const V2Geometry& g, hipStream_t st) {  // the build that sets the touched-row flags
-  const dim3 grid((unsigned)g.blocks);
-  if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, EIK, false, false, true>), grid, dim3(V3_BIG * 64), 0, st, a);
-  else hipLaunchKernelGGL((k_step_v3<L, 4, EIK, false, false, true>), grid, dim3(256), 0, st, a);
-}
-
-template <int L>
-static void launch_v3_ext(const V1Args& a, const V2Geometry& g, hipStream_t st) {
-  const dim3 grid((unsigned)g.blocks);
-  if (g.wg_waves == V3_BIG) hipLaunchKernelGGL((k_step_v3<L, V3_BIG, false, false, true>), grid, dim3(V3_BIG * 64), 0, st, a);
-  else hipLaunchKernelGGL((k_step_v3<L, 4, false, false, true>), grid, dim3(256), 0, st, a);
+// Everything of a fused-step launch but the launch itself: argument block, kernel instantiation, geometry.  Used by
+// shine_train_step_v3 (launches it) and by the iteration graph (shine_graph.hip: a kernel node with these parameters).
+int prepare_step_v3(StepLaunch* out, const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                    const float* sdf_label, const float* weight, const int32_t* perm, const int32_t* slots,
+                    const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows, const float* const* mlp,
+                    float* pred_out, float* grad_x_out, float* const* grad_feats, float* const* grad_mlp, double* loss_parts,
+                    unsigned char* const* touched, void* workspace, size_t workspace_bytes) {
+  if (!slots) return set_error(SHINE_E_INVALID, "shine_train_step_v3: needs a planned batch (slots)");
+  V1Args& a = out->a;
+  a = V1Args{};
+  int rc = fill_step_args(&a, t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
+                          grad_x_out, grad_feats, grad_mlp, loss_parts, touched);
+  if (rc != SHINE_OK) return rc;
+  out->fn = nullptr;
+  if (n == 0) return SHINE_OK;
+  V2Geometry g = v3_geometry(n);
+  if (a.ablate & 64) {  // kernel_variant bit 0x4000: the deterministic (single-wave) launch of the test suite
+    g.blocks = 1;
+    g.wg_waves = 4;
+    g.waves = 4;
+  }
+  a.tiles = g.tiles;
+  a.waves_total = g.waves;
+  a.prof = g_prof_buffer;
+  const size_t need = (size_t)g.blocks * PART_STRIDE * sizeof(float);
+  if (!workspace || workspace_bytes < need)
+    return set_error(SHINE_E_INVALID, "shine_train_step_v3: workspace too small (shine_train_step_workspace_bytes)");
+  a.partials = (float*)workspace;
+  // touched-row flags: set by the scatter of the MARK build (steps whose every level has a gradient table: a level without
+  // one is not walked), by a marking pass in front of the step otherwise
+  bool mark_in_kernel = touched && !a.prof;
+  for (int s = 0; s < cfg->n_levels; ++s) mark_in_kernel = mark_in_kernel && a.lv[s].grad != nullptr;
+  out->mark_pass = touched && !mark_in_kernel;
+  const bool prof = a.prof != nullptr;
+  if (mark_in_kernel)
+    out->fn = cfg->eikonal_on ? step_fn<true, false, true>(cfg->n_levels, g.wg_waves, prof)
+                              : step_fn<false, false, true>(cfg->n_levels, g.wg_waves, prof);
+  else
+    out->fn = cfg->eikonal_on ? step_fn<true, false, false>(cfg->n_levels, g.wg_waves, prof)
+                              : step_fn<false, false, false>(cfg->n_levels, g.wg_waves, prof);
+  out->grid = dim3((unsigned)g.blocks);
+  out->block = dim3((unsigned)(g.wg_waves * 64));
+  out->blocks = (int)g.blocks;
+  return SHINE_OK;
 }
 
 }  // namespace shine
@@ -114,70 +153,25 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
                                    float* const* grad_feats, float* const* grad_mlp, double* loss_parts,
                                    unsigned char* const* touched, void* workspace, size_t workspace_bytes,
                                    void* stream) {
-  if (!slots) return set_error(SHINE_E_INVALID, "shine_train_step_v3: needs a planned batch (slots)");
-  V1Args a = {};
-  int rc = fill_step_args(&a, t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
-                          grad_x_out, grad_feats, grad_mlp, loss_parts, touched);
+  StepLaunch sl;
+  int rc = prepare_step_v3(&sl, t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,
+                           grad_x_out, grad_feats, grad_mlp, loss_parts, touched, workspace, workspace_bytes);
   if (rc != SHINE_OK) return rc;
-  if (n == 0) return SHINE_OK;
-  V2Geometry g = v3_geometry(n);
-  if (a.ablate & 64) {  // kernel_variant bit 0x4000: the deterministic (single-wave) launch of the test suite
-    g.blocks = 1;
-    g.wg_waves = 4;
-    g.waves = 4;
-  }
-  a.tiles = g.tiles;
-  a.waves_total = g.waves;
-  a.prof = g_prof_buffer;
-  const size_t need = (size_t)g.blocks * PART_STRIDE * sizeof(float);
-  if (!workspace || workspace_bytes < need)
-    return set_error(SHINE_E_INVALID, "shine_train_step_v3: workspace too small (shine_train_step_workspace_bytes)");
-  a.partials = (float*)workspace;
+  if (!sl.fn) return SHINE_OK;  // (empty batch)
   hipStream_t st = (hipStream_t)stream;
-  // touched-row flags: set by the scatter of the MARK build (steps whose every level has a gradient table: a level without
-  // one is not walked), by a marking pass in front of the step otherwise
-  bool mark_in_kernel = touched && !a.prof;
-  for (int s = 0; s < cfg->n_levels; ++s) mark_in_kernel = mark_in_kernel && a.lv[s].grad != nullptr;
-  if (touched && !mark_in_kernel) {
+  V1Args& a = sl.a;
+  if (sl.mark_pass) {
     hipLaunchKernelGGL(k_mark_touched, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     SHINE_HIP_CHECK(hipGetLastError());
   }
-  if (mark_in_kernel && cfg->eikonal_on) {
-    switch (cfg->n_levels) {
-      case 1: launch_v3_mark<1, true>(a, g, st); break;
-      case 2: launch_v3_mark<2, true>(a, g, st); break;
-      case 3: launch_v3_mark<3, true>(a, g, st); break;
-      default: launch_v3_mark<4, true>(a, g, st); break;
-    }
-  } else if (mark_in_kernel) {
-    switch (cfg->n_levels) {
-      case 1: launch_v3_mark<1, false>(a, g, st); break;
-      case 2: launch_v3_mark<2, false>(a, g, st); break;
-      case 3: launch_v3_mark<3, false>(a, g, st); break;
-      default: launch_v3_mark<4, false>(a, g, st); break;
-    }
-  } else if (cfg->eikonal_on) {
-    switch (cfg->n_levels) {
-      case 1: launch_v3<1, true>(a, g, st); break;
-      case 2: launch_v3<2, true>(a, g, st); break;
-      case 3: launch_v3<3, true>(a, g, st); break;
-      default: launch_v3<4, true>(a, g, st); break;
-    }
-  } else {
-    switch (cfg->n_levels) {
-      case 1: launch_v3<1, false>(a, g, st); break;
-      case 2: launch_v3<2, false>(a, g, st); break;
-      case 3: launch_v3<3, false>(a, g, st); break;
-      default: launch_v3<4, false>(a, g, st); break;
-    }
-  }
-  SHINE_HIP_CHECK(hipGetLastError());
+  void* params[] = {&a};
+  SHINE_HIP_CHECK(hipLaunchKernel(sl.fn, sl.grid, sl.block, params, 0, st));
   if (!(a.ablate & 32) && !a.defer_reduce) {  // (ablate bit 32: measurement only — time the dominant kernel by itself)
     Pass1Args p1;  // cfg->next_draw: pass 1 of the next sorted draw as extra blocks of this launch (4 sampler blocks each)
     rc = fill_pass1_args(&p1, cfg);
     if (rc != SHINE_OK) return rc;
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((PART_FLOATS + 63) / 64 + (p1.nblocks + 3) / 4)), dim3(1024), 0, st, a,
-                       (int)g.blocks, p1);
+                       sl.blocks, p1);
     SHINE_HIP_CHECK(hipGetLastError());
   }
   return SHINE_OK;
@@ -213,13 +207,9 @@ extern "C" int shine_interp_sdf_backward(const shine_tables* t, const shine_step
     return set_error(SHINE_E_INVALID, "shine_interp_sdf_backward: workspace too small (shine_train_step_workspace_bytes)");
   a.partials = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  switch (cfg->n_levels) {
-    case 1: launch_v3_ext<1>(a, g, st); break;
-    case 2: launch_v3_ext<2>(a, g, st); break;
-    case 3: launch_v3_ext<3>(a, g, st); break;
-    default: launch_v3_ext<4>(a, g, st); break;
-  }
-  SHINE_HIP_CHECK(hipGetLastError());
+  void* params[] = {&a};
+  SHINE_HIP_CHECK(hipLaunchKernel(step_fn<false, true, false>(cfg->n_levels, g.wg_waves, false), dim3((unsigned)g.blocks),
+                                  dim3((unsigned)(g.wg_waves * 64)), params, 0, st));
   hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks, Pass1Args{});
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;

@@ -16,8 +16,11 @@ replay draws a fresh batch and applies the right bias correction.  Learning-rate
 (`opt.sync_lr()` after changing `param_groups`).  Re-create after `octree.update()` (parameters are re-allocated, like
 the optimiser itself, shine_incre.py:108-109).
 """
+import ctypes as C
+
 import torch
 
+from . import _lib
 from .ops import StepOptions, fused_regularization, fused_train_step, touched_flags
 
 
@@ -60,6 +63,49 @@ def _capture(fn):
 _WARMED = set()  # devices on which an iteration has run eagerly in this process
 
 
+class IterationGraph:
+    """A library-built HIP graph of `unroll` iterations (include/shine_hip.h shine_iter_graph_*): kernel nodes created from the
+    launches fused_train_step(pending=..., graph=self) and FusedAdam.finish_iteration(..., graph=self) would make, re-bound in
+    place (commit) when the buffers change — a new frame of incremental mapping costs no capture and no instantiation."""
+
+    _cache = {}
+
+    def __init__(self, unroll):
+        self.unroll = int(unroll)
+        self.handle = C.c_void_p()
+        self.owner = None  # the GraphedIteration whose buffers the nodes currently name
+        _lib.check(_lib.lib().shine_iter_graph_create(self.unroll, C.byref(self.handle)), "shine_iter_graph_create")
+
+    @classmethod
+    def shared(cls, device, unroll):
+        """one graph per (device, unroll) for the life of the process: incremental mapping builds a GraphedIteration per frame"""
+        key = (str(device), int(unroll))
+        g = cls._cache.get(key)
+        if g is None:
+            g = cls._cache[key] = cls(unroll)
+        return g
+
+    def commit(self):
+        _lib.check(_lib.lib().shine_iter_graph_commit(self.handle), "shine_iter_graph_commit")
+
+    def launch(self, replays):
+        _lib.check(_lib.lib().shine_iter_graph_launch(self.handle, int(replays), _lib.current_stream_handle()),
+                   "shine_iter_graph_launch")
+
+    def stats(self):
+        c, b = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().shine_iter_graph_stats(self.handle, C.byref(c), C.byref(b)), "shine_iter_graph_stats")
+        return int(c.value), int(b.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().shine_iter_graph_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+
 class GraphedIteration:
     """`eager_first` (default True): the constructor runs iteration 1 eagerly (it allocates the optimiser state and loads the
     kernels outside the capture), so a frame of K iterations is the constructor + run(K - 1).  False: nothing runs in the
@@ -68,7 +114,7 @@ class GraphedIteration:
     object every frame: the eager iteration costs ~0.1 ms of launches that a replay does in a third of the time)."""
 
     def __init__(self, octree, decoder, pool, opt, opts: StepOptions, n: int, lambda_forget: float = 0.0, unroll: int = 1,
-                 fold: bool = True, eager_first: bool = True, active_rows: bool = True):
+                 fold: bool = True, eager_first: bool = True, active_rows: bool = True, native: bool = True):
         self.octree, self.decoder, self.pool, self.opt, self.opts, self.n = octree, decoder, pool, opt, opts, int(n)
         self.lambda_forget = float(lambda_forget)
         self.fold = bool(fold)  # the iteration's tail as one launch (False: reduction, regulariser and Adam as three)
@@ -93,7 +139,12 @@ class GraphedIteration:
         self._hooked = None  # StepOptions with the iteration hooks (made once the optimiser has its device state)
         self._ahead = False
         dev_key = str(pool.coord.device)
-        self.ran_eager = bool(eager_first) or dev_key not in _WARMED or not (self.fold and hasattr(opt, "prepare_graph_safe"))
+        # `native`: the graph is BUILT by the library from the two launches of an iteration and re-bound in place for this
+        # object's buffers (IterationGraph) instead of being captured from the stream — nothing to warm up, nothing to capture:
+        # the constructor runs no iteration whatever `eager_first` says.  Needs the two-launch iteration (fold, the next draw
+        # inside the tail: n < 16 K).
+        self.native = bool(native and can_fold and self.n + 1 <= 16 * 1024)
+        self.ran_eager = (not self.native) and (bool(eager_first) or dev_key not in _WARMED or not can_fold)
         if can_fold:
             # the optimiser's device-side step state up front: the eager warm-up iteration then runs the SAME two launches the
             # graph replays (with active rows it has to: its rows must end up flagged "touched earlier")
@@ -117,6 +168,7 @@ class GraphedIteration:
         # each capture has its own output tensors)
         self.graph = self.graph_k = None
         self._out_1 = self._out_k = None
+        self._native = {}  # unroll -> (IterationGraph, outputs, keep-alive) bound to this object's buffers
 
     def _graph_1(self):
         if self.graph is None:
@@ -134,7 +186,19 @@ class GraphedIteration:
             self.graph_k, self._out_k = _capture(body_k)
         return self.graph_k
 
-    def _body(self):
+    def _bound(self, unroll):
+        """the library-built graph of `unroll` iterations, its kernel nodes naming this object's buffers"""
+        ent = self._native.get(unroll)
+        g = ent[0] if ent is not None else IterationGraph.shared(self.pool.coord.device, unroll)
+        if ent is None or g.owner is not self:
+            keep = {}
+            out = self._body(graph=g, keep=keep)
+            g.commit()
+            g.owner = self
+            ent = self._native[unroll] = (g, out, keep)
+        return ent
+
+    def _body(self, graph=None, keep=None):
         idx = self._idx if self._ahead else self.pool.draw(self.n, out=self._idx, graph_safe=True, surf_parts=self._surf)
         n_surf = self._surf
         # Iteration hooks: the step's reduction launch also counts the optimiser step (+ bias corrections) and clears the
@@ -154,13 +218,17 @@ class GraphedIteration:
         # vectors, regulariser, Adam, clearing the grads} (FusedAdam.finish_iteration) — 3 launches per iteration instead of 5
         fold = hooked and self.fold and hasattr(self.opt, "finish_iteration")
         pending = {} if fold else None
+        if graph is not None and not (fold and self._ahead):
+            raise RuntimeError("the library-built iteration graph holds the two-launch iteration (fold, next draw in the tail)")
         loss, _, _ = fused_train_step(self.octree, self.decoder, None, None, None, opts, n_surf=n_surf, pool=self.pool,
-                                      idx=idx, touched=self.touched, pending=pending)
+                                      idx=idx, touched=self.touched, pending=pending, graph=graph)
+        if keep is not None:
+            keep["pending"] = pending  # (every device buffer the nodes name stays alive with this object)
         if fold:
             self.opt.finish_iteration(pending, dict(lambda_forget=self.lambda_forget, touched=self.touched,
                                                     out=self._reg_out) if self.regularize else None,
                                       next_draw=self.pool.next_draw(self.n, self._idx, self._surf) if self._ahead else None,
-                                      active_flags=self.touched if self.active_rows else None)
+                                      active_flags=self.touched if self.active_rows else None, graph=graph)
             return loss, (self._reg_out[0] if self.regularize else None)
         reg = None
         if self.regularize:
@@ -172,6 +240,11 @@ class GraphedIteration:
         """Run one iteration; returns the loss of the fused terms as a 0-dim device tensor (no host sync)."""
         if self.octree._tables_epoch != self._epoch:
             raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
+        if self.native:
+            g, out, _ = self._bound(1)
+            g.launch(1)
+            self.loss, self.reg = out
+            return self.loss
         self._graph_1().replay()
         self.loss, self.reg = self._out_1
         return self.loss
@@ -181,6 +254,17 @@ class GraphedIteration:
         if self.octree._tables_epoch != self._epoch:
             raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
         k = self.unroll if self.unroll > 1 else 0
+        if self.native:
+            if k and n_iters >= k:
+                g, out, _ = self._bound(k)
+                g.launch(n_iters // k)
+                self.loss, self.reg = out
+                n_iters %= k
+            if n_iters:
+                g, out, _ = self._bound(1)
+                g.launch(n_iters)
+                self.loss, self.reg = out
+            return self.loss
         while k and n_iters >= k:
             self._graph_unrolled().replay()
             self.loss, self.reg = self._out_k

@@ -98,7 +98,7 @@ def forward_sdf(octree, decoder, coord, want_feat=False, want_indices=False, wan
 
 def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
                      n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None,
-                     pool=None, idx: Optional[torch.Tensor] = None, pending: Optional[dict] = None):
+                     pool=None, idx: Optional[torch.Tensor] = None, pending: Optional[dict] = None, graph=None):
     """One training iteration's forward+backward (no optimiser): the fused Tier-B step, raw form.
 
     coord [N,3], sdf_label [N], weight [N] (sign: + surface / - free space, utils/data_sampler.py:102-103).
@@ -110,9 +110,11 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     `pending` (a dict): the step launches its fused kernel only (cfg->defer_reduce) and leaves the per-workgroup partial sums
     — decoder grads, trash-row grads, loss terms — in the workspace for the optimiser's launch; the dict is filled with what
     FusedAdam.finish_iteration(pending, ...) needs, and `loss` is valid after that call.
+    `graph` (loop.IterationGraph, with `pending`): nothing is launched — the launch this call would make becomes the step node
+    of the library-built iteration graph (shine_iter_graph_set_step); outputs are valid after the graph ran.
     """
     return _fused_launch(octree, decoder, coord, sdf_label, weight, opts, want_grad_x=want_grad_x, perm=perm,
-                         n_surf=n_surf, slots=slots, touched=touched, pool=pool, idx=idx, pending=pending)
+                         n_surf=n_surf, slots=slots, touched=touched, pool=pool, idx=idx, pending=pending, graph=graph)
 
 
 def train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
@@ -136,7 +138,8 @@ def train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, wan
 
 def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
                   n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None,
-                  pool=None, idx: Optional[torch.Tensor] = None, gfeat=None, gmlp=None, dec_grad=None, pending=None):
+                  pool=None, idx: Optional[torch.Tensor] = None, gfeat=None, gmlp=None, dec_grad=None, pending=None,
+                  graph=None):
     """shine_train_step on explicit gradient buffers (gfeat: L tensors or None entries, gmlp: 6 tensors; default: the
     parameters' own dense `.grad`)."""
     t = octree._require_tables()
@@ -219,15 +222,19 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         cfg.defer_reduce = 1
         pending.clear()
         pending.update(cfg=cfg, n=n, workspace=ws, n_surf=n_surf, loss_parts=loss_parts, dec_grad=bool(dec_grad),
-                       octree=octree, decoder=decoder)
+                       octree=octree, decoder=decoder, pred=pred, gx=gx)
+    if graph is not None and pending is None:
+        raise ValueError("graph= records the deferred-reduction step: pass pending= too")
     # the product library trains on <= 4 featured levels (every shipped yaml: 3 or 4) with kernel_variant 0 / 4; the
     # lane-per-point reference kernel (1: any batch, <= 8 levels) is the check library's — tests / tools ask for it by name
     if variant != 1 and octree.featured_level_num > 4:
         raise NotImplementedError("the fused step handles tree_level_feat <= 4 (every shipped config); deeper trees only run "
                                   "on the check library's reference kernel (StepOptions.kernel_variant = 1, tests / tools)")
     library = _lib.check_lib() if variant == 1 else _lib.lib()
+    entry = library.shine_train_step if graph is None else \
+        (lambda *a: library.shine_iter_graph_set_step(graph.handle, *a[:-1]))  # (the same arguments minus the stream)
     _lib.check(
-        library.shine_train_step(
+        entry(
             t.handle, C.byref(cfg), coord.data_ptr(), sdf_label.data_ptr(),
             weight.data_ptr() if weight is not None else None,
             perm.data_ptr() if perm is not None else None,

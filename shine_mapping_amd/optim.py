@@ -226,7 +226,7 @@ def _prepare_graph_safe(self):
     return self._dev[0]
 
 
-def _finish_iteration(self, pending, regulariser=None, next_draw=None, active_flags=None):
+def _finish_iteration(self, pending, regulariser=None, next_draw=None, active_flags=None, graph=None):
     """The tail of an iteration in ONE launch (shine_finish_iteration): `pending` is the dict a
     fused_train_step(..., pending=...) filled — its partial sums are added up where they are consumed, the regulariser
     (regulariser = dict(lambda_forget, touched, out) as for ops.fused_regularization) is evaluated on the touched rows, Adam
@@ -235,7 +235,8 @@ def _finish_iteration(self, pending, regulariser=None, next_draw=None, active_fl
     step (StepOptions.adam_state = device_state()).
     active_flags (the per-level uint8 flags the step was given as `touched`): EXACT active-row Adam — the flags are kept sticky
     and rows whose flag is 0 (no gradient since this optimiser and the flags were created: m = v = g = 0, which torch's Adam
-    leaves bit for bit unchanged) are not read.  The caller zeroes the flags whenever it creates the optimiser."""
+    leaves bit for bit unchanged) are not read.  The caller zeroes the flags whenever it creates the optimiser.
+    graph (loop.IterationGraph): nothing is launched — the launch becomes the tail node of the library-built iteration graph."""
     if self._dev is None:
         raise RuntimeError("finish_iteration needs the device-side step state: run one step(graph_safe=True) first")
     octree, decoder = pending["octree"], pending["decoder"]
@@ -271,8 +272,12 @@ def _finish_iteration(self, pending, regulariser=None, next_draw=None, active_fl
             raise ValueError("finish_iteration: active_flags must be the regulariser's touched flags")
         touched = _lib.ptr_array([t.data_ptr() for t in active_flags])
     ns = pending["n_surf"]
+    lib = _lib.lib()
+    entry = lib.shine_finish_iteration if graph is None else \
+        (lambda *a: lib.shine_iter_graph_set_finish(graph.handle, *a[:-1]))  # (the same arguments minus the stream)
+    pending.setdefault("keep", []).extend(t[k] for _, t in sel for k in (1, 2))  # (the optimiser state the launch names)
     _lib.check(
-        _lib.lib().shine_finish_iteration(
+        entry(
             C.byref(cfg), pending["n"], pending["workspace"].data_ptr(), ns.data_ptr() if ns is not None else None,
             pending["loss_parts"].data_ptr(), last, imp, touched, grad_on, lam, reg_out, n,
             _lib.ptr_array([t[0].data_ptr() for _, t in sel]), _lib.ptr_array([t[0].grad.data_ptr() for _, t in sel]),

@@ -1037,10 +1037,12 @@ def test_device_node_ranks_equal_host_ranks():
 
 # ---------------------------------------------------------------------------------------------------------
 # graph-replayable iteration (loop.GraphedIteration): device-resident sampler stream id and Adam step count
+@pytest.mark.parametrize("native", [True, False])
 @pytest.mark.parametrize("mode", ["bce", "incremental", "eikonal"])
-def test_graphed_iteration_matches_eager_loop(mode):
-    """K iterations through ONE captured HIP graph == K eager iterations: same batches (the stream id advances on the
-    device), same Adam bias corrections (the step count advances on the device), same parameters."""
+def test_graphed_iteration_matches_eager_loop(mode, native):
+    """K iterations through ONE HIP graph == K eager iterations: same batches (the stream id advances on the device), same
+    Adam bias corrections (the step count advances on the device), same parameters.  native: the graph is built and bound by
+    the library (shine_iter_graph_*) / captured from the stream by torch."""
     from shine_mapping_amd import StepOptions, fused_train_step, synth
     from shine_mapping_amd.loop import GraphedIteration
     from shine_mapping_amd.ops import fused_regularization, touched_flags
@@ -1086,15 +1088,17 @@ def test_graphed_iteration_matches_eager_loop(mode):
 
     # the same K iterations: 1 eager inside the constructor + K-1 replays of the captured graph
     cfg, octree2, dec2, opt2, pool2, opts2 = make()
-    step = GraphedIteration(octree2, dec2, pool2, opt2, opts2, N, lambda_forget=1e3 if incremental else 0.0)
+    step = GraphedIteration(octree2, dec2, pool2, opt2, opts2, N, lambda_forget=1e3 if incremental else 0.0, native=native)
+    assert step.native == native
+    first = 1 if step.ran_eager else 0  # (the torch-captured form runs iteration 1 eagerly in its constructor)
     # the optimiser's launch draws the NEXT iteration's batch: after iteration k, `_idx` holds batch k + 1
-    assert step._ahead and torch.equal(step._idx, eager_idx[1])
+    assert step._ahead and torch.equal(step._idx, eager_idx[first])
     seen = []
-    for it in range(1, K):
+    for it in range(first, K):
         loss = step()
         seen.append(step._idx.clone())
     torch.cuda.synchronize()
-    assert all(torch.equal(a, b) for a, b in zip(seen, eager_idx[2:])), "replays must draw the eager loop's batches"
+    assert all(torch.equal(a, b) for a, b in zip(seen, eager_idx[first + 1:])), "replays must draw the eager loop's batches"
     assert not torch.equal(seen[0], seen[1])
     assert opt2.steps_taken() == K and float(loss) == float(loss)
     # Both loops run the step in its DETERMINISTIC mode (StepOptions.deterministic: one wave walks the batch, the feature-grad

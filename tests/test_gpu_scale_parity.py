@@ -658,10 +658,12 @@ def test_touched_row_exchange_device_path():
     assert torch.equal(fake.msgs[0], fake2.msgs[0])
 
 
-def test_unrolled_graph_replays_draw_the_same_batches_and_count_the_same_steps():
+@pytest.mark.parametrize("native", [True, False])
+def test_unrolled_graph_replays_draw_the_same_batches_and_count_the_same_steps(native):
     """loop.GraphedIteration(unroll=k): k iterations per HIP graph.  run(n) must leave the sampler's stream id and Adam's
     step count exactly where n single-iteration replays leave them (both live in device memory and are advanced by the
-    kernels), i.e. the NEXT draw is the same batch either way."""
+    kernels), i.e. the NEXT draw is the same batch either way.  native: the graph built by the library (shine_iter_graph_*,
+    nothing runs in the constructor) / captured from the stream by torch (the constructor runs iteration 1 eagerly)."""
     from shine_mapping_amd import StepOptions
     from shine_mapping_amd.loop import GraphedIteration
     from shine_mapping_amd.optim import setup_optimizer
@@ -680,14 +682,15 @@ def test_unrolled_graph_replays_draw_the_same_batches_and_count_the_same_steps()
 
     n_iters, N = 11, 1024
     o1, d1, opt1, p1, s1 = make()
-    one = GraphedIteration(o1, d1, p1, opt1, s1, N)
+    one = GraphedIteration(o1, d1, p1, opt1, s1, N, native=native)
+    assert one.native == native and one.ran_eager == (not native)
     for _ in range(n_iters):
         one()
     o2, d2, opt2, p2, s2 = make()
-    many = GraphedIteration(o2, d2, p2, opt2, s2, N, unroll=4)
+    many = GraphedIteration(o2, d2, p2, opt2, s2, N, unroll=4, native=native)
     many.run(n_iters)  # 2 x 4 + 3 x 1
     torch.cuda.synchronize()
-    assert opt1.steps_taken() == opt2.steps_taken() == n_iters + 1
+    assert opt1.steps_taken() == opt2.steps_taken() == n_iters + (0 if native else 1)
     assert torch.equal(one._idx, many._idx)  # the last batch drawn
     one()
     many()
@@ -941,8 +944,9 @@ def test_the_iteration_tail_as_one_launch_equals_the_three_launches(mode):
                            ekional_loss_on=mode == "eikonal", weight_e=0.1,
                            decoder_grad_on=False if mode == "frozen-decoder" else None)
         it = GraphedIteration(octree, dec, pool, opt, opts, N, lambda_forget=1e3 if incremental else 0.0, fold=fold)
+        assert it.native == fold  # the one-launch tail runs from the library-built graph: no eager iteration in the constructor
         losses, regs = [], []
-        for _ in range(K):
+        for _ in range(K + (0 if it.ran_eager else 1)):
             loss = it()
             losses.append(float(loss))
             regs.append(float(it.reg) if it.reg is not None else 0.0)
@@ -964,6 +968,7 @@ def test_the_iteration_tail_as_one_launch_equals_the_three_launches(mode):
 
     a, b = run(True), run(False)
     assert a[5] == b[5] == K + 1
+    a = (a[0][1:], a[1][1:]) + a[2:]  # (run(False)'s first iteration ran inside the constructor: its loss was not recorded)
     for x, y in zip(a[0], b[0]):
         assert abs(x - y) <= 1e-6 * max(1.0, abs(y))
     for x, y in zip(a[1], b[1]):
@@ -1085,10 +1090,13 @@ def test_first_pass_of_the_next_draw_rides_on_the_step(n, world):
 
 
 @pytest.mark.gpu
-def test_graphed_iteration_without_the_eager_first_iteration():
-    """loop.GraphedIteration(eager_first=False): nothing runs in the constructor (the optimiser's device state is created
-    explicitly, the graph captured straight away) and run(K) does all K iterations — same batches, same step count, same
-    parameters (deterministic mode) as the default form, whose constructor runs iteration 1 eagerly."""
+@pytest.mark.parametrize("native", [False, True])
+def test_graphed_iteration_without_the_eager_first_iteration(native):
+    """loop.GraphedIteration(eager_first=False) and the library-built graph (native=True): nothing runs in the constructor
+    (the optimiser's device state is created explicitly, the graph captured straight away / re-bound) and run(K) does all K
+    iterations — same batches, same step count, same parameters (deterministic mode) as the torch-captured form whose
+    constructor runs iteration 1 eagerly.  native=True also checks that a second object RE-BINDS the shared graph instead of
+    building a new one (shine_iter_graph_stats)."""
     from shine_mapping_amd import StepOptions
     from shine_mapping_amd.loop import GraphedIteration
     from shine_mapping_amd.optim import setup_optimizer
@@ -1108,14 +1116,28 @@ def test_graphed_iteration_without_the_eager_first_iteration():
 
     K, N = 7, 4096
     o1, d1, opt1, p1, s1 = make()
-    a = GraphedIteration(o1, d1, p1, opt1, s1, N, lambda_forget=1e3)  # (also makes the device "warmed" for the second form)
+    a = GraphedIteration(o1, d1, p1, opt1, s1, N, lambda_forget=1e3, native=False)  # (also "warms" the device for the second form)
     assert a.ran_eager
     a.run(K - 1)
     o2, d2, opt2, p2, s2 = make()
-    b = GraphedIteration(o2, d2, p2, opt2, s2, N, lambda_forget=1e3, eager_first=False)
-    assert not b.ran_eager and opt2.steps_taken() == 0
+    b = GraphedIteration(o2, d2, p2, opt2, s2, N, lambda_forget=1e3, eager_first=False, native=native)
+    assert not b.ran_eager and opt2.steps_taken() == 0 and b.native == native
     b.run(K)
     torch.cuda.synchronize()
+    if native:
+        from shine_mapping_amd.loop import IterationGraph
+
+        g = IterationGraph.shared(p2.coord.device, 1)
+        commits, builds = g.stats()
+        o3, d3, opt3, p3, s3 = make()
+        c = GraphedIteration(o3, d3, p3, opt3, s3, N, lambda_forget=1e3)
+        c.run(K)
+        torch.cuda.synchronize()
+        commits2, builds2 = g.stats()
+        assert commits2 == commits + 1 and builds2 == builds, "a new object re-binds the graph: no build, no instantiation"
+        assert opt3.steps_taken() == K and torch.equal(c._idx, b._idx)
+        for x, y in zip(list(o3.hier_features) + d3.fused_params(), list(o2.hier_features) + d2.fused_params()):
+            assert rel_err(y.detach(), x.detach()) <= 1e-6
     assert opt1.steps_taken() == opt2.steps_taken() == K
     assert torch.equal(a._idx, b._idx)  # the batch iteration K + 1 would use
     assert abs(float(a.loss) - float(b.loss)) <= 1e-6 * abs(float(a.loss))
