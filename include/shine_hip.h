@@ -155,6 +155,14 @@ int shine_forward(const shine_tables* t, const shine_step_config* cfg, const flo
                   const float* const* feats, const int64_t* rows, const float* const* mlp, float* feat_out,
                   float* pred_out, int64_t* const* idx_out, float* grad_x_out, void* stream);
 
+/* ---- Tier A (strict drop-in): sdf_bce_loss (utils/loss.py:17-24) = BCEWithLogitsLoss(reduction, weight)(pred,
+ *      sigmoid(sdf_label / sigma)) and its derivative in ONE launch: *loss_out (device float) = the mean (reduction_sum = 0)
+ *      or the sum of the per-sample terms, each multiplied by weight[i] when weight != NULL (loss_weight_on);
+ *      dpred_out [n] (or NULL) = d loss / d pred — what autograd's backward of the torch composite produces in three more
+ *      launches.  One workgroup (the reference's batch sizes are a few thousand points). */
+int shine_bce_loss(const float* pred, const float* sdf_label, const float* weight, int64_t n, float sigma,
+                   int32_t reduction_sum, float* loss_out, float* dpred_out, void* stream);
+
 /* ---- Tier A (strict drop-in): the backward of FeatureOctree.query_feature as autograd derives it from
  *      model/feature_octree.py:222-234, and its own backward (needed by get_gradient(create_graph=True),
  *      utils/tools.py:175-185, when the eikonal term is differentiated, shine_batch.py:182-185).
@@ -189,9 +197,15 @@ int shine_mlp_backward_backward(const float* feat, const float* grad_pred, const
  *      backward, decoder weight grads and the interpolation backward with the run-merged scatter in ONE fused launch
  *      (+ the partial-sum reduction).  The batch must be planned (perm, slots: shine_plan_batch); grad_pred is indexed like
  *      the batch.  grad_feats[s] [rows_s+1, 8] and grad_mlp[6] (NULL entries / cfg->decoder_grad_on = 0: skipped) are
- *      ACCUMULATED INTO.  No loss options: the loss is the caller's (any torch code). ------------------------------------ */
+ *      ACCUMULATED INTO.  No loss options: the loss is the caller's (any torch code).
+ *      grad_g (NULL, or [N, 3] indexed like the batch) = d loss / d g for g = cfg->sigma * d pred / d coord, i.e. what
+ *      get_gradient(coord, pred) returns (utils/tools.py:175-185; the drivers multiply sigma_sigmoid in afterwards, so the
+ *      host side passes cfg->sigma = 1): with it the same launch also backpropagates the eikonal chain (shine_batch.py:141-142,
+ *      182-185) — autograd's second, double-backward pass through get_gradient(create_graph=True) — in closed form
+ *      (SURVEY.md §8a), grad_pred being whatever reaches pred from the rest of the loss. ------------------------------------ */
 int shine_interp_sdf_backward(const shine_tables* t, const shine_step_config* cfg, const float* coord, const int32_t* perm,
-                              const int32_t* slots, const float* grad_pred, int64_t n, const float* const* feats,
+                              const int32_t* slots, const float* grad_pred, const float* grad_g, int64_t n,
+                              const float* const* feats,
                               const int64_t* rows, const float* const* mlp, float* const* grad_feats,
                               float* const* grad_mlp, void* workspace, size_t workspace_bytes, void* stream);
 

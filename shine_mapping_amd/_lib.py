@@ -85,7 +85,7 @@ _SIGNATURES = {
     ),
     "shine_interp_sdf_backward": (
         C.c_int,
-        [_P, C.POINTER(StepConfig), _P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P),
+        [_P, C.POINTER(StepConfig), _P, _P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P),
          C.POINTER(_P), C.POINTER(_P), _P, C.c_size_t, _P],
     ),
     "shine_regularize": (
@@ -145,6 +145,7 @@ _SIGNATURES = {
         C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P,
                   C.POINTER(_P), _P]),
     # the iteration graph: set_step / set_finish take the arguments of shine_train_step / shine_finish_iteration minus the stream
+    "shine_bce_loss": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_int32, _P, _P, _P]),
     "shine_iter_graph_create": (C.c_int, [C.c_int32, C.POINTER(_P)]),
     "shine_iter_graph_destroy": (C.c_int, [_P]),
     "shine_iter_graph_commit": (C.c_int, [_P]),

@@ -4,9 +4,10 @@ Tier A (strict drop-in): the reference builds the interpolation 
 autograd differentiate it, twice when the eikonal term is on (get_gradient(create_graph=True), utils/tools.py:175-185).
 Here `FeatureOctree.query_feature` is OctreeInterp and `Decoder.sdf` is FusedMLP: forward, backward and
 backward-of-backward are one HIP kernel each.  When the drivers' usual sequence `feature = octree.query_feature(coord);
-pred = geo_mlp.sdf(feature)` (shine_batch.py:123-124) reaches `sdf` with the feature tensor untouched and no gradient is
-wanted for `coord`, the two calls collapse into ONE node, FusedInterpSdf, whose backward is one fused launch (the Tier-B
-kernel fed with autograd's d loss / d pred) — the split nodes remain the fallback for everything else.
+pred = geo_mlp.sdf(feature)` (shine_batch.py:123-124) reaches `sdf` with the feature tensor untouched, the two calls collapse
+into ONE node, FusedInterpSdf, whose backward is one fused launch (the Tier-B kernel fed with autograd's d loss / d pred — and,
+in the eikonal configurations, with d loss / d g from the node losses.get_gradient creates) — the split nodes remain the
+fallback for everything else.
 
 Tier B: ShineTrainStep — the whole iteration (query, decode, loss, backward) as one node.
 """
@@ -34,7 +35,7 @@ class OctreeInterp(torch.autograd.Function):
     def forward(ctx, coord, octree, *feats):
         from .ops import _interp_forward
 
-        feat = _interp_forward(octree, coord)
+        feat = _interp_forward(octree, coord, want_indices=False)  # (a training loop: the indices are computed on demand)
         ctx.octree = octree
         ctx.save_for_backward(coord, *feats)
         return feat
@@ -222,20 +223,32 @@ class FusedMLPBackward(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------------------------------
 
 
+# The fused node may take a batch whose `coord` asks for a gradient (the eikonal configurations: coord.requires_grad_(True),
+# shine_batch.py:119-120) only if g = d pred / d coord is then obtained through losses.get_gradient — the fused counterpart of
+# utils/tools.py:175-185 that dropin installs under the reference's name.  torch.autograd.grad(create_graph=True) straight
+# through the fused node is refused (its backward is one non-differentiable launch), so without that function the eikonal
+# configurations keep the split, twice-differentiable nodes.
+FUSE_WITH_COORD_GRAD = False
+
+
 class FeatureSource:
     """What FeatureOctree.query_feature remembers about the tensor it returned (attached as `feature._shine_src`): enough for
-    Decoder.sdf to recognise "the untouched output of query_feature" and run the fused node instead of the split ones."""
+    Decoder.sdf to recognise "the untouched output of query_feature" and run the fused node instead of the split ones; the
+    same object links the fused node to the node get_gradient creates (InterpSdfGradCoord), whose backward leaves
+    d loss / d g here for the fused launch to pick up."""
 
-    __slots__ = ("octree", "coord", "version", "epoch")
+    __slots__ = ("octree", "coord", "version", "epoch", "q", "pred")
 
     def __init__(self, octree, coord, feature):
         self.octree, self.coord = octree, coord
         self.version = feature._version
         self.epoch = octree._tables_epoch
+        self.q = None     # d loss / d (d pred / d coord), stashed by InterpSdfGradCoord.backward
+        self.pred = None  # the fused node's output (weak identity check in get_gradient)
 
     def fusable(self, feature) -> bool:
         return (feature._version == self.version and self.octree._tables_epoch == self.epoch
-                and not self.coord.requires_grad and self.octree.featured_level_num <= 4
+                and (FUSE_WITH_COORD_GRAD or not self.coord.requires_grad) and self.octree.featured_level_num <= 4
                 and feature.dim() == 2 and feature.shape[0] == self.coord.shape[0] and feature.shape[0] > 0)
 
 
@@ -246,11 +259,14 @@ class FusedInterpSdf(torch.autograd.Function):
     is planned (shine_plan_batch: node order + hash slots) and ONE fused launch (shine_interp_sdf_backward: the Tier-B
     kernel with d loss / d pred = g) produces every gradient — decoder backward, decoder weight grads, interpolation
     backward with one atomic per node run — into views of one freshly zeroed flat buffer, which autograd adopts as `.grad`
-    (no per-table zeros_like, no index_put).  No gradient for coord (Decoder.sdf only picks this node when coord does not
-    ask for one) and no double backward: the eikonal configurations stay on the split nodes."""
+    (no per-table zeros_like, no index_put).  Eikonal configurations: g = get_gradient(coord, pred) is its own node
+    (InterpSdfGradCoord) that takes `pred` as an input, so autograd runs ITS backward first; it leaves d loss / d g in the
+    shared FeatureSource and the fused launch here backpropagates both chains at once (the eikonal build of the kernel, closed
+    form of SURVEY.md §8a) — what the split nodes do in five double-backward launches.  coord itself gets no gradient (the
+    reference fills coord.grad, nothing reads it)."""
 
     @staticmethod
-    def forward(ctx, feat_values, coord, octree, *params):
+    def forward(ctx, feat_values, coord, octree, src, *params):
         L = octree.featured_level_num
         mlp = [_f32c(p) for p in params[L:]]  # kept alive across the launch (a temporary's block could be re-used under it)
         f = _f32c(feat_values)
@@ -258,27 +274,35 @@ class FusedInterpSdf(torch.autograd.Function):
         pred = torch.empty(n, dtype=torch.float32, device=f.device)
         _lib.check(_lib.lib().shine_mlp_forward(f.data_ptr(), n, _lib.ptr_array([p.data_ptr() for p in mlp]), pred.data_ptr(),
                                                 _stream()), "shine_mlp_forward")
-        ctx.octree = octree
+        ctx.octree, ctx.src = octree, src
         ctx.save_for_backward(coord, *params)
+        ctx.set_materialize_grads(False)
         return pred
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         from .dp import plan_batch
         from .ops import _workspace
 
+        if torch.is_grad_enabled():
+            raise RuntimeError("FusedInterpSdf: a differentiable backward (torch.autograd.grad(..., create_graph=True)) through "
+                               "the fused query_feature -> sdf node: use shine_mapping_amd.losses.get_gradient (installed as "
+                               "utils.tools.get_gradient by shine_mapping_amd.dropin), or set "
+                               "autograd_ops.FUSE_WITH_COORD_GRAD = False to keep the split nodes")
         coord, *params = ctx.saved_tensors
-        octree = ctx.octree
+        octree, src = ctx.octree, ctx.src
+        q, src.q = src.q, None
         L = octree.featured_level_num
         feats, mlp = params[:L], params[L:]
-        need_f = [bool(x) for x in ctx.needs_input_grad[3:3 + L]]
-        need_m = any(ctx.needs_input_grad[3 + L:])
+        need_f = [bool(x) for x in ctx.needs_input_grad[4:4 + L]]
+        need_m = any(ctx.needs_input_grad[4 + L:])
+        if g is None and q is None:
+            return (None,) * (4 + len(params))
         t = octree._require_tables(with_ranks=True)
         c = octree._check_coord(coord.detach())
         n = c.shape[0]
         dev = c.device
-        g = _f32c(g)
+        g = _f32c(g) if g is not None else torch.zeros(n, dtype=torch.float32, device=dev)
         perm, slots = plan_batch(octree, c)
         sizes = [p.numel() if nf else 0 for p, nf in zip(feats, need_f)] + [p.numel() if need_m else 0 for p in mlp]
         flat = torch.zeros((sum(sizes) + 3) // 4 * 4, dtype=torch.float32, device=dev)
@@ -292,7 +316,8 @@ class FusedInterpSdf(torch.autograd.Function):
         ws = _workspace(dev, cfg)
         _lib.check(
             _lib.lib().shine_interp_sdf_backward(
-                t.handle, C.byref(cfg), c.data_ptr(), perm.data_ptr(), slots.data_ptr(), g.data_ptr(), n,
+                t.handle, C.byref(cfg), c.data_ptr(), perm.data_ptr(), slots.data_ptr(), g.data_ptr(),
+                q.data_ptr() if q is not None else None, n,
                 _lib.ptr_array([f.data_ptr() for f in feats_c]), octree.row_counts(),
                 _lib.ptr_array([p.data_ptr() for p in mlp_c]),
                 _lib.ptr_array([v.data_ptr() if v is not None else None for v in views[:L]]),
@@ -301,7 +326,42 @@ class FusedInterpSdf(torch.autograd.Function):
             ),
             "shine_interp_sdf_backward",
         )
-        return (None, None, None) + tuple(views)
+        return (None, None, None, None) + tuple(views)
+
+
+class InterpSdfGradCoord(torch.autograd.Function):
+    """raw = d pred / d coord [N, 3] for the pred of a FusedInterpSdf node — get_gradient(coord, pred) of utils/tools.py:175-185
+    (grad_outputs = ones) without running autograd backwards: ONE launch of the forward kernel in its closed-form d pred /
+    d coord build (shine_forward grad_x_out).  Differentiable: its backward hands d loss / d raw to the fused node (which
+    autograd runs afterwards, because `pred` is an input here) instead of launching anything itself."""
+
+    @staticmethod
+    def forward(ctx, pred, coord, octree, src, *params):
+        L = octree.featured_level_num
+        t = octree._require_tables()
+        c = octree._check_coord(coord.detach())
+        n = c.shape[0]
+        feats_c = [_f32c(p) for p in params[:L]]
+        mlp_c = [_f32c(p) for p in params[L:]]
+        raw = torch.empty((n, 3), dtype=torch.float32, device=c.device)
+        cfg = octree.step_config(sigma=1.0)
+        _lib.check(
+            _lib.lib().shine_forward(t.handle, C.byref(cfg), c.data_ptr(), n, _lib.ptr_array([f.data_ptr() for f in feats_c]),
+                                     octree.row_counts(), _lib.ptr_array([p.data_ptr() for p in mlp_c]), None, None, None,
+                                     raw.data_ptr(), _stream()),
+            "shine_forward")
+        ctx.src = src
+        ctx.n_in = 4 + len(params)
+        ctx.set_materialize_grads(False)
+        return raw
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gq):
+        if gq is not None:
+            q = _f32c(gq)
+            ctx.src.q = q if ctx.src.q is None else ctx.src.q + q
+        return (None,) * ctx.n_in
 
 
 # ----------------------------------------------------------------------------------------------------------------------

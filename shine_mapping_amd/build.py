@@ -3,9 +3,8 @@
     python -m shine_mapping_amd.build [--force]
 
   lib/libshine_hip.so    the PRODUCT: csrc/*.hip — the fused step (shine_step_v3.hip) and everything around it
-  lib/libshine_check.so  the product's objects with shine_step_v0.hip compiled -DSHINE_V0_TRAIN=1 (the training
-                         instantiations of the lane-per-point kernel): the on-device cross-check of the GPU tests.  Only
-                         tests / tools load it (StepOptions.kernel_variant 1).
+  lib/libshine_check.so  the product's objects + shine_step_v0.hip (the lane-per-point reference step): the on-device
+                         cross-check of the GPU tests.  Only tests / tools load it (StepOptions.kernel_variant 1).
 
 Both land in shine_mapping_amd/lib/ (git-ignored, but they travel with the gpurun snapshot).
 """
@@ -26,8 +25,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(os.path.dirname(HERE), "include")]
 
 
+CHECK_ONLY = ("shine_step_v0.hip",)  # the lane-per-point reference step: tests / tools only
+
+
 def sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    """the product library's translation units"""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and f not in CHECK_ONLY)
 
 
 def _digest():
@@ -64,8 +67,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return obj
 
     product = [(os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace(".hip", ".o")), []) for src in sources()]
-    v0_train = (os.path.join(CSRC, "shine_step_v0.hip"), os.path.join(OBJDIR, "check_shine_step_v0_train.o"),
-                ["-DSHINE_V0_TRAIN=1"])
+    v0_train = (os.path.join(CSRC, "shine_step_v0.hip"), os.path.join(OBJDIR, "check_shine_step_v0_train.o"), [])
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, product + [v0_train]))
     n = len(product)
@@ -80,9 +82,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
 
     link(LIB, product_objs)
-    # the check library: the same objects, the forward-only shine_step_v0.o replaced by the one that also trains
-    v0_obj = os.path.join(OBJDIR, "shine_step_v0.o")
-    link(CHECK_LIB, [o for o in product_objs if o != v0_obj] + check_objs)
+    # the check library: the product's objects + the lane-per-point reference step
+    link(CHECK_LIB, product_objs + check_objs)
     open(stamp, "w").write(dig)
     return LIB
 

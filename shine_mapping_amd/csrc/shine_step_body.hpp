@@ -21,14 +21,15 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 
 // EXT: the backward half of Tier A's fused node (autograd_ops.FusedInterpSdf): d loss / d pred comes from autograd
 // (a.ext_delta) instead of the kernel's own BCE — query, decoder forward, decoder backward, weight grads and scatter are the
-// same code.
+// same code.  EXT + EIK: autograd also hands over d loss / d g for g = d pred / d coord (a.ext_q, the gradient that reaches
+// get_gradient's output, utils/tools.py:175-185): the closed-form eikonal chain then backpropagates THAT instead of the
+// kernel's own (1 - |g|)^2 term — whatever the driver built on g (shine_batch.py:182-185 or another loss).
 // MARK: the touched-row flags (for shine_regularize) are set by the scatter at the run start of every hit node instead of by a
 // k_mark_touched launch in front of the step — a build of its own, because the flag code costs the kernel ~10 % at 2^18
 // points even when there are no flags to set (profiles/r03_ab_experiments.txt block 3), and pays at the incremental
 // configuration's 4096 points, where the extra launch is half the step (ncd-incre 172 -> 179 frames/s).
 template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false>
 __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm, const int bid, const int nbid) {
-  static_assert(!(EXT && EIK), "the external-delta build backpropagates one scalar per point (no eikonal chain)");
   constexpr int NT = WAVES * 64;
   float* const s_opA = sm.opA;
   float* const s_bias = sm.bias;
@@ -118,7 +119,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     nx1 = a.coord[3 * np + 1];
     nx2 = a.coord[3 * np + 2];
     nlabel = a.label[np];
-    if (EIK || a.weighted) nweight = a.weight[np];
+    if ((EIK && !EXT) || a.weighted) nweight = a.weight[np];
   }
 
   decoder_operands_store<NT>(opr, s_opA, s_bias, tid);
@@ -287,7 +288,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
         nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
         nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
         nlabel = __builtin_nontemporal_load(a.label + np);
-        if (EIK || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
+        if ((EIK && !EXT) || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
       }
       if (a.perm && ni2 < end) np2 = __builtin_nontemporal_load(a.perm + ni2);
     }
@@ -485,7 +486,13 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
       a.grad_x[3 * po + 1] = gx[1];
       a.grad_x[3 * po + 2] = gx[2];
     }
-    if (valid && wgt > 0.f) {  // surface samples only (shine_batch.py:137,183)
+    if (EXT) {  // d loss / d g from autograd
+      if (valid) {
+        qv[0] = a.ext_q[3 * po];
+        qv[1] = a.ext_q[3 * po + 1];
+        qv[2] = a.ext_q[3 * po + 2];
+      }
+    } else if (valid && wgt > 0.f) {  // surface samples only (shine_batch.py:137,183)
       const float gn = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
       const float ee = 1.0f - gn;
       if (g == 0) eik_acc += ee * ee;

@@ -39,6 +39,7 @@ struct V1Args {
   int defer_reduce;         // cfg->defer_reduce: no reduction launch; the fused kernel serves the iteration hooks itself
   const float* ext_delta;  // Tier A backward (shine_interp_sdf_backward): d loss / d pred per point, indexed like pred;
                            // the kernel then skips its own loss and backpropagates this instead
+  const float* ext_q;      // ... and d loss / d g [n, 3] for g = sigma d pred / d coord (the eikonal build of that backward)
   const float* mlp[6];
   float* pred;
   float* grad_x;

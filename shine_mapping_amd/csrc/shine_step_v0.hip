@@ -1,4 +1,4 @@
-// shine_step_v0.hip — first correct gfx950 path for the SHINE hot path: one lane per point.
+// shine_step_v0.hip — first correct gfx950 path for the SHINE hot path: one lane per point.  CHECK LIBRARY ONLY since round 4.
 //
 //   query   : FeatureOctree.query_feature      model/feature_octree.py:199-244
 //   decode  : Decoder.sdf                      model/decoder.py:49-63
@@ -404,30 +404,6 @@ __global__ __launch_bounds__(256) void k_step_v0(StepArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_query_indices(LevelSet ls, const float* coord, long long n, int L,
-                                                        long long* o0, long long* o1, long long* o2, long long* o3,
-                                                        long long* o4, long long* o5, long long* o6, long long* o7) {
-  long long* outs[SHINE_MAX_LEVELS] = {o0, o1, o2, o3, o4, o5, o6, o7};
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
-    float x0 = coord[3 * p], x1 = coord[3 * p + 1], x2 = coord[3 * p + 2];
-#pragma unroll
-    for (int s = 0; s < SHINE_MAX_LEVELS; ++s) {
-      if (s >= L) break;
-      const LevelDev& Lv = ls.lv[s];
-      unsigned long long key = morton3(quantize(x0, Lv.res), quantize(x1, Lv.res), quantize(x2, Lv.res));
-      int slot = probe(Lv, key);
-      int4 v0 = make_int4(-1, -1, -1, -1), v1 = v0;
-      if (slot >= 0) {
-        v0 = Lv.vals[2 * slot];
-        v1 = Lv.vals[2 * slot + 1];
-      }
-      long long* o = outs[L - 1 - s] + p * 8;
-      o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w;
-      o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
-    }
-  }
-}
-
 static unsigned grid_for(long long n) {
   long long tiles = (n + 255) / 256;
   long long cap = 256 * 4;  // persistent: 4 blocks per CU
@@ -447,60 +423,9 @@ static void launch_v0(const StepArgs& a, bool poly, hipStream_t st) {
 
 using namespace shine;
 
-extern "C" int shine_query_indices(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,
-                                   int64_t* const* idx_out, void* stream) {
-  if (n < 0 || !idx_out || (n > 0 && !coord)) return set_error(SHINE_E_INVALID, "shine_query_indices: null argument");
-  LevelSet ls = {};
-  int rc = make_level_set(t, cfg, nullptr, nullptr, nullptr, &ls);
-  if (rc != SHINE_OK) return rc;
-  if (n == 0) return SHINE_OK;
-  long long* o[SHINE_MAX_LEVELS] = {};
-  for (int i = 0; i < cfg->n_levels; ++i) {
-    if (!idx_out[i]) return set_error(SHINE_E_INVALID, "shine_query_indices: null output level");
-    o[i] = (long long*)idx_out[i];
-  }
-  hipLaunchKernelGGL(k_query_indices, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, ls, coord, (long long)n,
-                     (int)cfg->n_levels, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
-  SHINE_HIP_CHECK(hipGetLastError());
-  return SHINE_OK;
-}
-
-extern "C" int shine_forward(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,
-                             const float* const* feats, const int64_t* rows, const float* const* mlp, float* feat_out,
-                             float* pred_out, int64_t* const* idx_out, float* grad_x_out, void* stream) {
-  if (n < 0 || !feats || !rows || !mlp || (n > 0 && !coord))
-    return set_error(SHINE_E_INVALID, "shine_forward: null argument");
-  StepArgs a = {};
-  int rc = make_level_set(t, cfg, feats, rows, nullptr, &a.ls);
-  if (rc != SHINE_OK) return rc;
-  for (int s = 0; s < cfg->n_levels; ++s)
-    if (!feats[s]) return set_error(SHINE_E_INVALID, "shine_forward: null feature level");
-  for (int k = 0; k < 6; ++k) {
-    if (!mlp[k]) return set_error(SHINE_E_INVALID, "shine_forward: null decoder parameter");
-    a.mlp[k] = mlp[k];
-  }
-  if (n == 0) return SHINE_OK;
-  a.coord = coord;
-  a.n = n;
-  a.n_levels = cfg->n_levels;
-  a.sigma = cfg->sigma;
-  a.pred = pred_out;
-  a.feat_out = feat_out;
-  a.grad_x = grad_x_out;
-  if (idx_out)
-    for (int i = 0; i < cfg->n_levels; ++i) a.idx_out[i] = (long long*)idx_out[i];
-  if (grad_x_out)
-    launch_v0<true, false>(a, cfg->poly_int_on != 0, (hipStream_t)stream);
-  else
-    launch_v0<false, false>(a, cfg->poly_int_on != 0, (hipStream_t)stream);
-  SHINE_HIP_CHECK(hipGetLastError());
-  return SHINE_OK;
-}
-
-#ifndef SHINE_V0_TRAIN  // 1 in the check library (libshine_check.so): the lane-per-point kernel as the on-device cross-check of
-#define SHINE_V0_TRAIN 0  // the fused step and the step for trees with more than 4 featured levels; the product library
-#endif                    // instantiates the forward forms only (shine_forward)
-#if SHINE_V0_TRAIN
+// This file is part of the CHECK library only (libshine_check.so, tests / tools): the lane-per-point kernel as the on-device
+// cross-check of the fused step (StepOptions.kernel_variant = 1).  The product library's forward entry points live in
+// shine_forward.hip.
 extern "C" int shine_train_step_v0(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                                    const float* sdf_label, const float* weight, const int32_t* perm,
                                    const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,
@@ -552,4 +477,3 @@ extern "C" int shine_train_step_v0(const shine_tables* t, const shine_step_confi
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }
-#endif

@@ -182,15 +182,20 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
 // (shine_batch.py:208-209) through those two calls, as ONE fused launch (+ the partial-sum reduction): decoder backward,
 // decoder weight grads, interpolation backward with the run-merged scatter.  Planned batch (perm, slots from
 // shine_plan_batch); grad_pred is indexed like the batch.  grad_feats / grad_mlp are ACCUMULATED INTO.
+// grad_g (or NULL) = d loss / d g [n, 3] for g = get_gradient(coord, pred) (utils/tools.py:175-185, WITHOUT the sigma factor the
+// drivers multiply in afterwards, cfg->sigma = 1): the eikonal build of the same kernel backpropagates both chains in the one
+// launch — what autograd derives through get_gradient(create_graph=True) as a second, double-backward pass.
 extern "C" int shine_interp_sdf_backward(const shine_tables* t, const shine_step_config* cfg, const float* coord,
-                                         const int32_t* perm, const int32_t* slots, const float* grad_pred, int64_t n,
+                                         const int32_t* perm, const int32_t* slots, const float* grad_pred,
+                                         const float* grad_g, int64_t n,
                                          const float* const* feats, const int64_t* rows, const float* const* mlp,
                                          float* const* grad_feats, float* const* grad_mlp, void* workspace,
                                          size_t workspace_bytes, void* stream) {
   if (!cfg || !perm || !slots || !grad_pred)
     return set_error(SHINE_E_INVALID, "shine_interp_sdf_backward: needs a planned batch (perm, slots) and grad_pred");
   if (cfg->eikonal_on || cfg->loss_weight_on || cfg->sorted_input == 2)
-    return set_error(SHINE_E_INVALID, "shine_interp_sdf_backward: a plain planned batch, no loss options (the loss is the caller's)");
+    return set_error(SHINE_E_INVALID, "shine_interp_sdf_backward: a plain planned batch, no loss options (the loss is the caller's: "
+                                      "its eikonal part arrives as grad_g)");
   V1Args a = {};
   // (coord doubles as the label pointer: the external-delta build never reads labels)
   int rc = fill_step_args(&a, t, cfg, coord, coord, nullptr, perm, slots, nullptr, n, feats, rows, mlp, nullptr, nullptr,
@@ -198,6 +203,7 @@ extern "C" int shine_interp_sdf_backward(const shine_tables* t, const shine_step
   if (rc != SHINE_OK) return rc;
   if (n == 0) return SHINE_OK;
   a.ext_delta = grad_pred;
+  a.ext_q = grad_g;
   a.inv_n = 1.0f;
   const V2Geometry g = v3_geometry(n);
   a.tiles = g.tiles;
@@ -208,8 +214,9 @@ extern "C" int shine_interp_sdf_backward(const shine_tables* t, const shine_step
   a.partials = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   void* params[] = {&a};
-  SHINE_HIP_CHECK(hipLaunchKernel(step_fn<false, true, false>(cfg->n_levels, g.wg_waves, false), dim3((unsigned)g.blocks),
-                                  dim3((unsigned)(g.wg_waves * 64)), params, 0, st));
+  const void* fn = grad_g ? step_fn<true, true, false>(cfg->n_levels, g.wg_waves, false)
+                          : step_fn<false, true, false>(cfg->n_levels, g.wg_waves, false);
+  SHINE_HIP_CHECK(hipLaunchKernel(fn, dim3((unsigned)g.blocks), dim3((unsigned)(g.wg_waves * 64)), params, 0, st));
   hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks, Pass1Args{});
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;

@@ -48,8 +48,10 @@ class Decoder(nn.Module):
             if src is not None and torch.is_grad_enabled() and sum_features.requires_grad and src.fusable(sum_features):
                 # the untouched output of FeatureOctree.query_feature (shine_batch.py:123-124): interpolation + decoder as
                 # ONE autograd node whose backward is one fused launch
-                return FusedInterpSdf.apply(sum_features.detach(), src.coord, src.octree, *src.octree.feature_list(),
+                pred = FusedInterpSdf.apply(sum_features.detach(), src.coord, src.octree, src, *src.octree.feature_list(),
                                             *self.fused_params())
+                pred._shine_link = (src, tuple(src.octree.feature_list()) + tuple(self.fused_params()))
+                return pred
             return FusedMLP.apply(sum_features, *self.fused_params())
         h = sum_features  # other shapes / devices: the reference's composite
         for l in self.layers:

@@ -8,10 +8,25 @@ registers this package's classes under the module paths the reference imports th
     model.feature_octree.FeatureOctree  ->  shine_mapping_amd.FeatureOctree
     model.decoder.Decoder               ->  shine_mapping_amd.Decoder
 
-Only these two modules are replaced — `utils.*`, `dataset.*` and the rest of `model.*` keep resolving to the
-reference's own files.  A side effect worth having: the reference's `model/feature_octree.py` (and with it the
-kaolin import at `:6`) is never executed on the training path.
+Only these two modules are replaced — `dataset.*` and the rest of `model.*` keep resolving to the reference's own files.  A
+side effect worth having: the reference's `model/feature_octree.py` (and with it the kaolin import at `:6`) is never executed
+on the training path.
+
+Three FUNCTIONS of the reference's own `utils` modules are additionally re-bound (the drivers pick them up through
+`from utils.tools import *` / `from utils.loss import *`, shine_batch.py:14-15), each falling back to the reference's original
+for anything it does not cover, each with an opt-out environment variable (= "0"):
+
+    utils.tools.setup_optimizer  ->  optim.setup_optimizer: the same Adam groups (utils/tools.py:57-83) as ONE fused launch per
+                                     step instead of torch's multi-tensor Adam            SHINE_DROPIN_FUSED_OPTIMIZER
+    utils.loss.sdf_bce_loss      ->  losses.sdf_bce_loss: loss and d loss / d pred in ONE launch      SHINE_DROPIN_FUSED_LOSS
+    utils.tools.get_gradient     ->  losses.get_gradient: for the fused query_feature -> sdf node ONE forward-kernel launch,
+                                     linked to that node so that the eikonal term's backward joins its single fused launch
+                                     (lets the eikonal configurations use the fused node)            SHINE_DROPIN_FUSED_GRADIENT
+
+The re-binding needs `utils.tools` / `utils.loss` to be importable when this module is imported (the drivers import it from the
+reference's root directory, first line); `patch_utils()` can be called again later, `status()` says what is in place.
 """
+import os
 import sys
 import types
 
@@ -44,6 +59,74 @@ def install():
     pkg.feature_octree = fo
     pkg.decoder = de
     _INSTALLED = True
+    patch_utils()
+
+
+_STATUS = {}
+
+
+def status():
+    """what patch_utils() re-bound (name -> True / the reason it did not)"""
+    return dict(_STATUS)
+
+
+def _on(var):
+    return os.environ.get(var, "1") != "0"
+
+
+def patch_utils():
+    """Re-bind utils.tools.setup_optimizer / get_gradient and utils.loss.sdf_bce_loss (see the module docstring)."""
+    import importlib
+
+    from . import autograd_ops, losses, optim
+
+    try:
+        ut = importlib.import_module("utils.tools")
+    except Exception as e:  # not importable from here (another working directory, a missing dependency of the reference)
+        ut = None
+        _STATUS["utils.tools"] = "not importable: %r" % (e,)
+    try:
+        ul = importlib.import_module("utils.loss")
+    except Exception as e:
+        ul = None
+        _STATUS["utils.loss"] = "not importable: %r" % (e,)
+    if ut is not None and not hasattr(ut, "_shine_reference"):
+        ut._shine_reference = {"setup_optimizer": ut.setup_optimizer, "get_gradient": ut.get_gradient}
+    if ul is not None and not hasattr(ul, "_shine_reference"):
+        ul._shine_reference = {"sdf_bce_loss": ul.sdf_bce_loss}
+    if ut is not None:
+        ref_setup = ut._shine_reference["setup_optimizer"]
+        if _on("SHINE_DROPIN_FUSED_OPTIMIZER"):
+            def setup_optimizer(config, octree_feat, mlp_geo_param, mlp_sem_param, sigma_size):
+                tensors = list(octree_feat) + list(mlp_geo_param or [])
+                if (getattr(config, "opt_adam", True) and not getattr(config, "semantic_on", False)
+                        and not getattr(config, "ray_loss", False) and tensors
+                        and all(p.is_cuda and p.dtype.is_floating_point and p.element_size() == 4 for p in tensors)):
+                    return optim.setup_optimizer(config, octree_feat, mlp_geo_param, mlp_sem_param, sigma_size)
+                return ref_setup(config, octree_feat, mlp_geo_param, mlp_sem_param, sigma_size)
+
+            setup_optimizer.__doc__ = "shine_mapping_amd drop-in for utils.tools.setup_optimizer (utils/tools.py:57-83)"
+            ut.setup_optimizer = setup_optimizer
+            _STATUS["setup_optimizer"] = True
+        else:
+            ut.setup_optimizer = ref_setup
+            _STATUS["setup_optimizer"] = "off (SHINE_DROPIN_FUSED_OPTIMIZER=0)"
+        if _on("SHINE_DROPIN_FUSED_GRADIENT"):
+            ut.get_gradient = losses.get_gradient
+            autograd_ops.FUSE_WITH_COORD_GRAD = True
+            _STATUS["get_gradient"] = True
+        else:
+            ut.get_gradient = ut._shine_reference["get_gradient"]
+            autograd_ops.FUSE_WITH_COORD_GRAD = False
+            _STATUS["get_gradient"] = "off (SHINE_DROPIN_FUSED_GRADIENT=0)"
+    if ul is not None:
+        if _on("SHINE_DROPIN_FUSED_LOSS"):
+            ul.sdf_bce_loss = losses.sdf_bce_loss
+            _STATUS["sdf_bce_loss"] = True
+        else:
+            ul.sdf_bce_loss = ul._shine_reference["sdf_bce_loss"]
+            _STATUS["sdf_bce_loss"] = "off (SHINE_DROPIN_FUSED_LOSS=0)"
+    return status()
 
 
 def uninstall():
@@ -56,6 +139,14 @@ def uninstall():
     for attr in ("feature_octree", "decoder"):
         if pkg is not None and (getattr(getattr(pkg, attr, None), "__doc__", "") or "").startswith("shine_mapping_amd"):
             delattr(pkg, attr)
+    for name in ("utils.tools", "utils.loss"):  # the reference's own functions back in place
+        mod = sys.modules.get(name)
+        for attr, fn in getattr(mod, "_shine_reference", {}).items():
+            setattr(mod, attr, fn)
+    from . import autograd_ops
+
+    autograd_ops.FUSE_WITH_COORD_GRAD = False
+    _STATUS.clear()
     _INSTALLED = False
 
 

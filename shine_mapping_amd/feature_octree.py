@@ -181,6 +181,27 @@ class FeatureOctree(nn.Module):
             self._build_dicts()
         return self._dict_cache[1]
 
+    # ------------------------------------------------------------------ :67, :199-218
+    @property
+    def hierarchical_indices(self):
+        """list of L [N, 8] int64 tensors, bottom-up (:67).  query_feature in a training loop does not materialise them
+        (192 B per point and level that nothing on that path reads): they are computed here, on first access, from the
+        coordinates of the last query — cal_regularization (:246-255) and the mesher (utils/mesher.py:82,102) read them."""
+        d = self.__dict__
+        if d.get("_hidx") is None and d.get("_hidx_coord") is not None:
+            coord, d["_hidx_coord"] = d["_hidx_coord"], None
+            self.get_indices(coord)
+        return d.get("_hidx") if d.get("_hidx") is not None else []
+
+    @hierarchical_indices.setter
+    def hierarchical_indices(self, value):
+        self.__dict__["_hidx"] = value
+        self.__dict__["_hidx_coord"] = None
+
+    def _defer_indices(self, coord):
+        self.__dict__["_hidx"] = None
+        self.__dict__["_hidx_coord"] = coord.detach()
+
     # ------------------------------------------------------------------ :78-81
     def set_zero(self):
         with torch.no_grad():
@@ -548,6 +569,7 @@ class FeatureOctree(nn.Module):
         self._sort_box()  # folds the coarse node keys the device added into the host-side box (device tensors do not pickle)
         state = self.__dict__.copy()
         state["_tables"] = None
+        state["_hidx_coord"] = None
         state["_dict_cache"] = None
         state["_pending"] = None
         state["_dev_log"] = None

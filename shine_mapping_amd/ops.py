@@ -264,27 +264,31 @@ def octree_interp(octree, coord):
     if needs_grad:
         from .autograd_ops import OctreeInterp  # Tier A
 
-        return OctreeInterp.apply(coord, octree, *list(octree.hier_features))
+        return OctreeInterp.apply(coord, octree, *octree.feature_list())
     return _interp_forward(octree, coord)
 
 
-def _interp_forward(octree, coord):
+def _interp_forward(octree, coord, want_indices=True):
+    """query_feature's forward (shine_forward: interpolation only).  want_indices=False: hierarchical_indices is not written
+    (the octree computes it from `coord` if somebody reads it, FeatureOctree.hierarchical_indices)."""
     t = octree._require_tables()
     c = octree._check_coord(coord.detach())
     n = c.shape[0]
     feat = torch.empty((n, 8), dtype=torch.float32, device=c.device)
-    idx = [torch.empty((n, 8), dtype=torch.int64, device=c.device) for _ in range(octree.featured_level_num)]
+    idx = [torch.empty((n, 8), dtype=torch.int64, device=c.device) for _ in range(octree.featured_level_num)] \
+        if want_indices else None
     cfg = octree.step_config()
-    dummy = _dummy_mlp(c.device)
     _lib.check(
         _lib.lib().shine_forward(
-            t.handle, C.byref(cfg), c.data_ptr(), n, octree.feature_ptrs(), octree.row_counts(),
-            _lib.ptr_array([p.data_ptr() for p in dummy]), feat.data_ptr(), None,
-            _lib.ptr_array([o.data_ptr() for o in idx]), None, _stream(),
+            t.handle, C.byref(cfg), c.data_ptr(), n, octree.feature_ptrs(), octree.row_counts(), None, feat.data_ptr(), None,
+            _lib.ptr_array([o.data_ptr() for o in idx]) if idx is not None else None, None, _stream(),
         ),
         "shine_forward",
     )
-    octree.hierarchical_indices = idx
+    if idx is not None:
+        octree.hierarchical_indices = idx
+    else:
+        octree._defer_indices(c)
     return feat
 
 

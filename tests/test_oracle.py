@@ -1,5 +1,7 @@
 """CPU suite: the oracle against the committed golden vectors (generated from the real reference by
 oracle/make_golden.py), the kaolin shim's self-consistency, and the host-side octree build."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -450,3 +452,55 @@ def test_incremental_trajectory_literal_vs_clean_regulariser():
     assert outliers <= 0.03 * total
     for a, b in zip(runs["literal"][1], runs["clean"][1]):  # the loss VALUES agree all along
         assert abs(a - b) <= 1e-2 * max(1.0, abs(b))
+
+
+@pytest.mark.reference
+def test_dropin_rebinds_the_reference_utils_functions():
+    """VERDICT r03 missing 2: `import shine_mapping_amd.dropin` hands the unchanged drivers the rest of the fast path — the
+    names they import with `from utils.tools import *` / `from utils.loss import *` (shine_batch.py:14-15): setup_optimizer
+    (utils/tools.py:57-83) -> the fused Adam on the same groups, get_gradient (:175-185) and sdf_bce_loss (utils/loss.py:17-24)
+    -> the one-launch forms; each falls back to the reference's original for what it does not cover (CPU tensors here), each
+    has an opt-out, uninstall() puts the originals back."""
+    import subprocess
+    import sys
+
+    if not ref_import.available():
+        pytest.skip("needs /root/reference")
+    code = (
+        "import os, sys, torch\n"
+        "from oracle import ref_import\n"
+        "ref = ref_import.install()\n"
+        "import utils.tools as ut, utils.loss as ul\n"
+        "orig = (ut.setup_optimizer, ut.get_gradient, ul.sdf_bce_loss)\n"
+        "import shine_mapping_amd.dropin as d\n"
+        "from shine_mapping_amd import losses, optim, autograd_ops\n"
+        "st = d.status()\n"
+        "assert st['setup_optimizer'] is True and st['get_gradient'] is True and st['sdf_bce_loss'] is True, st\n"
+        "assert ut.get_gradient is losses.get_gradient and ul.sdf_bce_loss is losses.sdf_bce_loss\n"
+        "assert ut.setup_optimizer is not orig[0] and autograd_ops.FUSE_WITH_COORD_GRAD\n"
+        "ns = {}\n"
+        "exec('from utils.tools import *\\nfrom utils.loss import *', ns)\n"  # what the drivers do
+        "assert ns['get_gradient'] is losses.get_gradient and ns['sdf_bce_loss'] is losses.sdf_bce_loss\n"
+        "# CPU parameters: the wrapper hands over to the reference's own setup_optimizer (torch.optim.Adam)\n"
+        "cfg = ref.SHINEConfig(); cfg.device = 'cpu'\n"
+        "feats = [torch.nn.Parameter(torch.zeros(5, 8)) for _ in range(cfg.tree_level_feat)]\n"
+        "dec = [torch.nn.Parameter(torch.zeros(4, 4))]\n"
+        "opt = ns['setup_optimizer'](cfg, feats, dec, dec, torch.nn.Parameter(torch.ones(1)))\n"
+        "assert isinstance(opt, torch.optim.Adam), type(opt)\n"
+        "# ... and CPU tensors through the loss / gradient wrappers are the reference's composites\n"
+        "x = torch.randn(16, requires_grad=True)\n"
+        "a = ns['sdf_bce_loss'](x, torch.zeros(16), 0.1, None)\n"
+        "b = orig[2](x, torch.zeros(16), 0.1, None)\n"
+        "assert torch.equal(a, b)\n"
+        "c = torch.randn(7, 3, requires_grad=True)\n"
+        "assert torch.equal(ns['get_gradient'](c, (c ** 2).sum(1)), orig[1](c, (c ** 2).sum(1)))\n"
+        "d.uninstall()\n"
+        "assert (ut.setup_optimizer, ut.get_gradient, ul.sdf_bce_loss) == orig and not autograd_ops.FUSE_WITH_COORD_GRAD\n"
+        "os.environ['SHINE_DROPIN_FUSED_LOSS'] = '0'\n"
+        "d.install()\n"
+        "assert ul.sdf_bce_loss is orig[2] and ut.get_gradient is losses.get_gradient, d.status()\n"
+        "print('ok')\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]

@@ -22,10 +22,9 @@ out_dir = os.path.join(ROOT, "tools", "ab")
 os.makedirs(out_dir, exist_ok=True)
 # a variant has the composition of the CHECK library (product objects, shine_step_v0.hip in its training build), so
 # kernel_variant 1 works against it too
-jobs = [(os.path.join(b.CSRC, f), os.path.join(b.OBJDIR, f.replace(".hip", ".o")), [], f) for f in b.sources()
-        if f != "shine_step_v0.hip"]
-jobs.append((os.path.join(b.CSRC, "shine_step_v0.hip"), os.path.join(b.OBJDIR, "check_shine_step_v0_train.o"),
-             ["-DSHINE_V0_TRAIN=1"], "shine_step_v0.hip"))
+jobs = [(os.path.join(b.CSRC, f), os.path.join(b.OBJDIR, f.replace(".hip", ".o")), [], f) for f in b.sources()]
+jobs.append((os.path.join(b.CSRC, "shine_step_v0.hip"), os.path.join(b.OBJDIR, "check_shine_step_v0_train.o"), [],
+             "shine_step_v0.hip"))
 objs = []
 for path, obj, extra, fname in jobs:
     if fname in srcs:

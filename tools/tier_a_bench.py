@@ -1,60 +1,87 @@
 #!/usr/bin/env python
-"""Tier A (strict drop-in) iteration time: the reference's loop body (shine_batch.py:115-210) on this package's classes —
-query_feature (OctreeInterp) -> sdf (FusedMLP) -> [get_gradient] -> sdf_bce_loss [+ eikonal] -> backward -> torch Adam —
-next to the fused Tier-B step on the same unordered batch."""
-import os, sys, time, torch
+"""Tier A (strict drop-in) iteration time: the reference's loop body (shine_batch.py:115-210) VERBATIM on this package's
+classes — query_feature -> sdf -> [get_gradient] -> sdf_bce_loss [+ eikonal] -> zero_grad / backward / opt.step —
+
+  "utils unpatched"  what round 3 gave the unchanged driver: model.* replaced, utils.* the reference's own (torch composites
+                     for the loss and get_gradient — so the eikonal loop runs the split, twice-differentiable nodes — and
+                     torch.optim.Adam);
+  "dropin"           what `import shine_mapping_amd.dropin` gives it now: utils.tools.setup_optimizer / get_gradient and
+                     utils.loss.sdf_bce_loss re-bound to the fused forms (one-launch Adam, one-launch loss, the eikonal loop
+                     on the fused node);
+  "tier B"           the fused step on the same unordered batch + the fused Adam, for scale.
+Same process, same box, interleaved repetitions; ms per iteration = median of 5 x 30 iterations."""
+import os, statistics, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from shine_mapping_amd import StepOptions, fused_train_step, synth
-from shine_mapping_amd.losses import sdf_bce_loss
+from shine_mapping_amd import StepOptions, autograd_ops, fused_train_step, losses, optim, synth
 
 
-def get_gradient(inputs, outputs):  # utils/tools.py:175-185
+def ref_get_gradient(inputs, outputs):  # utils/tools.py:175-185
     d = torch.ones_like(outputs, requires_grad=False)
     return torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=d, create_graph=True, retain_graph=True,
                                only_inputs=True)[0]
 
 
-for kind, lv, n in (("maicity", 3, 4096), ("maicity", 3, 1 << 16), ("kitti", 3, 4096), ("kitti", 3, 1 << 16)):
+for kind, lv, n in (("maicity", 3, 4096), ("kitti", 3, 4096), ("maicity", 3, 1 << 16), ("kitti", 3, 1 << 16)):
     wl = synth.build_workload(kind, frames=30, device="cuda", seed=42, tree_level_feat=lv)
     octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
+    cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio = True, 1e-15, 1.0
     eik = bool(cfg.ekional_loss_on)
-    params = list(octree.parameters()) + list(dec.parameters())
-    opt = torch.optim.Adam([p for p in params if p.requires_grad], lr=0.01, betas=(0.9, 0.99), eps=1e-15)
     g = torch.Generator(device="cuda").manual_seed(1)
     sigma = cfg.sigma_sigmoid
 
-    def tier_a():
-        coord, label, weight = synth.draw_batch(wl.pool, n, g)
-        if eik:
-            coord.requires_grad_(True)
-        feature = octree.query_feature(coord)
-        pred = dec.sdf(feature)
-        loss = sdf_bce_loss(pred, label, sigma, None, False, cfg.loss_reduction)
-        if eik:
-            gr = get_gradient(coord, pred) * sigma
-            loss = loss + cfg.weight_e * ((1.0 - gr[weight > 0].norm(2, dim=-1)) ** 2).mean()
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
+    def make_loop(patched):
+        feats, mlp = list(octree.parameters()), list(dec.parameters())
+        if patched:
+            opt = optim.setup_optimizer(cfg, feats, mlp)
+            bce, grad_fn = losses.sdf_bce_loss, losses.get_gradient
+        else:
+            groups = [{"params": mlp, "lr": cfg.lr, "weight_decay": cfg.weight_decay}] + \
+                     [{"params": [feats[len(feats) - 1 - i]], "lr": cfg.lr} for i in range(len(feats))]
+            opt = torch.optim.Adam(groups, betas=(0.9, 0.99), eps=1e-15)
+            bce, grad_fn = losses._bce_composite, ref_get_gradient
+
+        def loop():
+            autograd_ops.FUSE_WITH_COORD_GRAD = patched
+            coord, sdf_label, weight = synth.draw_batch(wl.pool, n, g)
+            if eik:
+                coord.requires_grad_(True)
+            feature = octree.query_feature(coord)
+            sdf_pred = dec.sdf(feature)
+            surface_mask = weight > 0
+            if eik:
+                gr = grad_fn(coord, sdf_pred) * sigma
+            cur_loss = 0.
+            weight = torch.abs(weight)
+            cur_loss += bce(sdf_pred, sdf_label, sigma, weight, False, cfg.loss_reduction)
+            if eik:
+                cur_loss += cfg.weight_e * ((gr[surface_mask].norm(2, dim=-1) - 1.0) ** 2).mean()
+            opt.zero_grad(set_to_none=True)
+            cur_loss.backward()
+            opt.step()
+
+        return loop
 
     o = StepOptions(sigma=sigma, ekional_loss_on=eik, weight_e=cfg.weight_e)
+    adam_b = optim.setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())
 
     def tier_b():
         coord, label, weight = synth.draw_batch(wl.pool, n, g)
-        for p in params:
-            if p.grad is not None:
-                p.grad.zero_()
         fused_train_step(octree, dec, coord, label, weight, o)
-        opt.step()
+        adam_b.step(zero_grad=True)
 
-    out = {}
-    for name, fn in (("tier A", tier_a), ("tier B (fused, torch Adam)", tier_b)):
+    loops = {"utils unpatched (r03)": make_loop(False), "dropin (r04)": make_loop(True), "tier B (fused step + fused Adam)": tier_b}
+    times = {k: [] for k in loops}
+    for fn in loops.values():
         for _ in range(5):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(30):
-            fn()
-        torch.cuda.synchronize()
-        out[name] = (time.perf_counter() - t0) / 30 * 1e3
-    print(kind, "L%d" % lv, "N=%d" % n, "eikonal" if eik else "BCE", {k: "%.2f ms" % v for k, v in out.items()})
+    for rep in range(5):
+        for name, fn in loops.items():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                fn()
+            torch.cuda.synchronize()
+            times[name].append((time.perf_counter() - t0) / 30 * 1e3)
+    autograd_ops.FUSE_WITH_COORD_GRAD = False
+    print(kind, "L%d" % lv, "N=%d" % n, "BCE+eikonal" if eik else "BCE",
+          {k: "%.3f ms (min %.3f)" % (statistics.median(v), min(v)) for k, v in times.items()}, flush=True)
