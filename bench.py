@@ -112,22 +112,27 @@ def step_info(octree, cfg_eik, n):
                 useful_flop_per_point=out[5])
 
 
-def cpu_baseline(wl, seconds=12.0, n=4096, max_iters=400):
+def cpu_baseline(wl, seconds=12.0, n=4096, max_iters=400, regularize=False):
     """The oracle port of the reference's CPU path (same per-point dict lookups, the same torch CPU op sequence, the
     reference's Adam groups) on a bounded sample of the same workload: whole iterations — query + decode + loss +
     backward + Adam step (shine_batch.py:115-210, the reference's timing(s)/total) — of N=4096 points (the reference's
-    own batch size, config/*/..._batch.yaml `bs`) drawn from the same pool / octree, for ~`seconds` of CPU work."""
+    own batch size, config/*/..._batch.yaml `bs`) drawn from the same pool / octree, for ~`seconds` of CPU work.
+    regularize: the incremental configuration's iteration (shine_incre.py:152-158): + lambda_forget * cal_regularization on the
+    octree's importance_weight / features_last_frame (an attached clone, model/feature_octree.py:160, as in a later frame)."""
     from oracle import shine_oracle as so
 
     cfg = wl.cfg
     ocfg = so.make_config(tree_level_world=cfg.tree_level_world, tree_level_feat=cfg.tree_level_feat,
                           leaf_vox_size=cfg.leaf_vox_size, sigma_sigmoid_m=cfg.sigma_sigmoid_m,
                           ekional_loss_on=cfg.ekional_loss_on, weight_e=cfg.weight_e,
-                          loss_reduction=cfg.loss_reduction)
+                          loss_reduction=cfg.loss_reduction, lambda_forget=getattr(cfg, "lambda_forget", 0.0))
     oct_ = so.OracleOctree(ocfg)
     for lvl, tab in enumerate(wl.octree.nodes_lookup_tables):
         oct_.node_table[lvl] = tab
     oct_.hier_features = [p.detach().cpu().clone().requires_grad_(True) for p in wl.octree.hier_features]
+    if regularize:
+        oct_.importance_weight = [t.detach().cpu().clone() for t in wl.octree.importance_weight]
+        oct_.features_last_frame = [p.clone() for p in oct_.hier_features]  # (:160: attached)
     mlp = so.OracleDecoder(ocfg)
     mlp.load_state_dict({k: v.cpu() for k, v in wl.decoder.state_dict().items()})
     opt = so.adam_param_groups(oct_, mlp, 0.01)
@@ -140,7 +145,7 @@ def cpu_baseline(wl, seconds=12.0, n=4096, max_iters=400):
         idx = torch.randint(0, pool_n, (n,), generator=g).to(pdev)
         c, l, w = wl.pool.coord[idx].cpu(), wl.pool.sdf_label[idx].cpu(), wl.pool.weight[idx].cpu()
         t0 = time.perf_counter()
-        so.train_step(oct_, mlp, c, l, w, ocfg)
+        so.train_step(oct_, mlp, c, l, w, ocfg, regularize=regularize)
         t1 = time.perf_counter()
         opt.step()
         opt.zero_grad(set_to_none=True)
@@ -172,10 +177,11 @@ def cpu_baseline(wl, seconds=12.0, n=4096, max_iters=400):
         "host_cores": host_cores, "value_without_adam": done / max(t_nopt, 1e-9),
         "ms_per_iteration": t_used / max(it, 1) * 1e3,
         "thread_calibration_ms": {str(k): v * 1e3 for k, v in sorted(calib.items())},
-        "sample": "%d whole iterations (query+decode+loss+backward+Adam step, the reference's timing(s)/total) of N=%d "
+        "sample": "%d whole iterations (query+decode+loss%s+backward+Adam step, the reference's timing(s)/total) of N=%d "
                   "(reference batch size) from the same pool/octree; oracle/shine_oracle.py train_step + "
                   "torch.optim.Adam(betas=(0.9,0.99), eps=1e-15) on the reference's groups, torch %s CPU, thread count = "
-                  "best median of 3 iterations over {32,8,1} (+ all cores on hosts of <= 64)" % (it, n, torch.__version__),
+                  "best median of 3 iterations over {32,8,1} (+ all cores on hosts of <= 64)" % (
+                      it, "+lambda_forget*cal_regularization" if regularize else "", n, torch.__version__),
     }
 
 
@@ -296,7 +302,8 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
             "points_per_iter_per_gpu": bs, "levels": cfg.tree_level_feat, "frames": steps,
             "samples_per_frame": int(np.mean([f[0].shape[0] for f in frames])),
             "corner_rows": [int(p.shape[0]) for p in octree.hier_features], "parallelism": "dp1",
-            "launch": "%d iterations per hipgraph replay (loop.GraphedIteration), re-captured per frame" % args.unroll,
+            "launch": "%d iterations per hipgraph replay (loop.GraphedIteration): the graph is built by the library and its "
+                      "kernel nodes are re-bound per frame (shine_iter_graph_*), no capture" % args.unroll,
         },
         "frames_per_s": steps / dt,
         "per_frame_ms_median": {"update+ranks": med[0], "optimiser+pool plan": med[1],
@@ -308,13 +315,12 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
     # roofline of the dominant kernel at this batch size (HIP events around back-to-back launches of the fused kernel)
     out["roofline"] = kernel_roofline("ncd-incre", octree, dec, cfg, pool, bs, None)
     if with_cpu_baseline:
-        cb = cpu_baseline(wl, n=bs, seconds=cpu_seconds)
+        cb = cpu_baseline(wl, n=bs, seconds=cpu_seconds, regularize=True)
         out["cpu_baseline"] = cb
         gpu_iter = med[2] / iters * 1e-3
         out["like_for_like"] = {"n": bs, "gpu_samples_per_s_in_loop": bs / gpu_iter, "cpu_samples_per_s": cb["value"],
                                 "speedup": (bs / gpu_iter) / cb["value"],
-                                "note": "both sides: whole iterations incl. Adam at N=%d (the CPU side has no regulariser "
-                                        "term: it would only make it slower)" % bs}
+                                "note": "both sides: whole iterations incl. the regulariser term and Adam at N=%d" % bs}
     return out
 
 
@@ -539,7 +545,11 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
     octree._require_tables(with_ranks=True)
     # ONE pool order and ONE random stream on every rank: the global draw is common knowledge
     # (canonical: the plan leaves the samples of one node in atomic-retirement order, which differs between processes)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter()
     spool = SortedPool(octree, pool.coord, pool.sdf_label, pool.weight, seed=1000, canonical=use_dist)
+    torch.cuda.synchronize()
+    pool_plan_ms = (time.perf_counter() - t_plan) * 1e3
     feats, dec_params = list(octree.hier_features), decoder.fused_params()
     idx_buf = torch.empty(points, dtype=torch.int32, device=dev)
     surf_parts = spool.surf_parts_buffer(points) if opts.ekional_loss_on else None
@@ -708,7 +718,14 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
         exchange = "dense"  # (no exchange at all on one rank)
     if use_dist and exchange == "auto":
         tuned = {}
+        t_tune = time.perf_counter()
         for kind, m in [("dense", 1), ("gather", 1)] + ([("gather", want_m)] if want_m > 1 else []):
+            # (a bound on the tuning itself: the SCALE run times the whole process; every rank takes the same decision)
+            over = torch.tensor([1.0 if (tuned and time.perf_counter() - t_tune > 45.0) else 0.0], device=dev)
+            dist.all_reduce(over, op=dist.ReduceOp.MAX)
+            if float(over) > 0:
+                tuned["%s%s" % (kind, "" if m == 1 else " x%d micro-batches" % m)] = "skipped: tuning budget (45 s) spent"
+                continue
             r_ = build_runner(kind, m)
             name = kind if m == 1 else "%s x%d micro-batches" % (kind, m)
             if r_ is None:
@@ -753,18 +770,30 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
         barrier()
         preheat_ms = (time.perf_counter() - t_pre) * 1e3
     run(warmup)
-    barrier()
-    t0 = time.perf_counter()
-    loss = run(steps)
-    barrier()
-    dt_local = time.perf_counter() - t0
-    dt, rank_ms = dt_local, None
+    # R windows of exactly K steps each, every window bracketed by barrier + synchronize on both sides and scored by its
+    # slowest rank; the line reports the MEDIAN window (one window of the driver's K = 20 is ~2 ms: a single one says nothing
+    # about its own spread), the others go into config.window_ms.
+    windows, rank_windows = [], []
+    loss = None
+    for _ in range(max(1, int(args.repeats))):
+        barrier()
+        t0 = time.perf_counter()
+        loss = run(steps)
+        barrier()
+        dt_local = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+            all_t = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(all_t, t)
+            per = [float(x) for x in all_t]
+            windows.append(max(per))
+            rank_windows.append(per)
+        else:
+            windows.append(dt_local)
+    dt = statistics.median(windows)
+    rank_ms = None
     if dist is not None:
-        t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
-        all_t = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(all_t, t)
-        per = [float(x) for x in all_t]
-        dt = max(per)
+        per = rank_windows[min(range(len(windows)), key=lambda i: abs(windows[i] - dt))]
         rank_ms = {"max": max(per) / steps * 1e3, "min": min(per) / steps * 1e3}
 
     gather_overflow = None
@@ -820,18 +849,27 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": "%s: %s, batch mode, %d points/iter/GPU, %d-level octree (levels %d..%d), F=8, decoder "
-                        "8-32-32-1, %s" % (workload,
+                        "8-32-32-1, %s; synthetic scans: %d poses x 64 beams x %d azimuths (SURVEY.md 8(d)'s recipe asks for "
+                        "100 x 64 x 1800: the map is the full one, the sample pool is thinner)" % (workload,
                                            {"maicity": "MaiCity-like 100 m street canyon",
                                             "kitti": "KITTI-like 600 m polyline with two turns",
                                             "kitti-large": "KITTI-like 8.4 km serpentine (map larger than the "
                                                            "256 MiB Infinity Cache)"}[workload],
                                            points, levels, cfg.tree_level_world - levels + 1, cfg.tree_level_world,
-                                           "BCE+eikonal" if cfg.ekional_loss_on else "BCE"),
+                                           "BCE+eikonal" if cfg.ekional_loss_on else "BCE", frames, spec["azimuths"]),
             "points_per_iter_per_gpu": points, "levels": levels, "frames": frames,
             "pool_samples": int(pool.sdf_label.shape[0]), "corner_rows": rows,
             "feature_table_bytes": int(sum(rows) * 32),
             "batch_order": "sorted draw from the node-ordered pool (f-3); under DP one global draw, rank r takes the "
                            "r-th contiguous slice",
+            "lookup": "hoisted to the pool plan: the Morton-keyed hash probe of get_indices (model/feature_octree.py:199-218) "
+                      "runs once per pool plan (pool and tree are static in batch mode) — every step reads a memoised 4-byte "
+                      "hash slot per (sample, level) and the node's 8 corner ids (32 B)",
+            "pool_plan_ms": pool_plan_ms,
+            "window_ms": {"median": dt * 1e3, "min": min(windows) * 1e3, "max": max(windows) * 1e3,
+                          "all": [w * 1e3 for w in windows],
+                          "note": "%d windows of exactly %d steps; value / ms_per_step are the median window's" % (
+                              len(windows), steps)},
             "parallelism": "dp%d" % world, "launch": launch,
             "world_size_reported": dist.get_world_size() if dist is not None else 1,
             "rank_ms_per_step": rank_ms,
@@ -895,6 +933,8 @@ def main():
                     help="ncd-incre: iterations captured per HIP graph.  The graph is re-captured every frame, so captured nodes "
                          "are paid for per frame against the ~8 us of idle GPU per graph boundary they save: measured 3.98 / "
                          "3.93 / 4.11 / 4.54 ms per frame of 50 iterations at 1 / 2 / 5 / 10 (lab book block 15)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed windows of exactly --steps steps each; the line reports the median window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default invocation: skip the abbreviated kitti / ncd-incre legs")

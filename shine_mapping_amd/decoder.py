@@ -48,8 +48,11 @@ class Decoder(nn.Module):
             if src is not None and torch.is_grad_enabled() and sum_features.requires_grad and src.fusable(sum_features):
                 # the untouched output of FeatureOctree.query_feature (shine_batch.py:123-124): interpolation + decoder as
                 # ONE autograd node whose backward is one fused launch
-                pred = FusedInterpSdf.apply(sum_features.detach(), src.coord, src.octree, src, *src.octree.feature_list(),
-                                            *self.fused_params())
+                import weakref
+
+                src.octree.__dict__["_spec_decoder"] = weakref.ref(self)  # (the next query_feature evaluates this decoder too)
+                pred = FusedInterpSdf.apply(sum_features.detach(), src.coord, src.octree, src, src.speculated(self),
+                                            *src.octree.feature_list(), *self.fused_params())
                 pred._shine_link = (src, tuple(src.octree.feature_list()) + tuple(self.fused_params()))
                 return pred
             return FusedMLP.apply(sum_features, *self.fused_params())

@@ -570,6 +570,8 @@ class FeatureOctree(nn.Module):
         state = self.__dict__.copy()
         state["_tables"] = None
         state["_hidx_coord"] = None
+        state.pop("_spec_decoder", None)
+        state.pop("_spec_result", None)
         state["_dict_cache"] = None
         state["_pending"] = None
         state["_dev_log"] = None

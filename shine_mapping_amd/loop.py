@@ -21,6 +21,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .autograd_ops import bump_param_epoch
 from .ops import StepOptions, fused_regularization, fused_train_step, touched_flags
 
 
@@ -240,6 +241,7 @@ class GraphedIteration:
         """Run one iteration; returns the loss of the fused terms as a 0-dim device tensor (no host sync)."""
         if self.octree._tables_epoch != self._epoch:
             raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
+        bump_param_epoch()
         if self.native:
             g, out, _ = self._bound(1)
             g.launch(1)
@@ -253,6 +255,7 @@ class GraphedIteration:
         """n_iters iterations: replays of the `unroll`-iteration graph, the remainder one by one.  Returns the last loss."""
         if self.octree._tables_epoch != self._epoch:
             raise RuntimeError("the octree grew since this iteration was captured: build a new GraphedIteration")
+        bump_param_epoch()  # (replays update the parameters without torch noticing)
         k = self.unroll if self.unroll > 1 else 0
         if self.native:
             if k and n_iters >= k:

@@ -268,7 +268,7 @@ def octree_interp(octree, coord):
     return _interp_forward(octree, coord)
 
 
-def _interp_forward(octree, coord, want_indices=True):
+def _interp_forward(octree, coord, want_indices=True, mlp=None, pred_out=None):
     """query_feature's forward (shine_forward: interpolation only).  want_indices=False: hierarchical_indices is not written
     (the octree computes it from `coord` if somebody reads it, FeatureOctree.hierarchical_indices)."""
     t = octree._require_tables()
@@ -280,7 +280,9 @@ def _interp_forward(octree, coord, want_indices=True):
     cfg = octree.step_config()
     _lib.check(
         _lib.lib().shine_forward(
-            t.handle, C.byref(cfg), c.data_ptr(), n, octree.feature_ptrs(), octree.row_counts(), None, feat.data_ptr(), None,
+            t.handle, C.byref(cfg), c.data_ptr(), n, octree.feature_ptrs(), octree.row_counts(),
+            _lib.ptr_array([p.data_ptr() for p in mlp]) if mlp is not None else None, feat.data_ptr(),
+            pred_out.data_ptr() if pred_out is not None else None,
             _lib.ptr_array([o.data_ptr() for o in idx]) if idx is not None else None, None, _stream(),
         ),
         "shine_forward",

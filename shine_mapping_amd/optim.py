@@ -104,6 +104,9 @@ class FusedAdam:
         ts = self._tensors()
         if not ts:
             return
+        from .autograd_ops import bump_param_epoch
+
+        bump_param_epoch()  # (the parameters change behind torch's back: tensor._version does not move)
         n = len(ts)
         ages = [self._age.get(t[0], 0) for t in ts]
         if graph_safe:
@@ -239,6 +242,9 @@ def _finish_iteration(self, pending, regulariser=None, next_draw=None, active_fl
     graph (loop.IterationGraph): nothing is launched — the launch becomes the tail node of the library-built iteration graph."""
     if self._dev is None:
         raise RuntimeError("finish_iteration needs the device-side step state: run one step(graph_safe=True) first")
+    from .autograd_ops import bump_param_epoch
+
+    bump_param_epoch()
     octree, decoder = pending["octree"], pending["decoder"]
     ts = self._tensors()
     by_param = {id(t[0]): (i, t) for i, t in enumerate(ts)}

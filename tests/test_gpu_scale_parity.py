@@ -419,6 +419,46 @@ def test_tier_a_eikonal_loop_on_the_fused_node(name):
         autograd_ops.FUSE_WITH_COORD_GRAD = False
 
 
+def test_query_feature_speculates_the_decoder_and_notices_changed_weights():
+    """From the second iteration on, query_feature's launch also evaluates the decoder that consumed this octree's features last
+    (the drivers' next line is `geo_mlp.sdf(feature)`, shine_batch.py:123-124), and Decoder.sdf launches nothing — but only while
+    the decoder's weights are the ones the launch saw: an in-place torch update (tensor._version) or a step of the fused
+    optimiser (which writes behind torch's back: autograd_ops.param_epoch) between the two calls voids the speculation."""
+    from shine_mapping_amd import autograd_ops
+    from shine_mapping_amd.optim import FusedAdam
+
+    fx = load_golden("maicity_bce_L3")
+    cfg, octree, dec = product_from_golden(fx)
+    coord = fx["coord"].cuda()
+
+    def sdf_of(feature):
+        return autograd_ops.FusedMLP.apply(feature.detach(), *[p.detach() for p in dec.fused_params()])
+
+    f1 = octree.query_feature(coord)
+    assert f1._shine_src.spec is None  # nobody has consumed this octree's features yet
+    p1 = dec.sdf(f1)
+    f2 = octree.query_feature(coord)
+    assert f2._shine_src.speculated(dec) is not None
+    p2 = dec.sdf(f2)
+    assert p2.data_ptr() == f2._shine_src.spec[0].data_ptr() and "FusedInterpSdf" in type(p2.grad_fn).__name__
+    assert abs_err(p2, p1) <= 1e-5 and abs_err(p2, sdf_of(f2)) <= 1e-5
+    p2.sum().backward()  # (and the node still backpropagates)
+    assert all(p.grad is not None for p in list(octree.hier_features) + dec.fused_params())
+    f3 = octree.query_feature(coord)
+    with torch.no_grad():
+        dec.fused_params()[5].add_(1.0)  # b3 += 1, in place: torch notices
+    assert f3._shine_src.speculated(dec) is None
+    p3 = dec.sdf(f3)
+    assert abs_err(p3, p1 + 1.0) <= 1e-5
+    f4 = octree.query_feature(coord)
+    opt = FusedAdam([{"params": dec.fused_params(), "lr": 0.1}])
+    opt.step()  # the fused optimiser moves the weights without touching tensor._version
+    assert f4._shine_src.speculated(dec) is None
+    p4 = dec.sdf(f4)
+    torch.cuda.synchronize()
+    assert abs_err(p4, sdf_of(f4)) <= 1e-5 and abs_err(p4, p3) > 1e-3
+
+
 @pytest.mark.parametrize("reduction", ["mean", "sum"])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_one_launch_bce_loss_matches_the_torch_composite(reduction, weighted):
