@@ -81,6 +81,72 @@ __global__ void k_compact(const u64* src, long long n, int sh, const int* flags,
   if (i == n - 1) *count_out = (long long)pos[i] + flags[i];
 }
 
+// ---- the same three steps for ALL featured levels in one launch each (blockIdx.y = level): an octree update is a chain of
+//      ~10^2 small launches whose cost is the host's launch rate, not the GPU's (tools/update_breakdown.py)
+struct LevelProbes {
+  ProbeTable T[SHINE_MAX_LEVELS];
+  int sh[SHINE_MAX_LEVELS];
+  u64* out[SHINE_MAX_LEVELS];
+};
+__global__ void k_flag_fresh_levels(const u64* sorted, long long n, LevelProbes P, int* flags) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = blockIdx.y, sh = P.sh[s];
+  const u64 k = sorted[i] >> sh;
+  const bool first = i == 0 || (sorted[i - 1] >> sh) != k;
+  flags[(long long)s * n + i] = (first && find_slot(P.T[s], k) < 0) ? 1 : 0;
+}
+// pos = exclusive scan of the L x n flags: level s's fresh nodes go to out[s][pos - pos[s n]]
+__global__ void k_compact_levels(const u64* src, long long n, LevelProbes P, const int* flags, const int* pos,
+                                 long long* count_out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = blockIdx.y;
+  const long long j = (long long)s * n + i;
+  const int base = pos[(long long)s * n];
+  if (flags[j]) P.out[s][pos[j] - base] = src[i] >> P.sh[s];
+  if (i == n - 1) count_out[s] = (long long)(pos[j] + flags[j] - base);
+}
+
+// corners of the fresh nodes of all levels in ONE array, the level in the key's top three bits (x << 42 | y << 21 | z uses 58)
+constexpr int CORNER_TAG_SHIFT = 61;
+constexpr u64 CORNER_KEY_MASK = (1ull << CORNER_TAG_SHIFT) - 1ull;
+struct ExpandLevels {
+  const u64* fresh[SHINE_MAX_LEVELS];
+  long long nf[SHINE_MAX_LEVELS];
+  long long off[SHINE_MAX_LEVELS];  // first output element of the level (8 per fresh node)
+};
+__global__ void k_expand_corners_levels(ExpandLevels E, u64* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  if (i >= E.nf[s] * 8) return;
+  out[E.off[s] + i] = ((u64)s << CORNER_TAG_SHIFT) | corner_key(E.fresh[s][i >> 3], (int)(i & 7));
+}
+struct CornerProbes {
+  ProbeTable T[SHINE_MAX_LEVELS];
+};
+// sorted by (level, lexicographic corner key): flag the first of every run whose corner table does not hold it
+__global__ void k_flag_fresh_corners(const u64* sorted, long long m, CornerProbes P, int* flags) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const u64 k = sorted[i];
+  const bool first = i == 0 || sorted[i - 1] != k;
+  flags[i] = (first && find_slot(P.T[(int)(k >> CORNER_TAG_SHIFT)], k & CORNER_KEY_MASK) < 0) ? 1 : 0;
+}
+// new corners of all levels back to back (level by level, lexicographic inside a level); seg[l] = where level l starts
+__global__ void k_compact_corners(const u64* sorted, long long m, int L, const int* flags, const int* pos, u64* out,
+                                  long long* seg) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const u64 k = sorted[i];
+  const int lvl = (int)(k >> CORNER_TAG_SHIFT);
+  if (flags[i]) out[pos[i]] = k & CORNER_KEY_MASK;
+  const int prev = i == 0 ? -1 : (int)(sorted[i - 1] >> CORNER_TAG_SHIFT);
+  for (int l = prev + 1; l <= lvl; ++l) seg[l] = pos[i];  // (levels without fresh nodes in between start — and end — here)
+  if (i == m - 1)
+    for (int l = lvl + 1; l <= L; ++l) seg[l] = (long long)pos[i] + flags[i];
+}
+
 __global__ void k_expand_corners(const u64* fresh, long long nf, u64* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nf * 8) return;
@@ -251,7 +317,8 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   size_t sort_bytes = 0, scan_bytes = 0;
   SHINE_HIP_CHECK(prim_sort_keys_u64(nullptr, sort_bytes, nullptr, nullptr, (size_t)n, 0u, end_bit, st));
   SHINE_HIP_CHECK(prim_scan_int(nullptr, scan_bytes, nullptr, nullptr, (size_t)n, st));
-  const size_t kb = galign((size_t)n * 8), ib = galign((size_t)n * 4);
+  SHINE_HIP_CHECK(prim_scan_int(nullptr, scan_bytes, nullptr, nullptr, (size_t)n * (size_t)L, st));  // (all levels in one scan)
+  const size_t kb = galign((size_t)n * 8), ib = galign((size_t)n * 4 * (size_t)L);
   const size_t tmp_a = galign(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
   const size_t need_a = 2 * kb + 2 * ib + tmp_a + (size_t)L * kb + galign(2 * SHINE_MAX_LEVELS * 8);
   int rc = ensure(&G.a, &G.a_bytes, need_a, st);
@@ -270,15 +337,19 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   hipLaunchKernelGGL(k_leaf_keys, dim3(blocks_for(n)), dim3(256), 0, st, points, (long long)n, res, k0);
   SHINE_HIP_CHECK(hipGetLastError());
   SHINE_HIP_CHECK(prim_sort_keys_u64(tmp, sort_bytes, k0, k1, (size_t)n, 0u, end_bit, st));
-  for (int s = 0; s < L; ++s) {
-    const int level = cfg->max_level - (L - 1 - s);
-    const int sh = 3 * (cfg->max_level - level);
-    ProbeTable T = {t->lv[s].keys, t->lv[s].shift, t->lv[s].mask};
-    G.fresh_keys[s] = (u64*)(fresh_base + (size_t)s * kb);
-    hipLaunchKernelGGL(k_flag_fresh, dim3(blocks_for(n)), dim3(256), 0, st, k1, (long long)n, sh, T, flags);
-    SHINE_HIP_CHECK(prim_scan_int(tmp, scan_bytes, flags, pos, (size_t)n, st));
-    hipLaunchKernelGGL(k_compact, dim3(blocks_for(n)), dim3(256), 0, st, k1, (long long)n, sh, flags, pos,
-                       G.fresh_keys[s], d_counts + s);
+  {
+    LevelProbes P = {};
+    for (int s = 0; s < L; ++s) {
+      const int level = cfg->max_level - (L - 1 - s);
+      P.sh[s] = 3 * (cfg->max_level - level);
+      P.T[s] = ProbeTable{t->lv[s].keys, t->lv[s].shift, t->lv[s].mask};
+      G.fresh_keys[s] = (u64*)(fresh_base + (size_t)s * kb);
+      P.out[s] = G.fresh_keys[s];
+    }
+    const dim3 grid(blocks_for(n), (unsigned)L);
+    hipLaunchKernelGGL(k_flag_fresh_levels, grid, dim3(256), 0, st, k1, (long long)n, P, flags);
+    SHINE_HIP_CHECK(prim_scan_int(tmp, scan_bytes, flags, pos, (size_t)n * (size_t)L, st));
+    hipLaunchKernelGGL(k_compact_levels, grid, dim3(256), 0, st, k1, (long long)n, P, flags, pos, d_counts);
     SHINE_HIP_CHECK(hipGetLastError());
   }
   long long h_counts[2 * SHINE_MAX_LEVELS];
@@ -293,18 +364,16 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   }
   if (sum_nf == 0) return SHINE_OK;  // nothing new anywhere (:129-130 for every level)
 
-  // ---------------- phase B: new corners per level, lexicographic order
-  const size_t mc = (size_t)max_nf * 8;
+  // ---------------- phase B: new corners per level, lexicographic order — all levels in one sort / flag / scan / compact
+  const size_t mc = (size_t)sum_nf * 8;
   size_t csort_bytes = 0, cscan_bytes = 0;
   SHINE_HIP_CHECK(prim_sort_keys_u64(nullptr, csort_bytes, nullptr, nullptr, mc, 0u, 64u, st));
   SHINE_HIP_CHECK(prim_scan_int(nullptr, cscan_bytes, nullptr, nullptr, mc, st));
   const size_t ckb = galign(mc * 8), cib = galign(mc * 4);
   const size_t tmp_b = galign(csort_bytes > cscan_bytes ? csort_bytes : cscan_bytes);
-  size_t need_b = 2 * ckb + 2 * cib + tmp_b;
-  size_t off_new[SHINE_MAX_LEVELS], off_ids[SHINE_MAX_LEVELS];
+  size_t need_b = 3 * ckb + 2 * cib + tmp_b;  // tagged keys (x 2, sort), new corners of all levels, flags, positions
+  size_t off_ids[SHINE_MAX_LEVELS];
   for (int s = 0; s < L; ++s) {
-    off_new[s] = need_b;
-    need_b += galign((size_t)G.n_fresh[s] * 8 * 8);  // at most 8 new corners per fresh node
     off_ids[s] = need_b;
     need_b += galign((size_t)G.n_fresh[s] * 8 * 4);
   }
@@ -313,28 +382,39 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   char* b = (char*)G.b;
   u64* c0 = (u64*)b;
   u64* c1 = (u64*)(b + ckb);
-  int* cflags = (int*)(b + 2 * ckb);
-  int* cpos = (int*)(b + 2 * ckb + cib);
-  void* ctmp = b + 2 * ckb + 2 * cib;
-  for (int s = 0; s < L; ++s) {
-    const long long nf = G.n_fresh[s];
-    if (nf == 0) continue;
-    const long long m = nf * 8;
-    G.new_corners[s] = (u64*)(b + off_new[s]);
-    G.fresh_ids[s] = (int*)(b + off_ids[s]);
-    ProbeTable T = {t->cl[s].keys, t->cl[s].shift, t->cl[s].mask};
-    hipLaunchKernelGGL(k_expand_corners, dim3(blocks_for(m)), dim3(256), 0, st, G.fresh_keys[s], nf, c0);
+  u64* new_all = (u64*)(b + 2 * ckb);
+  int* cflags = (int*)(b + 3 * ckb);
+  int* cpos = (int*)(b + 3 * ckb + cib);
+  void* ctmp = b + 3 * ckb + 2 * cib;
+  long long* d_seg = d_counts + SHINE_MAX_LEVELS;  // [L + 1] starts of the levels' new corners (SHINE_MAX_LEVELS + 1 <= 16)
+  {
+    ExpandLevels E = {};
+    CornerProbes CP = {};
+    long long off = 0;
+    for (int s = 0; s < L; ++s) {
+      E.fresh[s] = G.fresh_keys[s];
+      E.nf[s] = G.n_fresh[s];
+      E.off[s] = off;
+      off += G.n_fresh[s] * 8;
+      CP.T[s] = ProbeTable{t->cl[s].keys, t->cl[s].shift, t->cl[s].mask};
+      G.fresh_ids[s] = G.n_fresh[s] ? (int*)(b + off_ids[s]) : nullptr;
+    }
+    const long long m = (long long)mc;
+    hipLaunchKernelGGL(k_expand_corners_levels, dim3(blocks_for(max_nf * 8), (unsigned)L), dim3(256), 0, st, E, c0);
     size_t sb = csort_bytes, cb = cscan_bytes;
-    SHINE_HIP_CHECK(prim_sort_keys_u64(ctmp, sb, c0, c1, (size_t)m, 0u, 64u, st));
-    hipLaunchKernelGGL(k_flag_fresh, dim3(blocks_for(m)), dim3(256), 0, st, c1, m, 0, T, cflags);
-    SHINE_HIP_CHECK(prim_scan_int(ctmp, cb, cflags, cpos, (size_t)m, st));
-    hipLaunchKernelGGL(k_compact, dim3(blocks_for(m)), dim3(256), 0, st, c1, m, 0, cflags, cpos, G.new_corners[s],
-                       d_counts + SHINE_MAX_LEVELS + s);
+    SHINE_HIP_CHECK(prim_sort_keys_u64(ctmp, sb, c0, c1, mc, 0u, 64u, st));
+    hipLaunchKernelGGL(k_flag_fresh_corners, dim3(blocks_for(m)), dim3(256), 0, st, c1, m, CP, cflags);
+    SHINE_HIP_CHECK(prim_scan_int(ctmp, cb, cflags, cpos, mc, st));
+    hipLaunchKernelGGL(k_compact_corners, dim3(blocks_for(m)), dim3(256), 0, st, c1, m, L, cflags, cpos, new_all, d_seg);
     SHINE_HIP_CHECK(hipGetLastError());
   }
-  SHINE_HIP_CHECK(hipMemcpyAsync(h_counts + SHINE_MAX_LEVELS, d_counts + SHINE_MAX_LEVELS, SHINE_MAX_LEVELS * 8,
-                                 hipMemcpyDeviceToHost, st));
+  long long h_seg[SHINE_MAX_LEVELS + 1];
+  SHINE_HIP_CHECK(hipMemcpyAsync(h_seg, d_seg, (size_t)(L + 1) * 8, hipMemcpyDeviceToHost, st));
   SHINE_HIP_CHECK(hipStreamSynchronize(st));
+  for (int s = 0; s < L; ++s) {
+    h_counts[SHINE_MAX_LEVELS + s] = h_seg[s + 1] - h_seg[s];
+    G.new_corners[s] = G.n_fresh[s] ? new_all + h_seg[s] : nullptr;
+  }
 
   // ---------------- phase C: inserts
   for (int s = 0; s < L; ++s) {

@@ -34,13 +34,15 @@ CASES = (("maicity", 1 << 18, 4), ("kitti", 1 << 20, 3), ("maicity", 1 << 18, 3)
 only = os.environ.get("AB_ONLY")  # e.g. "maicity:4,kitti:3"
 if only:
     want = {tuple(x.split(":")) for x in only.split(",")}
-    CASES = tuple(c for c in CASES if (c[0], str(c[2])) in want)
+    CASES = tuple(c for c in CASES if (c[0], str(c[2])) in want) or \
+        tuple((k, 1 << 20, int(lv)) for k, lv in want)  # (e.g. AB_ONLY=kitti_large:3 AB_FRAMES=2800 AB_AZIMUTHS=300)
 else:
     CASES = CASES[:2]
 if os.environ.get("AB_POINTS"):  # e.g. AB_POINTS=4096: the reference's own batch size (every shipped yaml)
     CASES = tuple((k, int(os.environ["AB_POINTS"]), lv) for k, _, lv in CASES)
 for kind, pts, lv in CASES:
-    wl = synth.build_workload(kind, frames=60, device="cuda", seed=42, tree_level_feat=lv)
+    wl = synth.build_workload(kind, frames=int(os.environ.get("AB_FRAMES", 60)), device="cuda", seed=42, tree_level_feat=lv,
+                              azimuths=int(os.environ.get("AB_AZIMUTHS", 450)))
     octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
     params = list(octree.hier_features) + dec.fused_params()
     for p in params:
