@@ -276,18 +276,13 @@ int shine_importance_accumulate(float* importance, float* grad, int64_t rows, vo
  *      |grad_feats[s]|, grad_feats[s] = 0, importance[s][trash row] = 0 for every level.  grad_feats must be zero on
  *      entry (and are zero on return); pred_scratch: device float[max chunk size]; workspace as for shine_train_step of
  *      the largest chunk.  Like the query_feature of every chunk (set_zero, model/feature_octree.py:78-81,238) the call
- *      re-zeroes the trash row of every feats[s] — the one write through the `feats` pointers.
- *      grad_extra (NULL / n_extra = 0, or a host array of n_extra x L device pointers, n_extra <= 7): n_extra more sets of
- *      zeroed gradient tables (set k, level s at [k * L + s], shaped like grad_feats[s]; zero again on return).  The chunks are
- *      independent launches of the 4096-point fused step — a quarter of the chip, mostly latency — so 1 + n_extra of them
- *      run side by side on library-owned side streams, one table set each, and one epilogue launch adds their |grad| to the
- *      importance in chunk order: the same numbers as the sequential sweep, in about a third of the time. */
+ *      re-zeroes the trash row of every feats[s] — the one write through the `feats` pointers. */
 int shine_importance_sweep(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                            const float* sdf_label, const float* weight, const int32_t* idx, const int32_t* slots,
                            const int64_t* chunk_begin, int32_t n_chunks, const float* const* feats, const int64_t* rows,
                            const float* const* mlp, float* pred_scratch, float* const* grad_feats,
                            float* const* importance, double* loss_parts, void* workspace, size_t workspace_bytes,
-                           float* const* grad_extra, int32_t n_extra, void* stream);
+                           void* stream);
 
 /* ---- fused dense Adam (next row f-1): opt.step() [+ opt.zero_grad()] of shine_batch.py:208-210 for the optimiser of
  *      setup_optimizer (utils/tools.py:57-83): torch.optim.Adam semantics (betas, eps, L2 weight decay added to the

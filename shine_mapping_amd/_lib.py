@@ -93,7 +93,7 @@ _SIGNATURES = {
                   C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_float, _P, C.c_int32, C.c_int32, _P]),
     "shine_importance_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
     "shine_importance_sweep": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P,
-                                         C.c_size_t, C.POINTER(_P), C.c_int32, _P]),
+                                         C.c_size_t, _P]),
     "shine_adam_step": (
         C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_int64, C.c_int32,

@@ -64,22 +64,7 @@ __global__ void k_leaf_keys(const float* pts, long long n, float res, u64* out) 
   out[i] = morton3(quantize(pts[3 * i], res), quantize(pts[3 * i + 1], res), quantize(pts[3 * i + 2], res));
 }
 
-// sorted[i] >> sh is the node of leaf i at this level; flag the first leaf of every node the table does not hold
-__global__ void k_flag_fresh(const u64* sorted, long long n, int sh, ProbeTable T, int* flags) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u64 k = sorted[i] >> sh;
-  const bool first = i == 0 || (sorted[i - 1] >> sh) != k;
-  flags[i] = (first && find_slot(T, k) < 0) ? 1 : 0;
-}
 
-__global__ void k_compact(const u64* src, long long n, int sh, const int* flags, const int* pos, u64* out,
-                          long long* count_out) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (flags[i]) out[pos[i]] = src[i] >> sh;
-  if (i == n - 1) *count_out = (long long)pos[i] + flags[i];
-}
 
 // ---- the same three steps for ALL featured levels in one launch each (blockIdx.y = level): an octree update is a chain of
 //      ~10^2 small launches whose cost is the host's launch rate, not the GPU's (tools/update_breakdown.py)
@@ -147,11 +132,6 @@ __global__ void k_compact_corners(const u64* sorted, long long m, int L, const i
     for (int l = lvl + 1; l <= L; ++l) seg[l] = (long long)pos[i] + flags[i];
 }
 
-__global__ void k_expand_corners(const u64* fresh, long long nf, u64* out) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nf * 8) return;
-  out[i] = corner_key(fresh[i >> 3], (int)(i & 7));
-}
 
 __global__ void k_fill_u64(u64* p, long long n, u64 v) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,7 +300,7 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   SHINE_HIP_CHECK(prim_scan_int(nullptr, scan_bytes, nullptr, nullptr, (size_t)n * (size_t)L, st));  // (all levels in one scan)
   const size_t kb = galign((size_t)n * 8), ib = galign((size_t)n * 4 * (size_t)L);
   const size_t tmp_a = galign(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
-  const size_t need_a = 2 * kb + 2 * ib + tmp_a + (size_t)L * kb + galign(2 * SHINE_MAX_LEVELS * 8);
+  const size_t need_a = 2 * kb + 2 * ib + tmp_a + (size_t)L * kb + galign(3 * SHINE_MAX_LEVELS * 8);
   int rc = ensure(&G.a, &G.a_bytes, need_a, st);
   if (rc != SHINE_OK) return rc;
   char* a = (char*)G.a;
@@ -330,8 +310,8 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   int* pos = (int*)(a + 2 * kb + ib);
   void* tmp = a + 2 * kb + 2 * ib;
   char* fresh_base = a + 2 * kb + 2 * ib + tmp_a;
-  long long* d_counts = (long long*)(fresh_base + (size_t)L * kb);  // [2][SHINE_MAX_LEVELS]
-  SHINE_HIP_CHECK(hipMemsetAsync(d_counts, 0, 2 * SHINE_MAX_LEVELS * 8, st));
+  long long* d_counts = (long long*)(fresh_base + (size_t)L * kb);  // fresh counts [SHINE_MAX_LEVELS] | corner starts [L + 1]
+  SHINE_HIP_CHECK(hipMemsetAsync(d_counts, 0, 3 * SHINE_MAX_LEVELS * 8, st));
 
   const float res = (float)(1u << cfg->max_level);
   hipLaunchKernelGGL(k_leaf_keys, dim3(blocks_for(n)), dim3(256), 0, st, points, (long long)n, res, k0);

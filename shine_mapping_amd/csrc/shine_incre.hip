@@ -73,14 +73,10 @@ __global__ __launch_bounds__(256) void k_importance(float* imp, float* grad, lon
   }
 }
 
-// the epilogue for all levels in one launch (blockIdx.y = level), 16 bytes per lane.  `lanes` chunks ran side by side (one
-// gradient table set each: shine_importance_sweep); their |grad| are added in chunk order, so the result is the sequential one
-constexpr int IMP_MAX_LANES = 8;
+// the epilogue for all levels in one launch (blockIdx.y = level), 16 bytes per lane
 struct ImpArgs {
   float4* imp[SHINE_MAX_LEVELS];
   float4* grad[SHINE_MAX_LEVELS];
-  float4* grad_extra[IMP_MAX_LANES - 1][SHINE_MAX_LEVELS];  // the gradient tables of lanes 1 .. lanes - 1
-  int lanes;
   float4* feat[SHINE_MAX_LEVELS];      // the feature table: its trash row is re-zeroed (set_zero of the chunk's query_feature)
   long long n4[SHINE_MAX_LEVELS];      // (rows + 1) * F / 4
   long long trash4[SHINE_MAX_LEVELS];  // rows * F / 4: from here on the trash row
@@ -98,14 +94,8 @@ __global__ __launch_bounds__(256) void k_importance_levels(ImpArgs a) {
     // training iterations it holds the last Adam step's move (the fused step itself never reads it)
     if (e >= trash4) a.feat[s][e] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 v = imp[e];
-    v = make_float4(v.x + fabsf(g.x), v.y + fabsf(g.y), v.z + fabsf(g.z), v.w + fabsf(g.w));
-    for (int k = 1; k < a.lanes; ++k) {  // (wave-uniform trip count)
-      float4* const ge = a.grad_extra[k - 1][s] + e;
-      const float4 h = *ge;
-      *ge = make_float4(0.f, 0.f, 0.f, 0.f);
-      v = make_float4(v.x + fabsf(h.x), v.y + fabsf(h.y), v.z + fabsf(h.z), v.w + fabsf(h.w));
-    }
-    if (e >= trash4) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    v = e >= trash4 ? make_float4(0.f, 0.f, 0.f, 0.f)
+                    : make_float4(v.x + fabsf(g.x), v.y + fabsf(g.y), v.z + fabsf(g.z), v.w + fabsf(g.w));
     imp[e] = v;
   }
 }
@@ -164,46 +154,22 @@ extern "C" int shine_importance_accumulate(float* importance, float* grad, int64
   return SHINE_OK;
 }
 
-// Side streams of the importance sweep: the chunks of a sweep are independent launches of the N = 4096 fused step (64 workgroups
-// on a 256-CU chip, ~14 us of mostly latency each), so up to IMP_MAX_LANES of them run side by side, each on its own stream
-// into its own gradient tables.  Created on first use, for the life of the process.
-static hipStream_t g_imp_stream[IMP_MAX_LANES - 1];
-static hipEvent_t g_imp_done[IMP_MAX_LANES - 1];
-static hipEvent_t g_imp_fork = nullptr;
-static int g_imp_ready = 0;
-
-static int imp_streams(int lanes) {
-  while (g_imp_ready < lanes - 1) {
-    SHINE_HIP_CHECK(hipStreamCreateWithFlags(&g_imp_stream[g_imp_ready], hipStreamNonBlocking));
-    SHINE_HIP_CHECK(hipEventCreateWithFlags(&g_imp_done[g_imp_ready], hipEventDisableTiming));
-    ++g_imp_ready;
-  }
-  if (!g_imp_fork) SHINE_HIP_CHECK(hipEventCreateWithFlags(&g_imp_fork, hipEventDisableTiming));
-  return SHINE_OK;
-}
-
 // cal_feature_importance (utils/incre_learning.py:8-40) over a node-ordered pool, the chunk loop on this side of the ABI:
-// per chunk one fused step with the decoder frozen, per GROUP of `lanes` chunks one epilogue launch — the chunks of a group run
-// side by side on side streams (lanes = 1 + the number of extra gradient-table sets the caller provides), a frame's 35-70
-// chunks cost ~2 launches' time per group instead of ~3 launches each.
+// per chunk one fused step with the decoder frozen + one epilogue launch, back to back on the stream — a frame's 35-70
+// chunks cost their ~3 launches each instead of a Python iteration each.
 extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                                       const float* sdf_label, const float* weight, const int32_t* idx,
                                       const int32_t* slots, const int64_t* chunk_begin, int32_t n_chunks,
                                       const float* const* feats, const int64_t* rows, const float* const* mlp,
                                       float* pred_scratch, float* const* grad_feats, float* const* importance,
-                                      double* loss_parts, void* workspace, size_t workspace_bytes,
-                                      float* const* grad_extra, int32_t n_extra, void* stream) {
+                                      double* loss_parts, void* workspace, size_t workspace_bytes, void* stream) {
   if (!t || !cfg || !chunk_begin || n_chunks < 0 || !feats || !rows || !mlp || !grad_feats || !importance)
     return set_error(SHINE_E_INVALID, "shine_importance_sweep: null argument");
   const int L = cfg->n_levels;
   if (L < 1 || L > SHINE_MAX_LEVELS) return set_error(SHINE_E_INVALID, "shine_importance_sweep: bad level count");
   if (cfg->sorted_input != 2 || cfg->eikonal_on || cfg->decoder_grad_on)
     return set_error(SHINE_E_INVALID, "shine_importance_sweep: wants a pool-mode config, BCE only, decoder frozen");
-  if (n_extra < 0 || n_extra > IMP_MAX_LANES - 1 || (n_extra > 0 && !grad_extra))
-    return set_error(SHINE_E_INVALID, "shine_importance_sweep: 0 .. 7 extra gradient-table sets (n_extra x L pointers)");
-  const int lanes = 1 + n_extra;
   ImpArgs ia = {};
-  ia.lanes = lanes;
   long long max4 = 0;
   for (int s = 0; s < L; ++s) {
     if (!grad_feats[s] || !importance[s] || rows[s] < 0 ||
@@ -214,11 +180,6 @@ extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_co
     ia.imp[s] = (float4*)importance[s];
     ia.grad[s] = (float4*)grad_feats[s];
     ia.feat[s] = (float4*)const_cast<float*>(feats[s]);
-    for (int k = 0; k < n_extra; ++k) {
-      float* ge = grad_extra[k * L + s];
-      if (!ge || ((size_t)ge & 15)) return set_error(SHINE_E_INVALID, "shine_importance_sweep: null or unaligned extra gradient table");
-      ia.grad_extra[k][s] = (float4*)ge;
-    }
     ia.n4[s] = (rows[s] + 1) * F / 4;
     ia.trash4[s] = rows[s] * F / 4;
     if (ia.n4[s] > max4) max4 = ia.n4[s];
@@ -227,41 +188,20 @@ extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_co
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (lanes > 1) {
-    int rc = imp_streams(lanes);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int64_t b = chunk_begin[c], n = chunk_begin[c + 1] - b;
+    if (n < 0) return set_error(SHINE_E_INVALID, "shine_importance_sweep: chunk_begin must be non-decreasing");
+    if (n == 0) continue;
+    shine_step_config cc = *cfg;  // the reference normalises every chunk by its own size (sdf_bce_loss 'mean')
+    cc.n_global = n;
+    cc.inv_n = cc.reduction_sum ? 1.0 : 1.0 / (double)n;
+    // no reduction launch: the decoder is frozen, the loss is not read, and the trash rows' sums would be cleared below anyway
+    cc.defer_reduce = 1;
+    cc.adam_state = nullptr;
+    cc.zero_f64 = nullptr;
+    int rc = shine_train_step(t, &cc, coord, sdf_label, weight, idx + b, slots, nullptr, n, feats, rows, mlp, pred_scratch,
+                              nullptr, grad_feats, nullptr, loss_parts, nullptr, workspace, workspace_bytes, stream);
     if (rc != SHINE_OK) return rc;
-  }
-  float* lane_grads[IMP_MAX_LANES][SHINE_MAX_LEVELS];
-  for (int s = 0; s < L; ++s) {
-    lane_grads[0][s] = grad_feats[s];
-    for (int k = 0; k < n_extra; ++k) lane_grads[k + 1][s] = grad_extra[k * L + s];
-  }
-  for (int c0 = 0; c0 < n_chunks; c0 += lanes) {
-    const int in_group = n_chunks - c0 < lanes ? n_chunks - c0 : lanes;
-    if (in_group > 1) SHINE_HIP_CHECK(hipEventRecord(g_imp_fork, st));
-    for (int k = 0; k < in_group; ++k) {
-      const int c = c0 + k;
-      const int64_t b = chunk_begin[c], n = chunk_begin[c + 1] - b;
-      if (n < 0) return set_error(SHINE_E_INVALID, "shine_importance_sweep: chunk_begin must be non-decreasing");
-      if (n == 0) continue;
-      shine_step_config cc = *cfg;  // the reference normalises every chunk by its own size (sdf_bce_loss 'mean')
-      cc.n_global = n;
-      cc.inv_n = cc.reduction_sum ? 1.0 : 1.0 / (double)n;
-      // no reduction launch: the decoder is frozen, the loss is not read, and the trash rows' sums would be cleared below anyway
-      // (so the chunks of a group may share the workspace and the pred scratch: nothing reads either)
-      cc.defer_reduce = 1;
-      cc.adam_state = nullptr;
-      cc.zero_f64 = nullptr;
-      hipStream_t sk = k == 0 ? st : g_imp_stream[k - 1];
-      if (k > 0) SHINE_HIP_CHECK(hipStreamWaitEvent(sk, g_imp_fork, 0));
-      int rc = shine_train_step(t, &cc, coord, sdf_label, weight, idx + b, slots, nullptr, n, feats, rows, mlp, pred_scratch,
-                                nullptr, lane_grads[k], nullptr, loss_parts, nullptr, workspace, workspace_bytes, (void*)sk);
-      if (rc != SHINE_OK) return rc;
-      if (k > 0) {
-        SHINE_HIP_CHECK(hipEventRecord(g_imp_done[k - 1], sk));
-        SHINE_HIP_CHECK(hipStreamWaitEvent(st, g_imp_done[k - 1], 0));
-      }
-    }
     hipLaunchKernelGGL(k_importance_levels, dim3((unsigned)blocks, (unsigned)L), dim3(256), 0, st, ia);
     SHINE_HIP_CHECK(hipGetLastError());
   }

@@ -32,10 +32,6 @@ def chunk_partition(perm, sample_count, batch_interval, down_rate):
     return idx, begin
 
 
-SWEEP_LANES = 8                 # chunks run side by side (include/shine_hip.h shine_importance_sweep grad_extra: <= 1 + 7)
-SWEEP_EXTRA_BYTES = 1 << 30     # ... as long as their extra gradient tables stay below this
-
-
 def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduction="mean", loss_weight_on=False, pool=None):
     """Same signature as the reference; `data` needs .coord_pool and .sdf_label_pool (utils/incre_learning.py:14-26).
     `pool` (extension): the frame's sampler.SortedPool built from the SAME data.coord_pool / sdf_label_pool — its plan (node
@@ -78,18 +74,6 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
     grads = [_dense_grad(f) for f in octree.hier_features]
     for g in grads:
         g.zero_()
-    # extra (zeroed) gradient-table sets: the chunks are independent 4096-point launches, run side by side
-    table_bytes = sum(g.numel() for g in grads) * 4
-    n_extra = max(0, min(SWEEP_LANES, iter_n) - 1)
-    n_extra = min(n_extra, SWEEP_EXTRA_BYTES // max(table_bytes, 1))
-    extra = []
-    if n_extra:
-        flat = torch.zeros(n_extra * sum(g.numel() for g in grads), dtype=torch.float32, device=dev)
-        off = 0
-        for _ in range(n_extra):
-            for g in grads:
-                extra.append(flat[off:off + g.numel()])
-                off += g.numel()
     pred = torch.empty(max_chunk, dtype=torch.float32, device=dev)
     loss_parts = torch.empty(4, dtype=torch.float64, device=dev)
     ws = _workspace(dev, cfg)
@@ -101,6 +85,5 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
             _lib.ptr_array([q.data_ptr() for q in mlp.fused_params()]), pred.data_ptr(),
             _lib.ptr_array([g.data_ptr() for g in grads]),
             _lib.ptr_array([w.data_ptr() for w in octree.importance_weight]), loss_parts.data_ptr(), ws.data_ptr(),
-            ws.numel(), _lib.ptr_array([e.data_ptr() for e in extra]) if extra else None, n_extra,
-            _lib.current_stream_handle()),
+            ws.numel(), _lib.current_stream_handle()),
         "shine_importance_sweep")
