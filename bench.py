@@ -258,6 +258,13 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
     torch.cuda.synchronize()
     t_start = None
     pool = step = opt = None
+    # A full (generation-2) collection of the interpreter's heap — every module this process imported — lands on a fixed frame
+    # (the allocation count decides) and costs 35-65 ms of a 3.4 ms frame: the objects alive now are moved out of the
+    # collector's way (gc.freeze); the loop's own garbage is still collected.
+    import gc
+
+    gc.collect()
+    gc.freeze()
     for fi, (coord, label, weight) in enumerate(frames):
         if fi == warmup:
             torch.cuda.synchronize()
@@ -287,6 +294,7 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
         t4 = time.perf_counter()
         split[fi] = (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)
     dt = time.perf_counter() - t_start
+    gc.unfreeze()
     med = np.median(split[warmup:], axis=0) * 1e3
     wl = type("WL", (), {})()
     wl.cfg, wl.octree, wl.decoder = cfg, octree, dec
@@ -310,6 +318,10 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
                                 "%d iterations (incl. graph capture)" % iters: med[2], "importance sweep": med[3],
                                 "total": med[4]},
         "us_per_iteration": med[2] / iters * 1e3,
+        "per_frame_total_ms": [round(float(x) * 1e3, 3) for x in split[warmup:, 4]],
+        "slowest_frame_split_ms": [round(float(x) * 1e3, 3) for x in split[warmup + int(np.argmax(split[warmup:, 4]))]],
+        "iteration_graph": (lambda g: dict(zip(("commits", "builds"), g.stats())))(
+            __import__("shine_mapping_amd.loop", fromlist=["IterationGraph"]).IterationGraph.shared(dev, args.unroll)),
         "final_loss": float(loss),
     }
     # roofline of the dominant kernel at this batch size (HIP events around back-to-back launches of the fused kernel)

@@ -199,21 +199,21 @@ __global__ void k_rank_scatter(const u64* sorted_vals, long long total_nodes, Ra
   P.ranks[(int)(v >> 32)][(unsigned int)v] = (int)i;
 }
 
-static int ensure(void** ptr, size_t* have, size_t need, hipStream_t st) {
+static int ensure(shine_tables* t, void** ptr, size_t* have, size_t need, hipStream_t st) {
+  (void)st;
   if (need <= *have) return SHINE_OK;
   if (*ptr) {
-    SHINE_HIP_CHECK(hipStreamSynchronize(st));
-    (void)hipFree(*ptr);
+    t->retired.push_back(*ptr);  // (launches that read it may still be in flight: no free, no sync — shine_internal.hpp)
     *ptr = nullptr;
     *have = 0;
   }
-  const size_t want = need + need / 2;
+  const size_t want = 2 * need;
   if (hipMalloc(ptr, want) != hipSuccess) return set_error(SHINE_E_NOMEM, "shine_tables_grow: scratch allocation failed");
   *have = want;
   return SHINE_OK;
 }
 
-static int corner_reserve(CornerLevel& Cn, long long need, hipStream_t st) {
+static int corner_reserve(shine_tables* t, CornerLevel& Cn, long long need, hipStream_t st) {
   long long cap = Cn.cap ? Cn.cap : 1024;
   while (cap < 2 * need) cap <<= 1;
   if (cap == Cn.cap) return SHINE_OK;
@@ -233,9 +233,8 @@ static int corner_reserve(CornerLevel& Cn, long long need, hipStream_t st) {
     hipLaunchKernelGGL(k_rehash_corners, dim3((unsigned)((Cn.cap + 255) / 256)), dim3(256), 0, st, Cn.keys, Cn.vals,
                        Cn.cap, keys, vals, shift, mask);
     SHINE_HIP_CHECK(hipGetLastError());
-    SHINE_HIP_CHECK(hipStreamSynchronize(st));
-    (void)hipFree(Cn.keys);
-    (void)hipFree(Cn.vals);
+    t->retired.push_back(Cn.keys);
+    t->retired.push_back(Cn.vals);
   }
   Cn.keys = keys;
   Cn.vals = vals;
@@ -258,7 +257,7 @@ extern "C" int shine_tables_insert_corners(shine_tables* t, int32_t slot, const 
   if (!corner_keys || !ids) return set_error(SHINE_E_INVALID, "shine_tables_insert_corners: null keys/ids");
   hipStream_t st = (hipStream_t)stream;
   CornerLevel& Cn = t->cl[slot];
-  int rc = corner_reserve(Cn, Cn.count + n, st);
+  int rc = corner_reserve(t, Cn, Cn.count + n, st);
   if (rc != SHINE_OK) return rc;
   hipLaunchKernelGGL(k_insert_corners, dim3(blocks_for(n)), dim3(256), 0, st, Cn.keys, Cn.vals, Cn.shift, Cn.mask,
                      (const u64*)corner_keys, (const int*)ids, 0, (long long)n);
@@ -291,6 +290,7 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   }
   if (n == 0) return SHINE_OK;
   if (n >= (1ll << 31)) return set_error(SHINE_E_INVALID, "shine_tables_grow: more than 2^31 points in one frame");
+  SHINE_HIP_CHECK(prim_warmup(st));
 
   // ---------------- phase A: fresh nodes per level, Morton order
   const unsigned end_bit = 3u * (unsigned)cfg->max_level;
@@ -301,7 +301,7 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
   const size_t kb = galign((size_t)n * 8), ib = galign((size_t)n * 4 * (size_t)L);
   const size_t tmp_a = galign(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
   const size_t need_a = 2 * kb + 2 * ib + tmp_a + (size_t)L * kb + galign(3 * SHINE_MAX_LEVELS * 8);
-  int rc = ensure(&G.a, &G.a_bytes, need_a, st);
+  int rc = ensure(t, &G.a, &G.a_bytes, need_a, st);
   if (rc != SHINE_OK) return rc;
   char* a = (char*)G.a;
   u64* k0 = (u64*)a;
@@ -357,7 +357,7 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
     off_ids[s] = need_b;
     need_b += galign((size_t)G.n_fresh[s] * 8 * 4);
   }
-  rc = ensure(&G.b, &G.b_bytes, need_b, st);
+  rc = ensure(t, &G.b, &G.b_bytes, need_b, st);
   if (rc != SHINE_OK) return rc;
   char* b = (char*)G.b;
   u64* c0 = (u64*)b;
@@ -405,7 +405,7 @@ extern "C" int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, 
     added_counts[s] = added;
     CornerLevel& Cn = t->cl[s];
     if (Cn.count + added >= (1ll << 29)) return set_error(SHINE_E_INVALID, "shine_tables_grow: level exceeds 2^29 rows");
-    rc = corner_reserve(Cn, Cn.count + added, st);
+    rc = corner_reserve(t, Cn, Cn.count + added, st);
     if (rc != SHINE_OK) return rc;
     if (added > 0) {
       hipLaunchKernelGGL(k_insert_corners, dim3(blocks_for(added)), dim3(256), 0, st, Cn.keys, Cn.vals, Cn.shift,
@@ -451,7 +451,7 @@ extern "C" int shine_tables_rank_nodes(shine_tables* t, int64_t* n_buckets_out, 
   SHINE_HIP_CHECK(prim_sort_pairs_u64(nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)total_cap, 0u, 64u, st));
   const size_t kb = galign((size_t)total_cap * 8);
   GrowScratch& G = t->grow;
-  int rc = ensure(&G.b, &G.b_bytes, 4 * kb + galign(sort_bytes), st);  // grow results in b are consumed by now
+  int rc = ensure(t, &G.b, &G.b_bytes, 4 * kb + galign(sort_bytes), st);  // grow results in b are consumed by now
   if (rc != SHINE_OK) return rc;
   for (int s = 0; s < SHINE_MAX_LEVELS; ++s) {  // ...and no longer fetchable
     G.n_fresh[s] = G.n_added[s] = 0;

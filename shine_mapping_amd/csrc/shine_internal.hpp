@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <new>
+#include <vector>
 
 #include "shine_device.hpp"
 
@@ -71,6 +72,10 @@ int set_hip_error(hipError_t e, const char* what);
 }  // namespace shine
 
 struct shine_tables {
+  // Device arrays a growth replaced (a rehashed table, an outgrown scratch buffer): kept until the handle is destroyed instead
+  // of being freed on the spot.  hipFree waits for the whole device and was measured at 40-68 ms inside an incremental run whose
+  // frames take 3.4 ms; the arrays double, so what is retired never exceeds what is live.
+  std::vector<void*> retired;
   int n_levels = 0;
   long long n_buckets = 0;  // nodes of all featured levels + 1 ("misses everywhere"); 0: ranks not set
   shine::TableLevel lv[SHINE_MAX_LEVELS];
@@ -117,6 +122,7 @@ hipError_t prim_scan_int(void* tmp, size_t& bytes, const int* in, int* out, size
 hipError_t prim_scan_flags(void* tmp, size_t& bytes, const unsigned char* flags, int* out, size_t n, hipStream_t st);
 hipError_t prim_sort_keys_u64(void* tmp, size_t& bytes, const unsigned long long* k0, unsigned long long* k1, size_t n,
                               unsigned begin_bit, unsigned end_bit, hipStream_t st);
+hipError_t prim_warmup(hipStream_t st);  // once per process: loads rocPRIM's size-class kernels (shine_prims.hip)
 hipError_t prim_sort_pairs_u64(void* tmp, size_t& bytes, const unsigned long long* k0, unsigned long long* k1,
                                const unsigned long long* v0, unsigned long long* v1, size_t n, unsigned begin_bit,
                                unsigned end_bit, hipStream_t st);

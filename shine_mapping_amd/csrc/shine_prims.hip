@@ -53,4 +53,41 @@ hipError_t prim_sort_pairs_u64(void* tmp, size_t& bytes, const unsigned long lon
   return rocprim::radix_sort_pairs(tmp, bytes, k0, k1, v0, v1, n, begin_bit, end_bit, st);
 }
 
+// rocPRIM picks its kernels by problem size (single-block sorts, merge sort, onesweep radix passes: a dozen code objects), and
+// HIP loads a kernel's code on its first launch — tens of milliseconds the first time a frame's octree growth crosses into a
+// size class (measured: one 40-68 ms frame in an incremental run whose other frames take 3.5 ms).  One pass over the size
+// classes, once per process, in front of the first growth.
+hipError_t prim_warmup(hipStream_t st) {
+  static bool done = false;
+  if (done) return hipSuccess;
+  const size_t sizes[] = {64, 1024, 3000, 4096, 10000, 40000, 200000, 1500000};
+  const size_t nmax = sizes[sizeof(sizes) / sizeof(sizes[0]) - 1];
+  size_t sort_bytes = 0, scan_bytes = 0;
+  hipError_t e = prim_sort_keys_u64(nullptr, sort_bytes, nullptr, nullptr, nmax, 0u, 64u, st);
+  if (e != hipSuccess) return e;
+  e = prim_scan_int(nullptr, scan_bytes, nullptr, nullptr, nmax, st);
+  if (e != hipSuccess) return e;
+  const size_t tb = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  char* buf = nullptr;
+  e = hipMalloc(reinterpret_cast<void**>(&buf), 2 * nmax * 8 + tb);
+  if (e != hipSuccess) return e;
+  unsigned long long* k0 = reinterpret_cast<unsigned long long*>(buf);
+  unsigned long long* k1 = k0 + nmax;
+  e = hipMemsetAsync(buf, 0x5a, 2 * nmax * 8, st);
+  for (size_t n : sizes) {
+    for (unsigned end_bit : {36u, 45u, 64u}) {
+      size_t sb = 0;
+      if (e == hipSuccess) e = prim_sort_keys_u64(nullptr, sb, nullptr, nullptr, n, 0u, end_bit, st);
+      if (e == hipSuccess) e = prim_sort_keys_u64(buf + 2 * nmax * 8, sb, k0, k1, n, 0u, end_bit, st);
+    }
+    size_t cb = 0;
+    if (e == hipSuccess) e = prim_scan_int(nullptr, cb, nullptr, nullptr, n, st);
+    if (e == hipSuccess) e = prim_scan_int(buf + 2 * nmax * 8, cb, reinterpret_cast<const int*>(k0), reinterpret_cast<int*>(k1), n, st);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(buf);
+  done = e == hipSuccess;
+  return e;
+}
+
 }  // namespace shine

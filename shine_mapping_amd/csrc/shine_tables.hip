@@ -124,6 +124,7 @@ extern "C" int shine_tables_destroy(shine_tables* t) {
   }
   if (t->grow.a) (void)hipFree(t->grow.a);
   if (t->grow.b) (void)hipFree(t->grow.b);
+  for (void* p : t->retired) (void)hipFree(p);
   delete t;
   return SHINE_OK;
 }
@@ -154,10 +155,9 @@ extern "C" int shine_tables_insert(shine_tables* t, int32_t slot, const int64_t*
       hipLaunchKernelGGL(k_rehash, dim3((unsigned)((L.cap + 255) / 256)), dim3(256), 0, st, L.keys, L.vals,
                          (long long)L.cap, fresh.keys, fresh.vals, fresh.shift, fresh.mask);
       SHINE_HIP_CHECK(hipGetLastError());
-      SHINE_HIP_CHECK(hipStreamSynchronize(st));  // old arrays are freed below
-      (void)hipFree(L.keys);
-      (void)hipFree(L.vals);
-      (void)hipFree(L.ranks);
+      t->retired.push_back(L.keys);  // (no free on the spot: shine_internal.hpp)
+      t->retired.push_back(L.vals);
+      t->retired.push_back(L.ranks);
     }
     fresh.count = L.count;
     L = fresh;
