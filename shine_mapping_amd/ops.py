@@ -354,5 +354,13 @@ def fused_regularization(octree, lambda_forget: float, touched, out=None, out_ze
 
 
 def touched_flags(octree):
-    """Per-level uint8 row flags for fused_train_step(touched=...) / fused_regularization (zero-initialised)."""
-    return [torch.zeros(p.shape[0], dtype=torch.uint8, device=p.device) for p in octree.hier_features]
+    """Per-level uint8 row flags for fused_train_step(touched=...) / fused_regularization (zero-initialised; views of one
+    buffer: one fill)."""
+    feats = octree.feature_list()
+    sizes = [(int(p.shape[0]) + 15) // 16 * 16 for p in feats]
+    flat = torch.zeros(sum(sizes), dtype=torch.uint8, device=feats[0].device)
+    out, off = [], 0
+    for p, sz in zip(feats, sizes):
+        out.append(flat[off:off + int(p.shape[0])])
+        off += sz
+    return out

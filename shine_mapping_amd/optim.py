@@ -210,7 +210,22 @@ def setup_optimizer(config, octree_feat, mlp_geo_param, mlp_sem_param=None, sigm
 def _prepare_graph_safe(self):
     """Create the device-side step state (what the first step(graph_safe=True) does) without taking a step, so that an
     iteration can be captured into a HIP graph without an eager one in front of it."""
-    for g in self.param_groups:  # the dense gradient tensors the fused step would create on its first launch
+    # the dense gradient tensors the fused step would create on its first launch and the optimiser's exp_avg / exp_avg_sq, for
+    # every parameter that has neither yet: views of ONE zero-filled buffer (incremental mapping builds a new optimiser every
+    # frame, shine_incre.py:107-109: 27 small fills per frame otherwise)
+    fresh = [p for g in self.param_groups for p in g["params"]
+             if p.requires_grad and p.grad is None and p not in self.state and p.is_cuda and p.dtype == torch.float32]
+    if fresh:
+        sizes = [(p.numel() + 3) // 4 * 4 for p in fresh]  # (16-byte aligned views)
+        total = sum(sizes)
+        flat = torch.zeros(3 * total, dtype=torch.float32, device=fresh[0].device)
+        off = 0
+        for p, sz in zip(fresh, sizes):
+            n = p.numel()
+            p.grad = flat[off:off + n].view(p.shape)
+            self.state[p] = (flat[total + off:total + off + n].view(p.shape), flat[2 * total + off:2 * total + off + n].view(p.shape))
+            off += sz
+    for g in self.param_groups:
         for p in g["params"]:
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
