@@ -80,7 +80,12 @@ def pmc_record(workload, points, levels):
     used while it describes the code that runs: tools/pmc_to_json.py stamps the sha256 of the kernel's machine code
     (tools/kernel_hash.py) and the record is dropped — every PMC-derived field becomes null — when the loaded
     libshine_hip.so holds a different kernel.  -> (record or None, reason)"""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_%s_%d_L%d.json" % (workload, points, levels))
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s_%d_L%d.json" % (workload, points, levels))))
+    if not found:
+        return None, "no counter file for this configuration"
+    path = found[-1]  # (the latest round's collection)
     if not os.path.isfile(path):
         return None, "no counter file for this configuration"
     try:
