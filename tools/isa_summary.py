@@ -37,7 +37,7 @@ def main():
                 meta[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in KEYS if re.search(r"\.%s:\s+(\d+)" % k, blk)}
             names = [n for n in meta if "rocprim" not in n.lower()]
             pretty = dict(zip(names, demangle(names)))
-            print("## %s.hip" % stem)
+            print("## %s.hip%s" % (stem, "   (CHECK LIBRARY ONLY: libshine_check.so, tests / tools)" if stem == "shine_step_v0" else ""))
             for n in names:
                 m = re.search(r"^%s:[^\n]*\n(.*?)s_endpgm" % re.escape(n), asm, flags=re.S | re.M)
                 body = m.group(1) if m else ""
