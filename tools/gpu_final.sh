@@ -11,6 +11,7 @@ timeout 600 python bench.py --workload maicity --levels 3 --no-extra-configs --n
 timeout 600 python bench.py --workload maicity --points 4096 --no-extra-configs --no-cpu-baseline > $O/bench_maicity_4096.json.log 2>/dev/null
 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --force-dist --no-extra-configs --no-cpu-baseline > $O/bench_dist1.json.log 2>/dev/null
 timeout 600 python tools/tier_a_bench.py > $O/tier_a_bench.log 2>&1; grep -v amdgpu $O/tier_a_bench.log | tail -8
+timeout 300 python tools/update_breakdown.py > $O/update_breakdown.txt 2>&1; tail -3 $O/update_breakdown.txt
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/final/*.json.log')):
