@@ -26,6 +26,10 @@ struct shine_iter_graph {
   const void* built_step_fn = nullptr;
   const void* built_fin_fn = nullptr;
   long long commits = 0, builds = 0;
+  // recorded behind the last replay: commit() rewrites the instantiated graph's kernel arguments, and HIP does not say that a
+  // replay still queued keeps the old ones (this runtime keeps a graph's kernel arguments in memory the exec owns)
+  hipEvent_t last_replay = nullptr;
+  bool replayed = false;
 };
 
 namespace shine {
@@ -103,6 +107,7 @@ extern "C" int shine_iter_graph_create(int32_t unroll, shine_iter_graph** out) {
 extern "C" int shine_iter_graph_destroy(shine_iter_graph* g) {
   if (!g) return SHINE_OK;
   graph_drop(g);
+  if (g->last_replay) (void)hipEventDestroy(g->last_replay);
   delete g;
   return SHINE_OK;
 }
@@ -158,6 +163,12 @@ extern "C" int shine_iter_graph_commit(shine_iter_graph* g) {
     return set_error(SHINE_E_INVALID, "shine_iter_graph_commit: the tail must consume the step's workspace (same buffer, same batch size)");
   ++g->commits;
   g->dirty = false;
+  if (g->replayed) {
+    // waits for the last replay only, not for what the caller has queued since (the frame's octree update): the host keeps
+    // running ahead of the device
+    SHINE_HIP_CHECK(hipEventSynchronize(g->last_replay));
+    g->replayed = false;
+  }
   if (g->exec && g->built_step_fn == g->step.fn && g->built_fin_fn == g->fin.fn) {
     void* skp[1];
     void* fkp[3];
@@ -175,7 +186,11 @@ extern "C" int shine_iter_graph_commit(shine_iter_graph* g) {
 
 extern "C" int shine_iter_graph_launch(shine_iter_graph* g, int32_t replays, void* stream) {
   if (!g || !g->exec || g->dirty) return set_error(SHINE_E_STATE, "shine_iter_graph_launch: commit first");
+  if (replays < 1) return SHINE_OK;
+  if (!g->last_replay) SHINE_HIP_CHECK(hipEventCreateWithFlags(&g->last_replay, hipEventDisableTiming));
   for (int r = 0; r < replays; ++r) SHINE_HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  SHINE_HIP_CHECK(hipEventRecord(g->last_replay, (hipStream_t)stream));
+  g->replayed = true;
   return SHINE_OK;
 }
 

@@ -1121,6 +1121,52 @@ def test_graphed_iteration_matches_eager_loop(mode, native):
         step()
 
 
+def test_iteration_graph_rebound_while_its_replays_are_still_queued():
+    """Two maps share the library's iteration graph (one per device and unroll).  Map A's replays are queued behind a long
+    kernel, map B binds the graph straight away — the commit must not rewrite kernel arguments that A's queued replays still
+    need (shine_iter_graph_commit waits for the graph's own last replay) — then A again.  Each map ends exactly where the same
+    iterations end when run with a synchronisation after every call."""
+    from shine_mapping_amd import StepOptions
+    from shine_mapping_amd.loop import GraphedIteration
+    from shine_mapping_amd.optim import setup_optimizer
+    from shine_mapping_amd.sampler import SortedPool
+
+    K, N = 8, 4096
+
+    def make(name, seed):
+        fx = load_golden(name)
+        cfg, octree, dec = product_from_golden(fx)
+        dec = dec.cuda()
+        cfg.lr, cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio, cfg.weight_decay = 0.01, True, 1e-15, 1.0, 1e-7
+        opt = setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())
+        octree._require_tables(with_ranks=True)
+        pool = SortedPool(octree, fx["coord"].cuda().repeat(8, 1), fx["sdf_label"].cuda().repeat(8),
+                          fx["weight"].cuda().repeat(8), seed=seed, canonical=True)
+        opts = StepOptions(sigma=fx["sigma"], deterministic=True)
+        return octree, dec, GraphedIteration(octree, dec, pool, opt, opts, N)
+
+    def run(overlapped):
+        oa, da, a = make("maicity_bce_L3", 3)
+        ob, db, b = make("ncd_reg_L3", 4)
+        assert a.native and b.native
+        torch.cuda.synchronize()
+        if overlapped:
+            # ~10 ms of device work in front of A's replays: they are still queued when B (and then A again) binds the graph
+            big = torch.randn(4096, 4096, device="cuda")
+            for _ in range(40):
+                big = big @ big.t() * 1e-4
+        for step in (a, b, a, b):
+            step.run(K)
+            if not overlapped:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return [p.detach().clone() for m in ((oa, da), (ob, db)) for p in list(m[0].hier_features) + m[1].fused_params()]
+
+    ref, got = run(False), run(True)
+    for x, y in zip(ref, got):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("kind,levels,n", [("maicity", 4, (1 << 18) + 37), ("kitti", 3, (1 << 17) + 1)])
 def test_pool_mode_at_scale_equals_planned_batch_mode(kind, levels, n):
     """BASELINE-size pool-mode launch (4 tiles per wave, ragged tail, indices prefetched two tiles ahead) against the
