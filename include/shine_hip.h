@@ -98,8 +98,7 @@ typedef struct shine_step_config {
   int32_t defer_reduce;    /* 1: shine_train_step launches the fused kernel ONLY and leaves its per-workgroup partial sums
                               (decoder grads, trash-row grads, loss terms) in the workspace: shine_finish_iteration consumes
                               them in the optimiser's launch.  loss_parts is then written by that call, and adam_state /
-                              zero_f64 are served by the fused kernel itself.  (shine_importance_sweep uses it too: it needs
-                              none of those sums.) */
+                              zero_f64 are served by the fused kernel itself. */
 } shine_step_config;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -272,17 +271,21 @@ int shine_importance_accumulate(float* importance, float* grad, int64_t rows, vo
  *      call.  coord / sdf_label / weight (or NULL) / slots: a node-ordered pool as for pool-mode shine_train_step
  *      (cfg->sorted_input = 2, eikonal off, decoder_grad_on = 0); idx: the chunks' members (sorted sample indices into the
  *      pool) stored chunk after chunk; chunk_begin: HOST int64[n_chunks + 1] offsets into idx.  Per chunk: the fused step
- *      with inv_n = 1 / chunk size (or 1 under reduction_sum) accumulating into grad_feats, then importance[s] +=
- *      |grad_feats[s]|, grad_feats[s] = 0, importance[s][trash row] = 0 for every level.  grad_feats must be zero on
- *      entry (and are zero on return); pred_scratch: device float[max chunk size]; workspace as for shine_train_step of
- *      the largest chunk.  Like the query_feature of every chunk (set_zero, model/feature_octree.py:78-81,238) the call
- *      re-zeroes the trash row of every feats[s] — the one write through the `feats` pointers. */
+ *      with inv_n = 1 / chunk size (or 1 under reduction_sum) into the chunk's OWN gradient tables (the reference sums a
+ *      chunk's gradient before the abs, :36-38), then importance[s] += |that gradient| for every level, chunk after chunk,
+ *      importance[s][trash row] = 0.  `group` chunks (1..32) are ONE launch of the step and one launch that folds their
+ *      tables into importance: scratch = zeroed device memory for `group` sets of {gradient tables, one flag byte per row}
+ *      — zero on entry, zero again on return, so it can be kept and re-used — workspace = the steps' partial vectors;
+ *      shine_importance_sweep_sizes gives group (32, fewer chunks, or what fits budget_bytes of scratch; 0 = no budget) and both
+ *      sizes.  Like the query_feature of every chunk (set_zero, model/feature_octree.py:78-81,238) the call re-zeroes the
+ *      trash row of every feats[s] — the one write through the `feats` pointers. */
+int shine_importance_sweep_sizes(int32_t n_levels, const int64_t* rows, int32_t n_chunks, int64_t max_chunk,
+                                 size_t budget_bytes, int32_t* group_out, size_t* scratch_bytes, size_t* workspace_bytes);
 int shine_importance_sweep(const shine_tables* t, const shine_step_config* cfg, const float* coord,
                            const float* sdf_label, const float* weight, const int32_t* idx, const int32_t* slots,
                            const int64_t* chunk_begin, int32_t n_chunks, const float* const* feats, const int64_t* rows,
-                           const float* const* mlp, float* pred_scratch, float* const* grad_feats,
-                           float* const* importance, double* loss_parts, void* workspace, size_t workspace_bytes,
-                           void* stream);
+                           const float* const* mlp, float* const* importance, int32_t group, void* scratch,
+                           size_t scratch_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- fused dense Adam (next row f-1): opt.step() [+ opt.zero_grad()] of shine_batch.py:208-210 for the optimiser of
  *      setup_optimizer (utils/tools.py:57-83): torch.optim.Adam semantics (betas, eps, L2 weight decay added to the

@@ -73,33 +73,6 @@ __global__ __launch_bounds__(256) void k_importance(float* imp, float* grad, lon
   }
 }
 
-// the epilogue for all levels in one launch (blockIdx.y = level), 16 bytes per lane
-struct ImpArgs {
-  float4* imp[SHINE_MAX_LEVELS];
-  float4* grad[SHINE_MAX_LEVELS];
-  float4* feat[SHINE_MAX_LEVELS];      // the feature table: its trash row is re-zeroed (set_zero of the chunk's query_feature)
-  long long n4[SHINE_MAX_LEVELS];      // (rows + 1) * F / 4
-  long long trash4[SHINE_MAX_LEVELS];  // rows * F / 4: from here on the trash row
-};
-
-__global__ __launch_bounds__(256) void k_importance_levels(ImpArgs a) {
-  const int s = blockIdx.y;
-  float4* const imp = a.imp[s];
-  float4* const grad = a.grad[s];
-  const long long n4 = a.n4[s], trash4 = a.trash4[s];
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
-    const float4 g = grad[e];
-    grad[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // FeatureOctree.set_zero (model/feature_octree.py:78-81): every chunk's query_feature zeroes the trash row — after the
-    // training iterations it holds the last Adam step's move (the fused step itself never reads it)
-    if (e >= trash4) a.feat[s][e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 v = imp[e];
-    v = e >= trash4 ? make_float4(0.f, 0.f, 0.f, 0.f)
-                    : make_float4(v.x + fabsf(g.x), v.y + fabsf(g.y), v.z + fabsf(g.z), v.w + fabsf(g.w));
-    imp[e] = v;
-  }
-}
-
 }  // namespace shine
 
 using namespace shine;
@@ -151,59 +124,5 @@ extern "C" int shine_importance_accumulate(float* importance, float* grad, int64
   hipLaunchKernelGGL(k_importance, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, importance, grad, n_elems,
                      (long long)rows * F);
   SHINE_HIP_CHECK(hipGetLastError());
-  return SHINE_OK;
-}
-
-// cal_feature_importance (utils/incre_learning.py:8-40) over a node-ordered pool, the chunk loop on this side of the ABI:
-// per chunk one fused step with the decoder frozen + one epilogue launch, back to back on the stream — a frame's 35-70
-// chunks cost their ~3 launches each instead of a Python iteration each.
-extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_config* cfg, const float* coord,
-                                      const float* sdf_label, const float* weight, const int32_t* idx,
-                                      const int32_t* slots, const int64_t* chunk_begin, int32_t n_chunks,
-                                      const float* const* feats, const int64_t* rows, const float* const* mlp,
-                                      float* pred_scratch, float* const* grad_feats, float* const* importance,
-                                      double* loss_parts, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!t || !cfg || !chunk_begin || n_chunks < 0 || !feats || !rows || !mlp || !grad_feats || !importance)
-    return set_error(SHINE_E_INVALID, "shine_importance_sweep: null argument");
-  const int L = cfg->n_levels;
-  if (L < 1 || L > SHINE_MAX_LEVELS) return set_error(SHINE_E_INVALID, "shine_importance_sweep: bad level count");
-  if (cfg->sorted_input != 2 || cfg->eikonal_on || cfg->decoder_grad_on)
-    return set_error(SHINE_E_INVALID, "shine_importance_sweep: wants a pool-mode config, BCE only, decoder frozen");
-  ImpArgs ia = {};
-  long long max4 = 0;
-  for (int s = 0; s < L; ++s) {
-    if (!grad_feats[s] || !importance[s] || rows[s] < 0 ||
-        (((size_t)grad_feats[s] | (size_t)importance[s]) & 15))
-      return set_error(SHINE_E_INVALID, "shine_importance_sweep: null or unaligned level tensor");
-    if (!feats[s] || ((size_t)feats[s] & 15))
-      return set_error(SHINE_E_INVALID, "shine_importance_sweep: null or unaligned feature table");
-    ia.imp[s] = (float4*)importance[s];
-    ia.grad[s] = (float4*)grad_feats[s];
-    ia.feat[s] = (float4*)const_cast<float*>(feats[s]);
-    ia.n4[s] = (rows[s] + 1) * F / 4;
-    ia.trash4[s] = rows[s] * F / 4;
-    if (ia.n4[s] > max4) max4 = ia.n4[s];
-  }
-  long long blocks = (max4 + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  if (blocks < 1) blocks = 1;
-  hipStream_t st = (hipStream_t)stream;
-  for (int c = 0; c < n_chunks; ++c) {
-    const int64_t b = chunk_begin[c], n = chunk_begin[c + 1] - b;
-    if (n < 0) return set_error(SHINE_E_INVALID, "shine_importance_sweep: chunk_begin must be non-decreasing");
-    if (n == 0) continue;
-    shine_step_config cc = *cfg;  // the reference normalises every chunk by its own size (sdf_bce_loss 'mean')
-    cc.n_global = n;
-    cc.inv_n = cc.reduction_sum ? 1.0 : 1.0 / (double)n;
-    // no reduction launch: the decoder is frozen, the loss is not read, and the trash rows' sums would be cleared below anyway
-    cc.defer_reduce = 1;
-    cc.adam_state = nullptr;
-    cc.zero_f64 = nullptr;
-    int rc = shine_train_step(t, &cc, coord, sdf_label, weight, idx + b, slots, nullptr, n, feats, rows, mlp, pred_scratch,
-                              nullptr, grad_feats, nullptr, loss_parts, nullptr, workspace, workspace_bytes, stream);
-    if (rc != SHINE_OK) return rc;
-    hipLaunchKernelGGL(k_importance_levels, dim3((unsigned)blocks, (unsigned)L), dim3(256), 0, st, ia);
-    SHINE_HIP_CHECK(hipGetLastError());
-  }
   return SHINE_OK;
 }

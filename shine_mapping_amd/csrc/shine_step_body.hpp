@@ -28,8 +28,16 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 // k_mark_touched launch in front of the step — a build of its own, because the flag code costs the kernel ~10 % at 2^18
 // points even when there are no flags to set (profiles/r03_ab_experiments.txt block 3), and pays at the incremental
 // configuration's 4096 points, where the extra launch is half the step (ncd-incre 172 -> 179 frames/s).
-template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false>
-__device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm, const int bid, const int nbid) {
+// SLICED: the launch holds many independent steps (shine_sweep.hip); `sl` names this workgroup's one — sample indices, size,
+// normaliser, private gradient tables and flags — and bid / nbid count inside the slice.
+template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false, bool SLICED = false>
+__device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm, const int bid, const int nbid,
+                                          const StepSlice* sl = nullptr) {
+// (spelled as expressions at every use, not as locals: the unsliced builds must stay the instruction streams the committed
+// counter files were measured on — tools/kernel_hash.py)
+#define SL_N (SLICED ? sl->n : a.n)
+#define SL_PERM (SLICED ? sl->perm : a.perm)
+#define SL_TOUCHED(s) (SLICED ? sl->touched[s] : a.touched[s])
   constexpr int NT = WAVES * 64;
   float* const s_opA = sm.opA;
   float* const s_bias = sm.bias;
@@ -70,7 +78,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     begin = V3_TP * (t0 + lo);
     end_t = V3_TP * (t0 + hi);
   }
-  const long long end = end_t < a.n ? end_t : a.n;
+  const long long end = end_t < SL_N ? end_t : SL_N;
   const long long second = begin + V3_TP;
 
   // ---- the first loads of the launch, in dependency order so that their round trips overlap (a wave's fixed cost was
@@ -84,8 +92,8 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
   int nslot = -1;
   bool nvalid = begin + pt < end;
   int np2 = 0, np1 = 0;
-  if (a.perm && second + pt < end) np2 = a.perm[second + pt];
-  if (a.perm && nvalid) np1 = a.perm[begin + pt];
+  if (SL_PERM && second + pt < end) np2 = SL_PERM[second + pt];
+  if (SL_PERM && nvalid) np1 = SL_PERM[begin + pt];
 
   // ---- per-workgroup setup: A operands in 16x16x4 lane order (lane l: row i = l & 15, k = l >> 4), biases.
   // Branch-free source select and a fully unrolled loop: the (up to 11) loads of a thread are all in flight together.
@@ -112,7 +120,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
   }
 
   if (nvalid) {
-    np = a.perm ? (long long)np1 : begin + pt;
+    np = SL_PERM ? (long long)np1 : begin + pt;
     const long long si = a.pool_mode ? np : begin + pt;
     if (lvl_on_i) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
     nx0 = a.coord[3 * np];
@@ -281,7 +289,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
       nx0 = nx1 = nx2 = nlabel = nweight = 0.f;
       nslot = -1;
       if (nvalid) {
-        np = a.perm ? (long long)np2 : ni;
+        np = SL_PERM ? (long long)np2 : ni;
         const long long si = a.pool_mode ? np : ni;
         if (lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
         nx0 = __builtin_nontemporal_load(a.coord + 3 * np);
@@ -290,7 +298,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
         nlabel = __builtin_nontemporal_load(a.label + np);
         if ((EIK && !EXT) || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
       }
-      if (a.perm && ni2 < end) np2 = __builtin_nontemporal_load(a.perm + ni2);
+      if (SL_PERM && ni2 < end) np2 = __builtin_nontemporal_load(SL_PERM + ni2);
     }
     // reduce-scatter of the per-level sums over the point's four lanes: lane g ends with features (2g, 2g+1)
     float f2[2];
@@ -371,7 +379,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
           loss_acc += lw * (fmaxf(y, 0.f) - y * zt + 0.693147180559945f * __builtin_amdgcn_logf(1.0f + e));
           cnt_acc += 1;
         }
-        delta = lw * (sg - zt) * a.inv_n;
+        delta = lw * (sg - zt) * (SLICED ? sl->inv_n : a.inv_n);
       }
     }
     float sdf2[2];  // what the scatter multiplies the staged weights with: d loss / d f (BCE build), d y / d f (eikonal build)
@@ -640,7 +648,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
             iq[(s + 1) & 1][j] = *reinterpret_cast<const int4*>(sc_ids + ((s + 1) * 8) * V3_WP + 4 * j);
           }
         }
-        float* gbase = a.lv[s].grad;
+        float* gbase = SLICED ? sl->grad[s] : a.lv[s].grad;
         if (gbase) {
           float wr[V3_TP];
           int idr[V3_TP];
@@ -664,7 +672,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
               rhit = (int)((hm >> p2) & 1u);
               // the touched-row flags (unique(hierarchical_indices) without -1, for shine_regularize) are set here, at the run
               // start of every hit node, by one lane per corner
-              if (MARK && rhit && a.touched[s] && sq == 0) a.touched[s][idr[p2]] = 1;
+              if (MARK && rhit && SL_TOUCHED(s) && sq == 0) SL_TOUCHED(s)[idr[p2]] = 1;
             }
             racc = fmaf(wr[p2], dfr[p2], racc);  // misses and padding lanes staged w = 0
           }
@@ -681,7 +689,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
   // ---- end of the wave's run: flush the open node runs
 #pragma unroll
   for (int s = 0; s < L; ++s) {
-    float* gbase = a.lv[s].grad;
+    float* gbase = SLICED ? sl->grad[s] : a.lv[s].grad;
     if (gbase && run_hit[s]) atomic_add_f32(gbase + (unsigned int)run_id[s], run_acc[s]);
   }
   __syncthreads();  // every wave is done with its staging region: it now holds the wave's partial vector
@@ -736,7 +744,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     for (int k = 0; k < 8; ++k) a.prof[wave_g * 8 + k] = pc[k];
   }
   const int mlp_lo = a.decoder_grad_on ? 0 : SHINE_MLP_PARAMS;  // a frozen decoder has no sums to move
-  float* dst = a.partials + (long long)bid * PART_STRIDE;
+  float* dst = a.partials + (long long)(SLICED ? sl->part_bid : bid) * PART_STRIDE;
   for (int idx = tid; idx < PART_TRASH + L * 8; idx += NT) {
     float v = 0.f;
     if (idx >= mlp_lo) {
@@ -759,6 +767,9 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     if (tid == 64 && a.zero_f64) *a.zero_f64 = 0.0;
   }
 #undef SHINE_STAMP
+#undef SL_N
+#undef SL_PERM
+#undef SL_TOUCHED
 }
 
 }  // namespace shine

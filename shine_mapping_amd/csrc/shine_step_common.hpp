@@ -69,6 +69,17 @@ struct V1Args {
   float weight_e;
 };
 
+// SLICED builds of the step body (shine_sweep.hip: many independent small steps in ONE launch): what differs from one slice of
+// the launch to the next, everything else comes from the shared V1Args
+struct StepSlice {
+  const int* perm;   // the slice's sample indices
+  long long n;       // ... and their number
+  float inv_n;       // the slice's own normaliser
+  int part_bid;      // index of the workgroup's partial vector in the workspace
+  float* grad[LCAP];             // the slice's private gradient tables
+  unsigned char* touched[LCAP];  // ... and touched-row flags (MARK builds)
+};
+
 __device__ __forceinline__ long long clk() { return (long long)__builtin_readcyclecounter(); }
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row (4 VALU ops, no LDS traffic)

@@ -1,0 +1,226 @@
+// shine_sweep.hip — cal_feature_importance (utils/incre_learning.py:8-40) as a BATCH of steps per launch.
+//
+// The reference walks the frame's pool in chunks and, per chunk, runs query + decode + BCE + backward and adds
+// |hier_features[i].grad| to importance_weight[i] (:27-40): the gradient is summed over a chunk BEFORE the abs, so the chunks
+// cannot share a gradient table.  Rounds 2-3 ran the chunk loop on this side of the ABI as {fused step, epilogue} per chunk:
+// 35-70 chunks x 2 small launches, 0.69 ms of a 3.3 ms frame at the incremental configuration, each launch using a quarter of
+// the chip.  Here a GROUP of chunks is one launch: workgroup b of the grid works on chunk b / bpc as workgroup b % bpc of that
+// chunk's step (the SLICED build of the step body: own sample range, own normaliser — sdf_bce_loss 'mean' divides by the
+// chunk's size — own gradient tables and touched-row flags), and ONE epilogue launch per group folds the group's tables into
+// importance_weight, visiting only the rows a chunk flagged, and leaves tables and flags zero for the next group.
+#include <algorithm>
+
+#include "shine_step_body.hpp"
+#include "shine_sweep.hpp"
+
+namespace shine {
+
+template <int L, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_sweep(SweepArgs s) {
+  __shared__ StepShared<WAVES> sm;
+  const int c = (int)blockIdx.x / s.bpc, b = (int)blockIdx.x - c * s.bpc;
+  const long long first = s.begin[c], n = s.begin[c + 1] - first;
+  if (n <= 0) return;  // (the whole workgroup)
+  StepSlice sl;
+  sl.perm = s.a.perm + first;
+  sl.n = n;
+  sl.inv_n = s.a.reduction_sum ? 1.0f : (float)(1.0 / (double)n);
+  sl.part_bid = (int)blockIdx.x;
+#pragma unroll
+  for (int l = 0; l < LCAP; ++l) {
+    sl.grad[l] = l < L ? s.a.lv[l].grad + (long long)c * s.grad_stride : nullptr;
+    sl.touched[l] = l < L ? s.a.touched[l] + (long long)c * s.flag_stride : nullptr;
+  }
+  step_body<L, WAVES, false, false, false, true, true>(s.a, sm, b, s.bpc, &sl);
+}
+
+// importance_weight[s] += sum over the group's chunks of |chunk gradient| on the rows a chunk flagged; tables and flags are
+// left zero.  One thread per 4 rows (their 4 flag bytes are one load per chunk); blockIdx.y = level.  The order of the
+// chunks in a row's sum is the chunk order, as in the reference's loop.
+__global__ __launch_bounds__(256) void k_sweep_fold(SweepFoldArgs a) {
+  const int s = blockIdx.y;
+  const long long rows = a.rows[s];       // without the trash row
+  const long long quads = (rows + 4) / 4;  // rows + 1 entries, 4 per thread
+  float4* const imp = a.imp[s];
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long long)gridDim.x * 256) {
+    unsigned int by_row[4] = {0u, 0u, 0u, 0u};  // bit c: chunk c flagged row 4 q + k
+    unsigned int by_chunk = 0u;
+    for (int c = 0; c < a.chunks; ++c) {
+      const unsigned int f = reinterpret_cast<const unsigned int*>(a.flags[s] + (long long)c * a.flag_stride)[q];
+      if (f) {
+        by_chunk |= 1u << c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) by_row[k] |= ((f >> (8 * k)) & 0xffu) ? 1u << c : 0u;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned int m = by_row[k];
+      if (!m) continue;
+      const long long r = 4 * q + k;  // (a flagged row is a real row: r < rows)
+      float4 v0 = imp[2 * r], v1 = imp[2 * r + 1];
+      while (m) {
+        const int c = __builtin_ctz(m);
+        m &= m - 1;
+        float4* g = reinterpret_cast<float4*>(a.grad[s] + (long long)c * a.grad_stride) + 2 * r;
+        const float4 g0 = g[0], g1 = g[1];
+        g[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        v0.x += fabsf(g0.x), v0.y += fabsf(g0.y), v0.z += fabsf(g0.z), v0.w += fabsf(g0.w);
+        v1.x += fabsf(g1.x), v1.y += fabsf(g1.y), v1.z += fabsf(g1.z), v1.w += fabsf(g1.w);
+      }
+      imp[2 * r] = v0;
+      imp[2 * r + 1] = v1;
+    }
+    while (by_chunk) {
+      const int c = __builtin_ctz(by_chunk);
+      by_chunk &= by_chunk - 1;
+      reinterpret_cast<unsigned int*>(a.flags[s] + (long long)c * a.flag_stride)[q] = 0u;
+    }
+    if (4 * q <= rows && rows < 4 * q + 4) {
+      // the trash row: importance_weight[i][-1] *= 0 (utils/incre_learning.py:40), and FeatureOctree.set_zero
+      // (model/feature_octree.py:78-81) — every chunk's query_feature zeroes the features' trash row, which holds the last Adam
+      // step's move after the training iterations (the fused step itself never reads it)
+      imp[2 * rows] = make_float4(0.f, 0.f, 0.f, 0.f);
+      imp[2 * rows + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a.feat[s][2 * rows] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a.feat[s][2 * rows + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+template <int WAVES>
+static const void* sweep_fn(int levels) {
+  switch (levels) {
+    case 1: return (const void*)k_step_sweep<1, WAVES>;
+    case 2: return (const void*)k_step_sweep<2, WAVES>;
+    case 3: return (const void*)k_step_sweep<3, WAVES>;
+    default: return (const void*)k_step_sweep<4, WAVES>;
+  }
+}
+
+}  // namespace shine
+
+using namespace shine;
+
+// bytes of the zeroed scratch (private gradient tables + flags for `group` chunks) and of the step workspace
+static void sweep_layout(const int64_t* rows, int L, size_t* grad_stride_f, size_t* flag_stride_b) {
+  size_t gf = 0, fb = 0;
+  for (int s = 0; s < L; ++s) {
+    gf += (size_t)(rows[s] + 1) * F;
+    fb += ((size_t)(rows[s] + 1) + 15) & ~(size_t)15;
+  }
+  *grad_stride_f = gf;  // floats per chunk (every level's table is a multiple of 8 floats: 16-byte aligned parts)
+  *flag_stride_b = fb;
+}
+
+extern "C" int shine_importance_sweep_sizes(int32_t n_levels, const int64_t* rows, int32_t n_chunks, int64_t max_chunk,
+                                            size_t budget_bytes, int32_t* group_out, size_t* scratch_bytes,
+                                            size_t* workspace_bytes) {
+  if (n_levels < 1 || n_levels > LCAP || !rows || n_chunks < 0 || max_chunk < 0 || !group_out || !scratch_bytes ||
+      !workspace_bytes)
+    return set_error(SHINE_E_INVALID, "shine_importance_sweep_sizes: bad argument");
+  size_t gf, fb;
+  sweep_layout(rows, n_levels, &gf, &fb);
+  const size_t per_chunk = gf * sizeof(float) + fb;
+  long long group = n_chunks < SWEEP_GROUP ? n_chunks : SWEEP_GROUP;
+  if (budget_bytes && per_chunk && (long long)(budget_bytes / per_chunk) < group) group = (long long)(budget_bytes / per_chunk);
+  if (group < 1) group = 1;
+  const V2Geometry g = v3_geometry(max_chunk > 0 ? max_chunk : 1);
+  *group_out = (int32_t)group;
+  *scratch_bytes = (size_t)group * per_chunk;
+  *workspace_bytes = (size_t)group * (size_t)g.blocks * PART_STRIDE * sizeof(float);
+  return SHINE_OK;
+}
+
+extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_config* cfg, const float* coord,
+                                      const float* sdf_label, const float* weight, const int32_t* idx,
+                                      const int32_t* slots, const int64_t* chunk_begin, int32_t n_chunks,
+                                      const float* const* feats, const int64_t* rows, const float* const* mlp,
+                                      float* const* importance, int32_t group, void* scratch, size_t scratch_bytes,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!t || !cfg || !chunk_begin || n_chunks < 0 || !feats || !rows || !mlp || !importance || !scratch)
+    return set_error(SHINE_E_INVALID, "shine_importance_sweep: null argument");
+  const int L = cfg->n_levels;
+  if (L < 1 || L > LCAP) return set_error(SHINE_E_INVALID, "shine_importance_sweep: bad level count");
+  if (cfg->sorted_input != 2 || cfg->eikonal_on || cfg->decoder_grad_on)
+    return set_error(SHINE_E_INVALID, "shine_importance_sweep: wants a pool-mode config, BCE only, decoder frozen");
+  if (group < 1 || group > SWEEP_GROUP) return set_error(SHINE_E_INVALID, "shine_importance_sweep: 1 <= group <= 32");
+  size_t gf, fb;
+  sweep_layout(rows, L, &gf, &fb);
+  if (scratch_bytes < (size_t)group * (gf * sizeof(float) + fb) || ((size_t)scratch & 15))
+    return set_error(SHINE_E_INVALID, "shine_importance_sweep: scratch too small or unaligned (shine_importance_sweep_sizes)");
+  int64_t max_chunk = 0;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int64_t n = chunk_begin[c + 1] - chunk_begin[c];
+    if (n < 0) return set_error(SHINE_E_INVALID, "shine_importance_sweep: chunk_begin must be non-decreasing");
+    if (n > max_chunk) max_chunk = n;
+  }
+  if (max_chunk == 0) return SHINE_OK;
+  // scratch = [group][levels' gradient tables] then [group][levels' flags]
+  float* const grad0 = reinterpret_cast<float*>(scratch);
+  unsigned char* const flag0 = reinterpret_cast<unsigned char*>(grad0 + (size_t)group * gf);
+  float* grad_l[LCAP] = {};
+  unsigned char* flag_l[LCAP] = {};
+  SweepFoldArgs fa = {};
+  {
+    size_t go = 0, fo = 0;
+    for (int s = 0; s < L; ++s) {
+      if (!importance[s] || !feats[s] || rows[s] < 0 || (((size_t)importance[s] | (size_t)feats[s]) & 15))
+        return set_error(SHINE_E_INVALID, "shine_importance_sweep: null or unaligned level tensor");
+      grad_l[s] = grad0 + go;
+      flag_l[s] = flag0 + fo;
+      fa.imp[s] = (float4*)importance[s];
+      fa.feat[s] = (float4*)const_cast<float*>(feats[s]);
+      fa.grad[s] = grad_l[s];
+      fa.flags[s] = flag_l[s];
+      fa.rows[s] = rows[s];
+      go += (size_t)(rows[s] + 1) * F;
+      fo += ((size_t)(rows[s] + 1) + 15) & ~(size_t)15;
+    }
+  }
+  fa.grad_stride = (long long)gf;
+  fa.flag_stride = (long long)fb;
+
+  SweepArgs sa = {};
+  shine_step_config cc = *cfg;
+  cc.n_global = max_chunk;
+  cc.defer_reduce = 0;  // (no hooks: nothing follows the step but the fold)
+  cc.adam_state = nullptr;
+  cc.zero_f64 = nullptr;
+  cc.next_draw = nullptr;
+  int rc = fill_step_args(&sa.a, t, &cc, coord, sdf_label, weight, idx, slots, nullptr, max_chunk, feats, rows, mlp, nullptr,
+                          nullptr, grad_l, nullptr, nullptr, flag_l);
+  if (rc != SHINE_OK) return rc;
+  V2Geometry g = v3_geometry(max_chunk);
+  if (sa.a.ablate & 64) {  // the test suite's deterministic accumulation: one wave per chunk
+    g.blocks = 1;
+    g.wg_waves = 4;
+    g.waves = 4;
+  }
+  sa.a.tiles = g.tiles;
+  sa.a.waves_total = g.waves;
+  sa.a.partials = (float*)workspace;
+  sa.bpc = (int)g.blocks;
+  sa.grad_stride = (long long)gf;
+  sa.flag_stride = (long long)fb;
+  if (!workspace || workspace_bytes < (size_t)group * (size_t)g.blocks * PART_STRIDE * sizeof(float))
+    return set_error(SHINE_E_INVALID, "shine_importance_sweep: workspace too small (shine_importance_sweep_sizes)");
+  const void* fn = g.wg_waves == V3_BIG ? sweep_fn<V3_BIG>(L) : sweep_fn<4>(L);
+
+  long long max_quads = 0;
+  for (int s = 0; s < L; ++s) max_quads = std::max(max_quads, (long long)(rows[s] + 4) / 4);
+  long long fold_blocks = (max_quads + 255) / 256;
+  if (fold_blocks > 2048) fold_blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  for (int c0 = 0; c0 < n_chunks; c0 += group) {
+    const int nc = n_chunks - c0 < group ? n_chunks - c0 : group;
+    for (int c = 0; c <= nc; ++c) sa.begin[c] = chunk_begin[c0 + c];
+    void* kp[] = {&sa};
+    SHINE_HIP_CHECK(hipLaunchKernel(fn, dim3((unsigned)(nc * sa.bpc)), dim3((unsigned)(g.wg_waves * 64)), kp, 0, st));
+    fa.chunks = nc;
+    hipLaunchKernelGGL(k_sweep_fold, dim3((unsigned)fold_blocks, (unsigned)L), dim3(256), 0, st, fa);
+    SHINE_HIP_CHECK(hipGetLastError());
+  }
+  return SHINE_OK;
+}

@@ -2,8 +2,9 @@
 
 Per chunk of the frame's pool the reference runs query + decode + BCE + backward and then
 ``importance_weight[i] += hier_features[i].grad.abs(); grad.zero_(); importance_weight[i][-1] *= 0``.
-Here the chunk's forward+backward is one fused step with the decoder frozen (only feature grads are needed) and the
-epilogue is one kernel per level (shine_importance_accumulate).
+Here the forward+backward of up to 32 chunks is ONE launch of the fused step with the decoder frozen (every chunk with its own
+gradient tables: a chunk's gradient is summed before the abs) and one more launch folds them into importance_weight
+(csrc/shine_sweep.hip).
 """
 import ctypes as C
 import math
@@ -12,7 +13,19 @@ import torch
 
 from . import _lib
 from .dp import plan_batch
-from .ops import StepOptions, _dense_grad, _workspace
+from .ops import StepOptions, _dense_grad
+
+# scratch of the sweep (the chunks' private gradient tables and row flags): zero on entry, left zero by the call, so ONE buffer per
+# device is kept and re-used by every frame, whatever the octree's size was when it was allocated
+_SCRATCH = {}
+SCRATCH_BUDGET_BYTES = 2 << 30
+
+
+def _zero_scratch(dev, nbytes):
+    buf = _SCRATCH.get(dev)
+    if buf is None or buf.numel() < nbytes:
+        buf = _SCRATCH[dev] = torch.zeros(nbytes + nbytes // 2, dtype=torch.uint8, device=dev)
+    return buf
 
 
 def chunk_partition(perm, sample_count, batch_interval, down_rate):
@@ -71,19 +84,22 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
                              reduction_sum=1 if loss_reduction == "sum" else 0, decoder_grad_on=0, sorted_input=2,
                              n_global=max_chunk, kernel_variant=int(opts.kernel_variant), loss_weight_on=0,
                              inv_n=1.0)
-    grads = [_dense_grad(f) for f in octree.hier_features]
-    for g in grads:
-        g.zero_()
-    pred = torch.empty(max_chunk, dtype=torch.float32, device=dev)
-    loss_parts = torch.empty(4, dtype=torch.float64, device=dev)
-    ws = _workspace(dev, cfg)
+    # the reference's post-condition (:38): the features' .grad are zero tensors (the chunks' gradients themselves live in the
+    # sweep's scratch, not here)
+    torch._foreach_zero_([_dense_grad(f) for f in octree.hier_features])
     lib = _lib.lib()
+    rows = octree.row_counts()
+    group, scratch_bytes, ws_bytes = C.c_int32(), C.c_size_t(), C.c_size_t()
+    _lib.check(lib.shine_importance_sweep_sizes(len(octree.hier_features), rows, iter_n, max_chunk, SCRATCH_BUDGET_BYTES,
+                                                C.byref(group), C.byref(scratch_bytes), C.byref(ws_bytes)),
+               "shine_importance_sweep_sizes")
+    scratch = _zero_scratch(dev, scratch_bytes.value)
+    ws = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
     _lib.check(
         lib.shine_importance_sweep(
             t.handle, C.byref(cfg), coord_s.data_ptr(), label_s.data_ptr(), None, idx.data_ptr(), slots.data_ptr(),
-            _lib.i64_array(begin), iter_n, octree.feature_ptrs(), octree.row_counts(),
-            _lib.ptr_array([q.data_ptr() for q in mlp.fused_params()]), pred.data_ptr(),
-            _lib.ptr_array([g.data_ptr() for g in grads]),
-            _lib.ptr_array([w.data_ptr() for w in octree.importance_weight]), loss_parts.data_ptr(), ws.data_ptr(),
-            ws.numel(), _lib.current_stream_handle()),
+            _lib.i64_array(begin), iter_n, octree.feature_ptrs(), rows,
+            _lib.ptr_array([q.data_ptr() for q in mlp.fused_params()]),
+            _lib.ptr_array([w.data_ptr() for w in octree.importance_weight]), group.value, scratch.data_ptr(),
+            scratch.numel(), ws.data_ptr(), ws.numel(), _lib.current_stream_handle()),
         "shine_importance_sweep")

@@ -70,11 +70,24 @@ def test_argument_checks_of_the_per_iteration_entry_points():
     assert lib.shine_sample_sorted(1000, 16, 1, 0, None, None, 0, None, None, None, None, None) == -1
     assert b"shine_sample_sorted" in lib.shine_last_error() if hasattr(lib, "shine_last_error") else True
     # importance sweep / regulariser: null handles and level counts
-    assert lib.shine_importance_sweep(None, None, None, None, None, None, None, None, 0, None, None, None, None, None, None,
-                                      None, None, 0, None) == -1
+    assert lib.shine_importance_sweep(None, None, None, None, None, None, None, None, 0, None, None, None, None, 1, None, 0,
+                                      None, 0, None) == -1
     with pytest.raises(_lib.ShineHipError):
-        _lib.check(lib.shine_importance_sweep(None, None, None, None, None, None, None, None, 0, None, None, None, None, None,
-                                              None, None, None, 0, None), "shine_importance_sweep")
+        _lib.check(lib.shine_importance_sweep(None, None, None, None, None, None, None, None, 0, None, None, None, None, 1,
+                                              None, 0, None, 0, None), "shine_importance_sweep")
+    # the sweep's sizes: 32 chunks per launch at most, fewer under a scratch budget, never less than one
+    rows3 = (C.c_int64 * 3)(1000, 5000, 20000)
+    group, sb, wb = C.c_int32(), C.c_size_t(), C.c_size_t()
+    per_chunk = sum((r + 1) * 32 + ((r + 1 + 15) & ~15) for r in rows3)
+    assert lib.shine_importance_sweep_sizes(3, rows3, 50, 4096, 0, C.byref(group), C.byref(sb), C.byref(wb)) == 0
+    assert group.value == 32 and sb.value == 32 * per_chunk and wb.value > 0
+    assert lib.shine_importance_sweep_sizes(3, rows3, 5, 4096, 0, C.byref(group), C.byref(sb), C.byref(wb)) == 0
+    assert group.value == 5 and sb.value == 5 * per_chunk
+    assert lib.shine_importance_sweep_sizes(3, rows3, 50, 4096, 3 * per_chunk + 7, C.byref(group), C.byref(sb), C.byref(wb)) == 0
+    assert group.value == 3
+    assert lib.shine_importance_sweep_sizes(3, rows3, 50, 4096, 1, C.byref(group), C.byref(sb), C.byref(wb)) == 0
+    assert group.value == 1 and sb.value == per_chunk
+    assert lib.shine_importance_sweep_sizes(5, rows3, 50, 4096, 0, C.byref(group), C.byref(sb), C.byref(wb)) == -1
     cfg = _lib.StepConfig()
     cfg.n_levels = 3
     assert lib.shine_train_step_workspace_bytes(C.byref(cfg), 4096) > 0

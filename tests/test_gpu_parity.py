@@ -416,14 +416,21 @@ def test_fused_regulariser_and_importance_sweep_match_reference():
         assert float(a[-1].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("reduction,bs,down_rate,take", [("mean", 100, 3, 1001), ("sum", 4096, 1, 700), ("mean", 64, 2, 1024)])
-def test_importance_sweep_chunking_matches_oracle(reduction, bs, down_rate, take):
+@pytest.mark.parametrize("reduction,bs,down_rate,take,budget", [
+    ("mean", 100, 3, 1001, None), ("sum", 4096, 1, 700, None), ("mean", 64, 2, 1024, None),
+    ("mean", 8, 2, 1024, None),   # 64 chunks: two launches of 32
+    ("sum", 64, 1, 1000, 3.5),    # a scratch budget of 3.5 chunks' tables: 16 chunks in groups of 3 (the last group has one)
+    ("mean", 50, 1, 1000, 0.5)])  # less than one chunk's tables: one chunk per launch
+def test_importance_sweep_chunking_matches_oracle(reduction, bs, down_rate, take, budget, monkeypatch):
     """cal_feature_importance's chunk loop runs behind the ABI (shine_importance_sweep): a chunk's gradient is summed
     before the abs, so chunk MEMBERSHIP (head:tail:down_rate of the pool in its original order, a short last chunk, one
-    chunk larger than the pool) must be the reference's — utils/incre_learning.py:27-40 — as must the per-chunk 'mean'."""
+    chunk larger than the pool) must be the reference's — utils/incre_learning.py:27-40 — as must the per-chunk 'mean'.
+    Up to 32 chunks are ONE launch (each with its own gradient tables in the sweep's scratch); more chunks, or a scratch
+    budget that holds fewer tables, take several."""
     import copy
 
     from oracle import shine_oracle as so
+    from shine_mapping_amd import incre_learning
     from shine_mapping_amd.incre_learning import cal_feature_importance
 
     fx = load_golden("ncd_reg_L3")
@@ -438,6 +445,11 @@ def test_importance_sweep_chunking_matches_oracle(reduction, bs, down_rate, take
     for t in octree.importance_weight:
         t.zero_()
     data = type("Pool", (), {"coord_pool": pool_c.cuda(), "sdf_label_pool": pool_l.cuda()})()
+    if budget is not None:
+        per_chunk = sum(p.shape[0] * 32 + ((p.shape[0] + 15) & ~15) for p in octree.hier_features)
+        monkeypatch.setattr(incre_learning, "SCRATCH_BUDGET_BYTES", int(budget * per_chunk))
+    for p in octree.hier_features:  # (a leftover gradient must not leak into the first chunk: shine_incre.py:192 clears it)
+        p.grad = torch.ones_like(p)
     cal_feature_importance(data, octree, dec, fx["sigma"], bs, down_rate, reduction)
     torch.cuda.synchronize()
     for a, b in zip(octree.importance_weight, oct_.importance_weight):
@@ -445,6 +457,8 @@ def test_importance_sweep_chunking_matches_oracle(reduction, bs, down_rate, take
         assert float(a[-1].abs().max()) == 0.0
     for f in octree.hier_features:  # the sweep leaves the gradients cleared (incre_learning.py:38)
         assert float(f.grad.abs().max()) == 0.0
+    # ... and its scratch (the chunks' private tables and row flags) zero, for the next call
+    assert all(int(b.count_nonzero()) == 0 for b in incre_learning._SCRATCH.values())
     # the same sweep re-using the plan of the frame's SortedPool (what the incremental loop has in hand) instead of planning
     # the pool a second time: chunk membership comes from the pool's own permutation
     from shine_mapping_amd.sampler import SortedPool
