@@ -960,10 +960,11 @@ def main():
     ap.add_argument("--levels", type=int, default=0, help="tree_level_feat (default: the workload's)")
     ap.add_argument("--frames", type=int, default=0, help="scans the synthetic map is built from")
     ap.add_argument("--iters", type=int, default=50, help="ncd-incre: iterations per frame (config iters)")
-    ap.add_argument("--unroll", type=int, default=2,
-                    help="ncd-incre: iterations captured per HIP graph.  The graph is re-captured every frame, so captured nodes "
-                         "are paid for per frame against the ~8 us of idle GPU per graph boundary they save: measured 3.98 / "
-                         "3.93 / 4.11 / 4.54 ms per frame of 50 iterations at 1 / 2 / 5 / 10 (lab book block 15)")
+    ap.add_argument("--unroll", type=int, default=5,
+                    help="ncd-incre: iterations per HIP graph.  The graph is built once and its nodes are re-bound every frame "
+                         "(two parameter updates per iteration held, on the host's critical path) against ~16 us of idle GPU per "
+                         "graph boundary: measured 351 / 390 / 378 frames/s at 2 / 5 / 10 (profiles/r04_ab_experiments.txt "
+                         "blocks 3 and 9)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of exactly --steps steps each; the line reports the median window")
     ap.add_argument("--no-cpu-baseline", action="store_true")

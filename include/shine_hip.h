@@ -129,6 +129,10 @@ int shine_tables_grow(shine_tables* t, const shine_step_config* cfg, const float
 /* copy out what the last shine_tables_grow added to one level (any pointer may be NULL): node keys [fresh] in
  * insertion (= Morton) order, their corner ids [fresh,8], the new corners' keys [added] in row-id order.
  * Valid until the next shine_tables_grow / shine_tables_rank_nodes on this handle. */
+/* shine_tables_grow_fetch_all: the same for all levels at once, one launch: out (device int64[out_words]) receives, level after
+ * level (top-down), {node keys [fresh] | corner ids [fresh][8] int32 = 4 words per node | new corner keys [added]};
+ * out_words >= sum over levels of 5 * fresh + added (the counts shine_tables_grow returned). */
+int shine_tables_grow_fetch_all(const shine_tables* t, int64_t* out, int64_t out_words, void* stream);
 int shine_tables_grow_fetch(const shine_tables* t, int32_t slot, int64_t* fresh_keys, int32_t* fresh_ids,
                             int64_t* new_corner_keys, void* stream);
 int shine_tables_insert_corners(shine_tables* t, int32_t slot, const int64_t* corner_keys, const int32_t* ids,
@@ -267,6 +271,14 @@ int shine_regularize(int32_t n_levels, const float* const* feats, const float* c
                      const int64_t* rows, const int32_t* grad_on, float lambda_forget, double* reg_out,
                      int32_t out_zeroed, int32_t keep_flags, void* stream);
 int shine_importance_accumulate(float* importance, float* grad, int64_t rows, void* stream);
+/*      shine_append_rows = the feature-side appends of FeatureOctree.update (model/feature_octree.py:147-160) for n_levels
+ *      levels that received `added[s]` new corners, ONE launch: feat[s] [old_rows + added + 1, 8] = the old rows without their
+ *      trash row, then feature_std * noise[s] (noise[s] = the caller's randn(added + 1, 8): the random stream stays the
+ *      caller's) with the last row — the new trash row — zeroed; imp[s] (or NULL) = old_imp[s] without its trash row, then
+ *      zeros; last[s] (or NULL) = a copy of feat[s] (features_last_frame).  old_rows[s] excludes the trash row. */
+int shine_append_rows(int32_t n_levels, const float* const* old_feat, const float* const* old_imp, const float* const* noise,
+                      const int64_t* old_rows, const int64_t* added, float feature_std, float* const* feat, float* const* imp,
+                      float* const* last, void* stream);
 /*      shine_importance_sweep = the whole of cal_feature_importance's chunk loop (utils/incre_learning.py:27-40) in one
  *      call.  coord / sdf_label / weight (or NULL) / slots: a node-ordered pool as for pool-mode shine_train_step
  *      (cfg->sorted_input = 2, eikonal off, decoder_grad_on = 0); idx: the chunks' members (sorted sample indices into the
@@ -279,6 +291,13 @@ int shine_importance_accumulate(float* importance, float* grad, int64_t rows, vo
  *      shine_importance_sweep_sizes gives group (32, fewer chunks, or what fits budget_bytes of scratch; 0 = no budget) and both
  *      sizes.  Like the query_feature of every chunk (set_zero, model/feature_octree.py:78-81,238) the call re-zeroes the
  *      trash row of every feats[s] — the one write through the `feats` pointers. */
+/*      shine_importance_chunks = the chunks of that loop (chunk c = pool[c * bs * down_rate : (c + 1) * bs * down_rate :
+ *      down_rate], :27-31) for a node-ordered pool: perm[j] = ORIGINAL pool index of the sample at sorted position j.  Writes
+ *      idx_out (device int32, >= number of kept samples, <= n): the sorted positions of the chunks' members, chunk after chunk,
+ *      ascending inside a chunk, and chunk_begin (HOST int64[n_chunks + 1], n_chunks = ceil(n / (bs * down_rate))): what
+ *      shine_importance_sweep takes.  workspace == NULL: *workspace_bytes = the size needed. */
+int shine_importance_chunks(const int32_t* perm, int64_t n, int64_t bs, int32_t down_rate, int32_t* idx_out,
+                            int64_t* chunk_begin, int32_t n_chunks, void* workspace, size_t* workspace_bytes, void* stream);
 int shine_importance_sweep_sizes(int32_t n_levels, const int64_t* rows, int32_t n_chunks, int64_t max_chunk,
                                  size_t budget_bytes, int32_t* group_out, size_t* scratch_bytes, size_t* workspace_bytes);
 int shine_importance_sweep(const shine_tables* t, const shine_step_config* cfg, const float* coord,

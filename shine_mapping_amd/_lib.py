@@ -92,6 +92,11 @@ _SIGNATURES = {
         C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                   C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_float, _P, C.c_int32, C.c_int32, _P]),
     "shine_importance_accumulate": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "shine_append_rows": (C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64), C.c_float, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P]),
+    "shine_tables_grow_fetch_all": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "shine_importance_chunks": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, _P, C.POINTER(C.c_int64), C.c_int32, _P,
+                                          C.POINTER(C.c_size_t), _P]),
     "shine_importance_sweep_sizes": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_int64, C.c_size_t,
                                                C.POINTER(C.c_int32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "shine_importance_sweep": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, C.c_size_t,

@@ -436,6 +436,50 @@ extern "C" int shine_tables_grow_fetch(const shine_tables* t, int32_t slot, int6
   return SHINE_OK;
 }
 
+// everything the last shine_tables_grow added, all levels, in ONE launch: per level {keys [fresh] | ids [fresh][8] as 4 words
+// per node | new corner keys [added]} as 8-byte words, level after level
+struct FetchAll {
+  const unsigned long long* src[3 * SHINE_MAX_LEVELS];
+  long long begin[3 * SHINE_MAX_LEVELS + 1];  // word offsets into the output
+  int segs;
+};
+__global__ __launch_bounds__(256) void k_fetch_all(FetchAll f, unsigned long long* __restrict__ out) {
+  const long long total = f.begin[f.segs];
+  for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < total; w += (long long)gridDim.x * 256) {
+    int k = 0;
+    while (w >= f.begin[k + 1]) ++k;
+    out[w] = f.src[k][w - f.begin[k]];
+  }
+}
+
+extern "C" int shine_tables_grow_fetch_all(const shine_tables* t, int64_t* out, int64_t out_words, void* stream) {
+  if (!t) return set_error(SHINE_E_INVALID, "shine_tables_grow_fetch_all: null tables");
+  const GrowScratch& G = t->grow;
+  FetchAll f = {};
+  long long w = 0;
+  for (int s = 0; s < t->n_levels; ++s) {
+    const long long nf = G.n_fresh[s], na = G.n_added[s];
+    const unsigned long long* src[3] = {G.fresh_keys[s], reinterpret_cast<const unsigned long long*>(G.fresh_ids[s]),
+                                        G.new_corners[s]};
+    const long long len[3] = {nf, 4 * nf, na};
+    for (int k = 0; k < 3; ++k) {
+      f.src[f.segs] = src[k];
+      f.begin[f.segs] = w;
+      w += len[k];
+      ++f.segs;
+    }
+  }
+  f.begin[f.segs] = w;
+  if (w == 0) return SHINE_OK;
+  if (!out || out_words < w) return set_error(SHINE_E_INVALID, "shine_tables_grow_fetch_all: output too small");
+  long long blocks = (w + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_fetch_all, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f,
+                     reinterpret_cast<unsigned long long*>(out));
+  SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
+}
+
 extern "C" int shine_tables_rank_nodes(shine_tables* t, int64_t* n_buckets_out, void* stream) {
   if (!t) return set_error(SHINE_E_INVALID, "shine_tables_rank_nodes: null tables");
   const int L = t->n_levels;

@@ -73,9 +73,77 @@ __global__ __launch_bounds__(256) void k_importance(float* imp, float* grad, lon
   }
 }
 
+// FeatureOctree.update's feature-side appends (model/feature_octree.py:147-160) for every level that grew, one launch:
+//   hier_features[s]       = cat(old[:-1], std * randn(added + 1, 8) with its last row zeroed)
+//   importance_weight[s]   = cat(old_imp[:-1], zeros(added + 1, 8))
+//   features_last_frame[s] = hier_features[s].clone()
+struct AppendArgs {
+  const float4* old_feat[SHINE_MAX_LEVELS];
+  const float4* old_imp[SHINE_MAX_LEVELS];  // or null (not incremental)
+  const float4* noise[SHINE_MAX_LEVELS];    // randn(added + 1, 8)
+  float4* feat[SHINE_MAX_LEVELS];
+  float4* imp[SHINE_MAX_LEVELS];
+  float4* last[SHINE_MAX_LEVELS];
+  long long keep4[SHINE_MAX_LEVELS];   // float4s carried over: (old rows without the trash row) * 2
+  long long total4[SHINE_MAX_LEVELS];  // float4s of the new table incl. its trash row
+  float std;
+};
+__global__ __launch_bounds__(256) void k_append_rows(AppendArgs a) {
+  const int s = blockIdx.y;
+  const long long keep4 = a.keep4[s], total4 = a.total4[s];
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+    float4 v;
+    if (e < keep4) {
+      v = a.old_feat[s][e];
+    } else if (e >= total4 - 2) {
+      v = make_float4(0.f, 0.f, 0.f, 0.f);  // the new trash row
+    } else {
+      const float4 r = a.noise[s][e - keep4];
+      v = make_float4(a.std * r.x, a.std * r.y, a.std * r.z, a.std * r.w);
+    }
+    a.feat[s][e] = v;
+    if (a.last[s]) a.last[s][e] = v;
+    if (a.imp[s]) a.imp[s][e] = e < keep4 ? a.old_imp[s][e] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 }  // namespace shine
 
 using namespace shine;
+
+extern "C" int shine_append_rows(int32_t n_levels, const float* const* old_feat, const float* const* old_imp,
+                                 const float* const* noise, const int64_t* old_rows, const int64_t* added, float feature_std,
+                                 float* const* feat, float* const* imp, float* const* last, void* stream) {
+  if (n_levels < 1 || n_levels > SHINE_MAX_LEVELS || !old_feat || !noise || !old_rows || !added || !feat)
+    return set_error(SHINE_E_INVALID, "shine_append_rows: null argument");
+  AppendArgs a = {};
+  a.std = feature_std;
+  long long max4 = 0;
+  for (int s = 0; s < n_levels; ++s) {
+    if (added[s] < 0 || old_rows[s] < 0) return set_error(SHINE_E_INVALID, "shine_append_rows: negative row count");
+    if (!old_feat[s] || !noise[s] || !feat[s] || (imp && imp[s] && !(old_imp && old_imp[s])))
+      return set_error(SHINE_E_INVALID, "shine_append_rows: null level tensor");
+    if ((((size_t)old_feat[s] | (size_t)noise[s] | (size_t)feat[s] | (size_t)(imp ? imp[s] : nullptr) |
+          (size_t)(old_imp ? old_imp[s] : nullptr) | (size_t)(last ? last[s] : nullptr)) & 15))
+      return set_error(SHINE_E_INVALID, "shine_append_rows: level tensors must be 16-byte aligned");
+    a.old_feat[s] = (const float4*)old_feat[s];
+    a.old_imp[s] = (const float4*)(old_imp ? old_imp[s] : nullptr);
+    a.noise[s] = (const float4*)noise[s];
+    a.feat[s] = (float4*)feat[s];
+    a.imp[s] = (float4*)(imp ? imp[s] : nullptr);
+    a.last[s] = (float4*)(last ? last[s] : nullptr);
+    a.keep4[s] = old_rows[s] * (F / 4);
+    a.total4[s] = (old_rows[s] + added[s] + 1) * (F / 4);
+    if (a.total4[s] > max4) max4 = a.total4[s];
+  }
+  long long blocks = (max4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_append_rows, dim3((unsigned)blocks, (unsigned)n_levels), dim3(256), 0, (hipStream_t)stream, a);
+  SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
+}
+
 
 extern "C" int shine_regularize(int32_t n_levels, const float* const* feats, const float* const* feats_last,
                                 const float* const* importance, float* const* grad_feats,

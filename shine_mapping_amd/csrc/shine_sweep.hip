@@ -89,6 +89,25 @@ __global__ __launch_bounds__(256) void k_sweep_fold(SweepFoldArgs a) {
   }
 }
 
+// chunk membership (utils/incre_learning.py:27-31: chunk c = pool[c * interval : (c + 1) * interval : down_rate]) of the sample at
+// sorted position j: key = its chunk, or n_chunks for a sample the stride skips; value = j
+__global__ __launch_bounds__(256) void k_sweep_keys(const int* __restrict__ perm, long long n, long long interval, int down_rate,
+                                                    int n_chunks, unsigned long long* __restrict__ key,
+                                                    unsigned long long* __restrict__ val) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const long long p = perm[j];
+  const long long c = p / interval, off = p - c * interval;
+  key[j] = off % down_rate == 0 ? (unsigned long long)c : (unsigned long long)n_chunks;
+  val[j] = (unsigned long long)j;
+}
+
+__global__ __launch_bounds__(256) void k_sweep_members(const unsigned long long* __restrict__ val, long long kept,
+                                                       int* __restrict__ idx) {
+  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (k < kept) idx[k] = (int)val[k];
+}
+
 template <int WAVES>
 static const void* sweep_fn(int levels) {
   switch (levels) {
@@ -112,6 +131,53 @@ static void sweep_layout(const int64_t* rows, int L, size_t* grad_stride_f, size
   }
   *grad_stride_f = gf;  // floats per chunk (every level's table is a multiple of 8 floats: 16-byte aligned parts)
   *flag_stride_b = fb;
+}
+
+// The chunks of cal_feature_importance as segments of a node-ordered pool: perm[j] = pool index of the sample at sorted position
+// j.  idx_out[chunk_begin[c] .. chunk_begin[c + 1]) = the sorted positions of chunk c's members, ascending (= node order inside
+// a chunk): one stable radix pass over the chunk ids.  chunk_begin (HOST, n_chunks + 1 entries) follows from the sizes alone.
+extern "C" int shine_importance_chunks(const int32_t* perm, int64_t n, int64_t bs, int32_t down_rate, int32_t* idx_out,
+                                       int64_t* chunk_begin, int32_t n_chunks, void* workspace, size_t* workspace_bytes,
+                                       void* stream) {
+  if (n < 0 || bs < 1 || down_rate < 1 || !workspace_bytes || n_chunks < 0)
+    return set_error(SHINE_E_INVALID, "shine_importance_chunks: bad argument");
+  const long long interval = (long long)bs * down_rate;
+  const long long want_chunks = (n + interval - 1) / interval;
+  if (n_chunks != want_chunks)
+    return set_error(SHINE_E_INVALID, "shine_importance_chunks: n_chunks must be ceil(n / (bs * down_rate))");
+  if (n > 0x7fffffffll) return set_error(SHINE_E_INVALID, "shine_importance_chunks: pool exceeds the int32 index range");
+  unsigned end_bit = 1;
+  while ((1ll << end_bit) <= (long long)n_chunks) ++end_bit;  // keys 0 .. n_chunks
+  const size_t ab = ((size_t)n * 8 + 255) & ~(size_t)255;
+  size_t tmp_bytes = 0;
+  SHINE_HIP_CHECK(prim_sort_pairs_u64(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)(n > 0 ? n : 1), 0u,
+                                      end_bit, (hipStream_t)stream));
+  const size_t need = 4 * ab + tmp_bytes;
+  if (!workspace) {
+    *workspace_bytes = need;
+    return SHINE_OK;
+  }
+  if (*workspace_bytes < need || !perm || !idx_out || !chunk_begin)
+    return set_error(SHINE_E_INVALID, "shine_importance_chunks: null argument or workspace too small");
+  long long kept = 0;
+  chunk_begin[0] = 0;
+  for (int c = 0; c < n_chunks; ++c) {
+    const long long head = (long long)c * interval, tail = std::min(head + interval, (long long)n);
+    kept += (tail - head + down_rate - 1) / down_rate;
+    chunk_begin[c + 1] = kept;
+  }
+  if (n == 0) return SHINE_OK;
+  char* w = (char*)workspace;
+  unsigned long long *k0 = (unsigned long long*)w, *k1 = (unsigned long long*)(w + ab);
+  unsigned long long *v0 = (unsigned long long*)(w + 2 * ab), *v1 = (unsigned long long*)(w + 3 * ab);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_sweep_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, perm, (long long)n, interval,
+                     (int)down_rate, (int)n_chunks, k0, v0);
+  SHINE_HIP_CHECK(hipGetLastError());
+  SHINE_HIP_CHECK(prim_sort_pairs_u64(w + 4 * ab, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0u, end_bit, st));
+  hipLaunchKernelGGL(k_sweep_members, dim3((unsigned)((kept + 255) / 256)), dim3(256), 0, st, v1, kept, (int*)idx_out);
+  SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
 }
 
 extern "C" int shine_importance_sweep_sizes(int32_t n_levels, const int64_t* rows, int32_t n_chunks, int64_t max_chunk,

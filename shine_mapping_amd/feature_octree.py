@@ -143,6 +143,7 @@ class FeatureOctree(nn.Module):
         # device growth (shine_tables_grow): per level the (node keys, corner ids, new corner keys) device tensors of
         # every frame, not yet merged into the host copies above (_sync_host does that when a host view is needed)
         self._dev_log = [[] for _ in range(L)]
+        self._dev_frames = []  # (flat copy, fresh counts, added counts) per frame, not yet split into _dev_log
         self._corners_on_device = False  # the handle's corner tables hold every corner of every level
         self._box = None  # running (lo, hi) of the coarsest featured level's node coords, for _sort_box
         self._box_pending = []  # device tensors of coarse node keys not yet folded into _box
@@ -335,31 +336,77 @@ class FeatureOctree(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.shine_tables_grow(t.handle, C.byref(cfg), pts.data_ptr(), pts.shape[0], fresh, added, stream),
                    "shine_tables_grow")
-        grew = False
-        for s in range(L):
-            nf, na = int(fresh[s]), int(added[s])
-            if nf == 0:
-                continue  # :129-130
-            grew = True
-            keys = torch.empty(nf, dtype=torch.int64, device=dev)
-            ids = torch.empty((nf, 8), dtype=torch.int32, device=dev)
-            newc = torch.empty(na, dtype=torch.int64, device=dev)
-            _lib.check(lib.shine_tables_grow_fetch(t.handle, s, keys.data_ptr(), ids.data_ptr(), newc.data_ptr(),
-                                                   stream), "shine_tables_grow_fetch")
-            self._dev_log[s].append((keys, ids, newc))
-            first = self._corner_count[s] == 0
-            self._corner_count[s] += na
-            if s == 0:
-                self._box_pending.append(keys)  # (the sort box is derived lazily: no host read per frame)
-                self._sort_box_cache = None
-            self._append_rows(s, first, na, incremental_on, dev)
-        if grew:
-            self._dict_cache = None
-            self._ranks_uploaded = False
-            self._tables_epoch += 1
+        nf, na = [int(v) for v in fresh], [int(v) for v in added]
+        grown = [s for s in range(L) if nf[s]]  # (a level without new nodes has no new corners: :129-130)
+        if not grown:
+            return
+        # what the device added — node keys, corner ids, new corner keys of every level — in ONE copy; it is split per level
+        # only when a host view is asked for (_drain_dev_frames)
+        words = sum(5 * nf[s] + na[s] for s in range(L))
+        flat = torch.empty(words, dtype=torch.int64, device=dev)
+        _lib.check(lib.shine_tables_grow_fetch_all(t.handle, flat.data_ptr(), words, stream), "shine_tables_grow_fetch_all")
+        self._dev_frames.append((flat, nf, na))
+        self._sort_box_cache = None
+        first = [self._corner_count[s] == 0 for s in range(L)]
+        for s in grown:
+            self._corner_count[s] += na[s]
+        if any(first[s] for s in grown):  # (the first frame: torch, level by level — the order of the random draws is the loop's)
+            for s in grown:
+                self._append_rows(s, first[s], na[s], incremental_on, dev)
+        else:
+            self._append_rows_fused(grown, [na[s] for s in grown], incremental_on, dev, stream)
+        self._dict_cache = None
+        self._ranks_uploaded = False
+        self._tables_epoch += 1
+
+    def _append_rows_fused(self, levels, added, incremental_on, dev, stream):
+        """_append_rows' second branch (:147-160) for all levels that grew, ONE launch (shine_append_rows): the random rows come
+        from torch.randn, level by level in the order the loop above would draw them — the generator's stream is the
+        reference's."""
+        lib = _lib.lib()
+        n = len(levels)
+        old = [self.hier_features[s].detach() for s in levels]
+        noise = [torch.randn(a + 1, self.feature_dim, device=dev) for a in added]
+        new = [torch.empty(o.shape[0] + a, self.feature_dim, device=dev) for o, a in zip(old, added)]
+        if incremental_on:
+            old_imp = [self.importance_weight[s] for s in levels]
+            imp = [torch.empty_like(f) for f in new]
+        _lib.check(lib.shine_append_rows(
+            n, _lib.ptr_array([o.data_ptr() for o in old]),
+            _lib.ptr_array([o.data_ptr() for o in old_imp]) if incremental_on else None,
+            _lib.ptr_array([r.data_ptr() for r in noise]), _lib.i64_array([o.shape[0] - 1 for o in old]),
+            _lib.i64_array(added), float(self.feature_std), _lib.ptr_array([f.data_ptr() for f in new]),
+            _lib.ptr_array([w.data_ptr() for w in imp]) if incremental_on else None, None, stream), "shine_append_rows")
+        for k, s in enumerate(levels):
+            self.hier_features[s] = nn.Parameter(new[k])
+            if incremental_on:
+                self.importance_weight[s] = imp[k]
+                # the reference clones the Parameter itself (attached to the graph, :160): the regulariser then adds to the
+                # loss value but its gradient cancels.  Kept, as a torch clone — cal_regularization below differentiates
+                # through it (SURVEY §8b quirk)
+                self.features_last_frame[s] = self.hier_features[s].clone()
+                self._reg_grad_on[s] = False
+
+    def _drain_dev_frames(self):
+        """Split the frames' flat copies (shine_tables_grow_fetch_all) into the per-level logs _sync_host / _sort_box read."""
+        frames, self._dev_frames = getattr(self, "_dev_frames", None) or [], []
+        for flat, nf, na in frames:
+            off = 0
+            for s in range(self.featured_level_num):
+                keys = flat[off:off + nf[s]]
+                off += nf[s]
+                ids = flat[off:off + 4 * nf[s]].view(torch.int32).view(nf[s], 8)
+                off += 4 * nf[s]
+                newc = flat[off:off + na[s]]
+                off += na[s]
+                if nf[s]:
+                    self._dev_log[s].append((keys, ids, newc))
+                    if s == 0:
+                        self._box_pending.append(keys)  # (the sort box is derived lazily: no host read per frame)
 
     def _sync_host(self):
         """Merge what the device added (shine_tables_grow) into the host copies the dict views / pickles read."""
+        self._drain_dev_frames()
         if not any(self._dev_log):
             return
         for s in range(self.featured_level_num):
@@ -470,6 +517,7 @@ class FeatureOctree(nn.Module):
     def _sort_box(self):
         """Leaf-level voxel bounding box of the map (from the coarsest featured level's nodes, tracked as the tree
         grows): lets shine_morton_sort use bx+by+bz-bit keys instead of 3*tree_level_world."""
+        self._drain_dev_frames()
         if self._box_pending:  # coarse node keys the device added since the box was last read: one host read, on demand
             pend, self._box_pending = self._box_pending, []
             for keys in pend:
@@ -575,6 +623,7 @@ class FeatureOctree(nn.Module):
         state["_dict_cache"] = None
         state["_pending"] = None
         state["_dev_log"] = None
+        state["_dev_frames"] = None
         state.pop("_feat_list", None)
         return state
 
@@ -609,6 +658,7 @@ class FeatureOctree(nn.Module):
         self._tables_epoch = 0
         self._pending = [[] for _ in range(L)]
         self._dev_log = [[] for _ in range(L)]
+        self._dev_frames = []
         self._corners_on_device = False
         # features_last_frame as pickled are plain tensors: the attached-clone quirk (:160) does not survive a pickle
         self._reg_grad_on = [True] * L
@@ -623,9 +673,10 @@ class FeatureOctree(nn.Module):
     def rebuild_device_tables(self):
         """Drop the library handle; it is re-created from the host copies at the next query / device update
         (after unpickling, a device move, or a host-side update that follows device-side ones)."""
-        if getattr(self, "_dev_log", None):
+        if getattr(self, "_dev_log", None) or getattr(self, "_dev_frames", None):
             self._sync_host()
         self._dev_log = [[] for _ in range(self.featured_level_num)]
+        self._dev_frames = []
         self._corners_on_device = False
         if getattr(self, "_box_pending", None) is None:  # (pickles written before the box became lazy)
             self._box_pending = []
@@ -645,6 +696,7 @@ class FeatureOctree(nn.Module):
         self._dict_cache = None
         self._sort_box_cache = None
         self._dev_log = [[] for _ in range(self.featured_level_num)]
+        self._dev_frames = []
         self._box = None
         self._box_pending = []
         for s, (keys, ids) in enumerate(tables):

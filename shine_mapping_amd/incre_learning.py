@@ -29,7 +29,7 @@ def _zero_scratch(dev, nbytes):
 
 
 def chunk_partition(perm, sample_count, batch_interval, down_rate):
-    """The reference's chunks (pool[head:tail:down_rate] for head = n * batch_interval, utils/incre_learning.py:27-31) as
+    """(torch form of shine_importance_chunks, kept as its cross-check in the tests.)  The reference's chunks (pool[head:tail:down_rate] for head = n * batch_interval, utils/incre_learning.py:27-31) as
     segments of node-ordered positions: perm[j] is the pool index of sorted position j.  Returns (idx int32 [kept],
     begin list[iter_n + 1]): chunk n = idx[begin[n]:begin[n+1]], ascending (= node order) inside a chunk."""
     iter_n = math.ceil(sample_count / batch_interval)
@@ -77,8 +77,19 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
         p = perm.long()
         coord_s = octree._check_coord(coord_pool)[p].contiguous()
         label_s = label_pool[p].contiguous()
-    idx, begin = chunk_partition(perm, sample_count, batch_interval, down_rate)
-    max_chunk = max(b - a for a, b in zip(begin[:-1], begin[1:]))
+    perm = perm.to(torch.int32).contiguous()
+    lib = _lib.lib()
+    # the chunks as segments of node-ordered positions: one radix pass over the chunk ids (csrc/shine_sweep.hip)
+    idx = torch.empty(sample_count, dtype=torch.int32, device=dev)
+    begin = (C.c_int64 * (iter_n + 1))()
+    need = C.c_size_t()
+    _lib.check(lib.shine_importance_chunks(None, sample_count, bs, down_rate, None, None, iter_n, None, C.byref(need), None),
+               "shine_importance_chunks")
+    part_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    _lib.check(lib.shine_importance_chunks(perm.data_ptr(), sample_count, bs, down_rate, idx.data_ptr(), begin, iter_n,
+                                           part_ws.data_ptr(), C.byref(need), _lib.current_stream_handle()),
+               "shine_importance_chunks")
+    max_chunk = max(begin[c + 1] - begin[c] for c in range(iter_n))
     opts = StepOptions(sigma=float(sigma), loss_reduction=loss_reduction, decoder_grad_on=False)
     cfg = octree.step_config(sigma=float(sigma), weight_e=0.0, eikonal_on=0,
                              reduction_sum=1 if loss_reduction == "sum" else 0, decoder_grad_on=0, sorted_input=2,
@@ -87,7 +98,6 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
     # the reference's post-condition (:38): the features' .grad are zero tensors (the chunks' gradients themselves live in the
     # sweep's scratch, not here)
     torch._foreach_zero_([_dense_grad(f) for f in octree.hier_features])
-    lib = _lib.lib()
     rows = octree.row_counts()
     group, scratch_bytes, ws_bytes = C.c_int32(), C.c_size_t(), C.c_size_t()
     _lib.check(lib.shine_importance_sweep_sizes(len(octree.hier_features), rows, iter_n, max_chunk, SCRATCH_BUDGET_BYTES,
@@ -98,7 +108,7 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
     _lib.check(
         lib.shine_importance_sweep(
             t.handle, C.byref(cfg), coord_s.data_ptr(), label_s.data_ptr(), None, idx.data_ptr(), slots.data_ptr(),
-            _lib.i64_array(begin), iter_n, octree.feature_ptrs(), rows,
+            begin, iter_n, octree.feature_ptrs(), rows,
             _lib.ptr_array([q.data_ptr() for q in mlp.fused_params()]),
             _lib.ptr_array([w.data_ptr() for w in octree.importance_weight]), group.value, scratch.data_ptr(),
             scratch.numel(), ws.data_ptr(), ws.numel(), _lib.current_stream_handle()),

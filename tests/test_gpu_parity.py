@@ -416,6 +416,103 @@ def test_fused_regulariser_and_importance_sweep_match_reference():
         assert float(a[-1].abs().max()) == 0.0
 
 
+def test_device_update_appends_rows_like_the_torch_loop():
+    """FeatureOctree.update on the device, second and later frames: the feature-side appends of all levels are ONE launch
+    (shine_append_rows) and what the device added is fetched in ONE copy (shine_tables_grow_fetch_all) — against the per-level
+    torch form of the same update (model/feature_octree.py:147-160) on the same generator state and the per-level fetch."""
+    import ctypes as C
+
+    from shine_mapping_amd import FeatureOctree, _lib, synth
+
+    fx = load_golden("ncd_reg_L3")
+    cfg = synth.make_config("maicity", device="cuda", **fx["cfg"])
+    frames = [sp.cuda() for sp in fx["surface_points"]]
+    assert len(frames) >= 2
+    frames = frames + [frames[-1] * 0.97 + 0.011]  # one more frame that certainly adds nodes
+
+    def run(fused):
+        torch.manual_seed(11)
+        octree = FeatureOctree(cfg)
+        if not fused:  # the torch form, level by level
+            octree._append_rows_fused = lambda levels, added, inc, dev, stream: [
+                octree._append_rows(s, False, a, inc, dev) for s, a in zip(levels, added)]
+        logs = []
+        for f in frames:
+            octree.update(f, incremental_on=True)
+            # the per-level fetch of what this frame added, for comparison with the flat copy
+            t = octree._tables
+            _, nf, na = octree._dev_frames[-1]
+            per_level = []
+            for s in range(octree.featured_level_num):
+                keys = torch.empty(nf[s], dtype=torch.int64, device="cuda")
+                ids = torch.empty((nf[s], 8), dtype=torch.int32, device="cuda")
+                newc = torch.empty(na[s], dtype=torch.int64, device="cuda")
+                if nf[s]:
+                    _lib.check(_lib.lib().shine_tables_grow_fetch(t.handle, s, keys.data_ptr(), ids.data_ptr(), newc.data_ptr(),
+                                                                   _lib.current_stream_handle()), "fetch")
+                per_level.append((keys, ids, newc))
+            logs.append(per_level)
+            with torch.no_grad():  # something for importance / last-frame copies to carry over
+                for w in octree.importance_weight:
+                    w[:-1] += 0.25
+        torch.cuda.synchronize()
+        return octree, logs
+
+    a, logs = run(True)
+    b, _ = run(False)
+    for x, y in zip(a.hier_features, b.hier_features):
+        assert x.shape == y.shape and torch.equal(x.detach(), y.detach()) and float(x[-1].abs().max()) == 0.0
+    for x, y in zip(a.importance_weight, b.importance_weight):
+        assert torch.equal(x, y)
+    for x, y in zip(a.features_last_frame, b.features_last_frame):
+        assert torch.equal(x.detach(), y.detach())
+    assert all(t.grad_fn is not None for t in a.features_last_frame)  # the reference's attached clone (:160)
+    assert a._reg_grad_on == b._reg_grad_on
+    # the flat copies, split per level, are the per-level fetches
+    frames_flat = list(a._dev_frames)
+    a._drain_dev_frames()
+    assert len(frames_flat) == len(logs)
+    for s in range(a.featured_level_num):
+        got = a._dev_log[s]
+        want = [lv[s] for lv in logs if lv[s][0].numel()]
+        assert len(got) == len(want)
+        for (k1, i1, c1), (k2, i2, c2) in zip(got, want):
+            assert torch.equal(k1, k2) and torch.equal(i1, i2) and torch.equal(c1, c2)
+
+
+@pytest.mark.parametrize("n,bs,down_rate", [(1, 4, 1), (1000, 64, 1), (1001, 100, 3), (70000, 4096, 2), (4096, 4096, 1),
+                                            (300001, 512, 5)])
+def test_importance_chunks_match_the_torch_partition(n, bs, down_rate):
+    """shine_importance_chunks (one radix pass over the chunk ids) == the torch form of the same partition: members of chunk c =
+    pool[c * bs * down_rate : (c + 1) * bs * down_rate : down_rate] (utils/incre_learning.py:27-31), as ascending sorted positions."""
+    import ctypes as C
+    import math
+
+    from shine_mapping_amd import _lib
+    from shine_mapping_amd.incre_learning import chunk_partition
+
+    g = torch.Generator().manual_seed(n)
+    perm = torch.randperm(n, generator=g).to(torch.int32).cuda()
+    interval = bs * down_rate
+    iter_n = math.ceil(n / interval)
+    want_idx, want_begin = chunk_partition(perm, n, interval, down_rate)
+    lib = _lib.lib()
+    idx = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    begin = (C.c_int64 * (iter_n + 1))()
+    need = C.c_size_t()
+    _lib.check(lib.shine_importance_chunks(None, n, bs, down_rate, None, None, iter_n, None, C.byref(need), None), "sizes")
+    ws = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.shine_importance_chunks(perm.data_ptr(), n, bs, down_rate, idx.data_ptr(), begin, iter_n, ws.data_ptr(),
+                                           C.byref(need), _lib.current_stream_handle()), "shine_importance_chunks")
+    torch.cuda.synchronize()
+    assert list(begin) == want_begin
+    kept = want_begin[-1]
+    assert torch.equal(idx[:kept], want_idx[:kept])
+    assert bool((idx[kept:] == -7).all())  # nothing is written behind the kept samples
+    assert lib.shine_importance_chunks(perm.data_ptr(), n, bs, down_rate, idx.data_ptr(), begin, iter_n + 1, ws.data_ptr(),
+                                       C.byref(need), None) == -1
+
+
 @pytest.mark.parametrize("reduction,bs,down_rate,take,budget", [
     ("mean", 100, 3, 1001, None), ("sum", 4096, 1, 700, None), ("mean", 64, 2, 1024, None),
     ("mean", 8, 2, 1024, None),   # 64 chunks: two launches of 32
@@ -924,7 +1021,7 @@ def test_device_octree_build_matches_reference_tables(name):
     octree = FeatureOctree(cfg)
     for sp in fx["surface_points"]:
         octree.update(sp.cuda(), incremental_on=bool(fx["regularize"]))
-    assert any(octree._dev_log), "CUDA points must take the device path"
+    assert octree._dev_frames, "CUDA points must take the device path"
     idx = octree.get_indices(fx["coord"].cuda())  # straight through the device tables, before any host sync
     for k, r in enumerate(fx["out"]["indices"]):
         assert torch.equal(idx[k].cpu(), r)
