@@ -285,10 +285,10 @@ int shine_append_rows(int32_t n_levels, const float* const* old_feat, const floa
  *      pool) stored chunk after chunk; chunk_begin: HOST int64[n_chunks + 1] offsets into idx.  Per chunk: the fused step
  *      with inv_n = 1 / chunk size (or 1 under reduction_sum) into the chunk's OWN gradient tables (the reference sums a
  *      chunk's gradient before the abs, :36-38), then importance[s] += |that gradient| for every level, chunk after chunk,
- *      importance[s][trash row] = 0.  `group` chunks (1..32) are ONE launch of the step and one launch that folds their
+ *      importance[s][trash row] = 0.  `group` chunks (1..64) are ONE launch of the step and one launch that folds their
  *      tables into importance: scratch = zeroed device memory for `group` sets of {gradient tables, one flag byte per row}
  *      — zero on entry, zero again on return, so it can be kept and re-used — workspace = the steps' partial vectors;
- *      shine_importance_sweep_sizes gives group (32, fewer chunks, or what fits budget_bytes of scratch; 0 = no budget) and both
+ *      shine_importance_sweep_sizes gives group (64, fewer chunks, or what fits budget_bytes of scratch; 0 = no budget) and both
  *      sizes.  Like the query_feature of every chunk (set_zero, model/feature_octree.py:78-81,238) the call re-zeroes the
  *      trash row of every feats[s] — the one write through the `feats` pointers. */
 /*      shine_importance_chunks = the chunks of that loop (chunk c = pool[c * bs * down_rate : (c + 1) * bs * down_rate :

@@ -4,7 +4,7 @@
 // |hier_features[i].grad| to importance_weight[i] (:27-40): the gradient is summed over a chunk BEFORE the abs, so the chunks
 // cannot share a gradient table.  Rounds 2-3 ran the chunk loop on this side of the ABI as {fused step, epilogue} per chunk:
 // 35-70 chunks x 2 small launches, 0.69 ms of a 3.3 ms frame at the incremental configuration, each launch using a quarter of
-// the chip.  Here a GROUP of chunks is one launch: workgroup b of the grid works on chunk b / bpc as workgroup b % bpc of that
+// the chip.  Here a GROUP of chunks (up to 64) is one launch: workgroup b of the grid works on chunk b / bpc as workgroup b % bpc of that
 // chunk's step (the SLICED build of the step body: own sample range, own normaliser — sdf_bce_loss 'mean' divides by the
 // chunk's size — own gradient tables and touched-row flags), and ONE epilogue launch per group folds the group's tables into
 // importance_weight, visiting only the rows a chunk flagged, and leaves tables and flags zero for the next group.
@@ -35,57 +35,46 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void 
 }
 
 // importance_weight[s] += sum over the group's chunks of |chunk gradient| on the rows a chunk flagged; tables and flags are
-// left zero.  One thread per 4 rows (their 4 flag bytes are one load per chunk); blockIdx.y = level.  The order of the
-// chunks in a row's sum is the chunk order, as in the reference's loop.
+// left zero.  One thread per row: the group's flag bytes of the row are all requested at once (unrolled, branch-free) and
+// folded into a 64-bit chunk mask; the flagged chunks' rows are then added in chunk order, as the reference's loop does.
+// blockIdx.y = level.
 __global__ __launch_bounds__(256) void k_sweep_fold(SweepFoldArgs a) {
   const int s = blockIdx.y;
-  const long long rows = a.rows[s];       // without the trash row
-  const long long quads = (rows + 4) / 4;  // rows + 1 entries, 4 per thread
+  const long long rows = a.rows[s];  // without the trash row
   float4* const imp = a.imp[s];
-  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long long)gridDim.x * 256) {
-    unsigned int by_row[4] = {0u, 0u, 0u, 0u};  // bit c: chunk c flagged row 4 q + k
-    unsigned int by_chunk = 0u;
-    for (int c = 0; c < a.chunks; ++c) {
-      const unsigned int f = reinterpret_cast<const unsigned int*>(a.flags[s] + (long long)c * a.flag_stride)[q];
-      if (f) {
-        by_chunk |= 1u << c;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) by_row[k] |= ((f >> (8 * k)) & 0xffu) ? 1u << c : 0u;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      unsigned int m = by_row[k];
-      if (!m) continue;
-      const long long r = 4 * q + k;  // (a flagged row is a real row: r < rows)
-      float4 v0 = imp[2 * r], v1 = imp[2 * r + 1];
-      while (m) {
-        const int c = __builtin_ctz(m);
-        m &= m - 1;
-        float4* g = reinterpret_cast<float4*>(a.grad[s] + (long long)c * a.grad_stride) + 2 * r;
-        const float4 g0 = g[0], g1 = g[1];
-        g[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        g[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        v0.x += fabsf(g0.x), v0.y += fabsf(g0.y), v0.z += fabsf(g0.z), v0.w += fabsf(g0.w);
-        v1.x += fabsf(g1.x), v1.y += fabsf(g1.y), v1.z += fabsf(g1.z), v1.w += fabsf(g1.w);
-      }
-      imp[2 * r] = v0;
-      imp[2 * r + 1] = v1;
-    }
-    while (by_chunk) {
-      const int c = __builtin_ctz(by_chunk);
-      by_chunk &= by_chunk - 1;
-      reinterpret_cast<unsigned int*>(a.flags[s] + (long long)c * a.flag_stride)[q] = 0u;
-    }
-    if (4 * q <= rows && rows < 4 * q + 4) {
+  const unsigned char* const flags = a.flags[s];
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r <= rows; r += (long long)gridDim.x * 256) {
+    if (r == rows) {
       // the trash row: importance_weight[i][-1] *= 0 (utils/incre_learning.py:40), and FeatureOctree.set_zero
       // (model/feature_octree.py:78-81) — every chunk's query_feature zeroes the features' trash row, which holds the last Adam
       // step's move after the training iterations (the fused step itself never reads it)
-      imp[2 * rows] = make_float4(0.f, 0.f, 0.f, 0.f);
-      imp[2 * rows + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      a.feat[s][2 * rows] = make_float4(0.f, 0.f, 0.f, 0.f);
-      a.feat[s][2 * rows + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      imp[2 * r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      imp[2 * r + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a.feat[s][2 * r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a.feat[s][2 * r + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
     }
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int c = 0; c < SWEEP_GROUP; ++c) {
+      const unsigned char f = c < a.chunks ? flags[(long long)c * a.flag_stride + r] : (unsigned char)0;
+      m |= f ? 1ull << c : 0ull;
+    }
+    if (!m) continue;
+    float4 v0 = imp[2 * r], v1 = imp[2 * r + 1];
+    while (m) {
+      const int c = __builtin_ctzll(m);
+      m &= m - 1;
+      float4* g = reinterpret_cast<float4*>(a.grad[s] + (long long)c * a.grad_stride) + 2 * r;
+      const float4 g0 = g[0], g1 = g[1];
+      g[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      g[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      v0.x += fabsf(g0.x), v0.y += fabsf(g0.y), v0.z += fabsf(g0.z), v0.w += fabsf(g0.w);
+      v1.x += fabsf(g1.x), v1.y += fabsf(g1.y), v1.z += fabsf(g1.z), v1.w += fabsf(g1.w);
+      const_cast<unsigned char*>(flags)[(long long)c * a.flag_stride + r] = 0;
+    }
+    imp[2 * r] = v0;
+    imp[2 * r + 1] = v1;
   }
 }
 
@@ -211,7 +200,7 @@ extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_co
   if (L < 1 || L > LCAP) return set_error(SHINE_E_INVALID, "shine_importance_sweep: bad level count");
   if (cfg->sorted_input != 2 || cfg->eikonal_on || cfg->decoder_grad_on)
     return set_error(SHINE_E_INVALID, "shine_importance_sweep: wants a pool-mode config, BCE only, decoder frozen");
-  if (group < 1 || group > SWEEP_GROUP) return set_error(SHINE_E_INVALID, "shine_importance_sweep: 1 <= group <= 32");
+  if (group < 1 || group > SWEEP_GROUP) return set_error(SHINE_E_INVALID, "shine_importance_sweep: 1 <= group <= 64");
   size_t gf, fb;
   sweep_layout(rows, L, &gf, &fb);
   if (scratch_bytes < (size_t)group * (gf * sizeof(float) + fb) || ((size_t)scratch & 15))
@@ -274,10 +263,10 @@ extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_co
     return set_error(SHINE_E_INVALID, "shine_importance_sweep: workspace too small (shine_importance_sweep_sizes)");
   const void* fn = g.wg_waves == V3_BIG ? sweep_fn<V3_BIG>(L) : sweep_fn<4>(L);
 
-  long long max_quads = 0;
-  for (int s = 0; s < L; ++s) max_quads = std::max(max_quads, (long long)(rows[s] + 4) / 4);
-  long long fold_blocks = (max_quads + 255) / 256;
-  if (fold_blocks > 2048) fold_blocks = 2048;
+  long long max_rows = 0;
+  for (int s = 0; s < L; ++s) max_rows = std::max(max_rows, (long long)rows[s] + 1);
+  long long fold_blocks = (max_rows + 255) / 256;
+  if (fold_blocks > 4096) fold_blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
   for (int c0 = 0; c0 < n_chunks; c0 += group) {
     const int nc = n_chunks - c0 < group ? n_chunks - c0 : group;

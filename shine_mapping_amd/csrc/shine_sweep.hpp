@@ -4,7 +4,7 @@
 
 namespace shine {
 
-constexpr int SWEEP_GROUP = 32;  // chunks of one launch (their private gradient tables live side by side in the scratch)
+constexpr int SWEEP_GROUP = 64;  // chunks of one launch (their private gradient tables live side by side in the scratch)
 
 struct SweepArgs {
   V1Args a;                         // what all chunks share; a.lv[].grad / a.touched[] = the FIRST chunk's tables / flags

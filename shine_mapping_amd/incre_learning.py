@@ -2,7 +2,7 @@
 
 Per chunk of the frame's pool the reference runs query + decode + BCE + backward and then
 ``importance_weight[i] += hier_features[i].grad.abs(); grad.zero_(); importance_weight[i][-1] *= 0``.
-Here the forward+backward of up to 32 chunks is ONE launch of the fused step with the decoder frozen (every chunk with its own
+Here the forward+backward of up to 64 chunks is ONE launch of the fused step with the decoder frozen (every chunk with its own
 gradient tables: a chunk's gradient is summed before the abs) and one more launch folds them into importance_weight
 (csrc/shine_sweep.hip).
 """

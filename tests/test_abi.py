@@ -79,12 +79,12 @@ def test_argument_checks_of_the_per_iteration_entry_points():
     assert lib.shine_importance_chunks(None, 1000, 64, 2, None, None, 8, None, C.byref(need), None) == 0 and need.value >= 4 * 8000
     assert lib.shine_importance_chunks(None, 1000, 64, 2, None, None, 7, None, C.byref(need), None) == -1  # ceil(1000 / 128) = 8
     assert lib.shine_importance_chunks(None, 1000, 0, 2, None, None, 8, None, C.byref(need), None) == -1
-    # the sweep's sizes: 32 chunks per launch at most, fewer under a scratch budget, never less than one
+    # the sweep's sizes: 64 chunks per launch at most, fewer under a scratch budget, never less than one
     rows3 = (C.c_int64 * 3)(1000, 5000, 20000)
     group, sb, wb = C.c_int32(), C.c_size_t(), C.c_size_t()
     per_chunk = sum((r + 1) * 32 + ((r + 1 + 15) & ~15) for r in rows3)
-    assert lib.shine_importance_sweep_sizes(3, rows3, 50, 4096, 0, C.byref(group), C.byref(sb), C.byref(wb)) == 0
-    assert group.value == 32 and sb.value == 32 * per_chunk and wb.value > 0
+    assert lib.shine_importance_sweep_sizes(3, rows3, 150, 4096, 0, C.byref(group), C.byref(sb), C.byref(wb)) == 0
+    assert group.value == 64 and sb.value == 64 * per_chunk and wb.value > 0
     assert lib.shine_importance_sweep_sizes(3, rows3, 5, 4096, 0, C.byref(group), C.byref(sb), C.byref(wb)) == 0
     assert group.value == 5 and sb.value == 5 * per_chunk
     assert lib.shine_importance_sweep_sizes(3, rows3, 50, 4096, 3 * per_chunk + 7, C.byref(group), C.byref(sb), C.byref(wb)) == 0

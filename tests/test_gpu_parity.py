@@ -515,14 +515,14 @@ def test_importance_chunks_match_the_torch_partition(n, bs, down_rate):
 
 @pytest.mark.parametrize("reduction,bs,down_rate,take,budget", [
     ("mean", 100, 3, 1001, None), ("sum", 4096, 1, 700, None), ("mean", 64, 2, 1024, None),
-    ("mean", 8, 2, 1024, None),   # 64 chunks: two launches of 32
+    ("mean", 4, 2, 1024, None),   # 128 chunks: two launches of 64
     ("sum", 64, 1, 1000, 3.5),    # a scratch budget of 3.5 chunks' tables: 16 chunks in groups of 3 (the last group has one)
     ("mean", 50, 1, 1000, 0.5)])  # less than one chunk's tables: one chunk per launch
 def test_importance_sweep_chunking_matches_oracle(reduction, bs, down_rate, take, budget, monkeypatch):
     """cal_feature_importance's chunk loop runs behind the ABI (shine_importance_sweep): a chunk's gradient is summed
     before the abs, so chunk MEMBERSHIP (head:tail:down_rate of the pool in its original order, a short last chunk, one
     chunk larger than the pool) must be the reference's — utils/incre_learning.py:27-40 — as must the per-chunk 'mean'.
-    Up to 32 chunks are ONE launch (each with its own gradient tables in the sweep's scratch); more chunks, or a scratch
+    Up to 64 chunks are ONE launch (each with its own gradient tables in the sweep's scratch); more chunks, or a scratch
     budget that holds fewer tables, take several."""
     import copy
 
