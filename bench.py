@@ -53,6 +53,8 @@ L2_PEAK_GBS = 34500.0      # aggregate L2
 MFMA_F32_PEAK_TF = 157.3   # exact-fp32 MFMA = the fp32 vector rate: 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
 PEAK_CLOCK_GHZ = 2.4
 N_SIMD = 1024
+L2_ATOMICS_PER_NS = 160.0  # global_atomic_add_f32 lanes per ns, chip-wide, 8 rows x 32 B per wave instruction (measured:
+                           # tools/ubench/atomics_rows.hip, 51-53 us for 131072 wave instructions whatever the address pattern)
 MFMA16_CYCLES = 32.0       # v_mfma_f32_16x16x4_f32 issue interval per SIMD (guide, per-instruction constants)
 # fp32-datapath cycles of one plain VALU wave-instruction.  The guide's SIMD-32 figure is 2; tools/ubench/mfma_valu_overlap
 # (profiles/r03_ubench_calibration.txt) measures 5.0 for ONE wave per SIMD issuing independent v_fma_f32 (mode 5) and 2.52
@@ -424,6 +426,14 @@ def kernel_roofline(workload, octree, decoder, cfg, spool, points, n_surf_fn, la
     useful_tf = points * info["useful_flop_per_point"] / t / 1e12
     rows = [int(p.shape[0]) for p in octree.hier_features]
     table_bytes = sum(rows) * 32
+    # the feature-grad atomics of this launch, counted from the batch itself: one 64-lane global_atomic_add_f32 per node run of
+    # the ordered stream and level (a run = consecutive samples in the same node; misses issue none)
+    sl = spool.slots[idx0.long()]
+    hit = sl >= 0
+    first = torch.ones_like(hit)
+    first[1:] = sl[1:] != sl[:-1]
+    node_runs = int((first & hit).sum())
+    atomics_us = node_runs * 64 / (L2_ATOMICS_PER_NS * 1e3)
     pmc, pmc_note = pmc_record(workload, points, levels)
     ctr = pmc.get("counters_per_launch", {}) if pmc else {}
     traffic = float(pmc["hbm_bytes_per_launch"]) if pmc and pmc.get("hbm_bytes_per_launch") else None
@@ -463,6 +473,12 @@ def kernel_roofline(workload, octree, decoder, cfg, spool, points, n_surf_fn, la
                      "frac_at_measured_clock": None if not clk else dp_cycles / (clk * N_SIMD),
                      "mfma_issued_tflops": issued_tf, "mfma_issued_frac": issued_tf / MFMA_F32_PEAK_TF,
                      "mfma_useful_frac": useful_tf / MFMA_F32_PEAK_TF, "mfma_busy_pmc": pmc.get("mfma_util") if pmc else None},
+        "l2_atomics": {"node_runs": node_runs, "fp32_atomics": node_runs * 64, "rate_per_ns": L2_ATOMICS_PER_NS,
+                       "floor_ms": atomics_us * 1e-3, "frac_of_kernel_time": atomics_us * 1e-3 / kernel_ms,
+                       "note": "the launch's feature-grad atomics at the chip's measured rate for this shape (8 rows x 32 B per "
+                               "wave instruction: tools/ubench/atomics_rows.hip, profiles/r04_ubench_atomics_rows.txt): the "
+                               "time the L2's atomic units are busy, hidden under the kernel's other work or not "
+                               "(profiles/r04_ab_experiments.txt block 10)"},
         "wave_cycle_split": None if not pmc else pmc.get("wave_cycle_split"),
         "launch_geometry": {k: info[k] for k in ("workgroups", "waves", "tile_points", "lds_bytes")},
         "pmc": {"used": pmc is not None, "note": pmc_note, "source": None if pmc is None else pmc.get("source")},
