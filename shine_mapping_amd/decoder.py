@@ -92,5 +92,9 @@ class Decoder(nn.Module):
         """W1,b1,W2,b2,w3,b3 in the order libshine_hip expects."""
         if not self.fusable:
             raise NotImplementedError("fused HIP decoder supports 8 -> 32 -> 32 -> 1 with bias (every shipped config)")
-        return [self.layers[0].weight, self.layers[0].bias, self.layers[1].weight, self.layers[1].bias,
-                self.lout.weight, self.lout.bias]
+        # (plain dict lookups: nn.Module.__getattr__ / ModuleList.__getitem__ cost ~1 us per hop, and the small-batch loop asks
+        # for these six tensors half a dozen times per iteration)
+        m = self._modules
+        hidden = m["layers"]._modules
+        l0, l1, lo = hidden["0"]._parameters, hidden["1"]._parameters, m["lout"]._parameters
+        return [l0["weight"], l0["bias"], l1["weight"], l1["bias"], lo["weight"], lo["bias"]]

@@ -21,7 +21,12 @@ def ref_get_gradient(inputs, outputs):  # utils/tools.py:175-185
                                only_inputs=True)[0]
 
 
-for kind, lv, n in (("maicity", 3, 4096), ("kitti", 3, 4096), ("maicity", 3, 1 << 16), ("kitti", 3, 1 << 16)):
+if os.environ.get("TIER_A_SINGLE_THREAD_AUTOGRAD"):  # experiment: backward on the calling thread (no hand-over to the device thread)
+    torch.autograd.set_multithreading_enabled(False)
+CASES = (("maicity", 3, 4096), ("kitti", 3, 4096), ("maicity", 3, 1 << 16), ("kitti", 3, 1 << 16))
+if os.environ.get("TIER_A_SMALL"):
+    CASES = CASES[:2]
+for kind, lv, n in CASES:
     wl = synth.build_workload(kind, frames=30, device="cuda", seed=42, tree_level_feat=lv)
     octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
     cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio = True, 1e-15, 1.0
