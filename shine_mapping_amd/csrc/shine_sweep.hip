@@ -97,6 +97,45 @@ __global__ __launch_bounds__(256) void k_sweep_members(const unsigned long long*
   if (k < kept) idx[k] = (int)val[k];
 }
 
+// The same partition without a sort of the pool, for chunks that fit a workgroup's LDS (bs <= 16384: every shipped yaml has 4096):
+// chunk c's members in ORIGINAL pool order are the kept samples p = c * interval + k * down_rate, so sample p's sorted position j
+// goes to slot c * bs + k (k_sweep_place: one scattered store per kept sample) — and a chunk's segment then only has to be sorted
+// ascending, which one workgroup does in LDS (bitonic network over the next power of two, padded with INT_MAX; the positions are
+// distinct).  Two launches instead of the ~20 of a radix / merge sort of (key, value) pairs of the whole pool.
+__global__ __launch_bounds__(256) void k_sweep_place(const int* __restrict__ perm, long long n, long long interval, int down_rate,
+                                                     long long bs, int* __restrict__ idx) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const long long p = perm[j];
+  const long long c = p / interval, off = p - c * interval;
+  if (off % down_rate == 0) idx[c * bs + off / down_rate] = (int)j;
+}
+
+__global__ __launch_bounds__(1024) void k_sweep_sort_chunks(int* __restrict__ idx, long long bs, long long kept, int pow2) {
+  extern __shared__ int s_v[];
+  const long long first = (long long)blockIdx.x * bs;
+  const long long cnt = kept - first < bs ? kept - first : bs;
+  for (int i = threadIdx.x; i < pow2; i += 1024) s_v[i] = i < cnt ? idx[first + i] : 0x7fffffff;
+  __syncthreads();
+  for (int k = 2; k <= pow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < pow2; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const int a = s_v[i], b = s_v[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            s_v[i] = b;
+            s_v[l] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < cnt; i += 1024) idx[first + i] = s_v[i];
+}
+
 template <int WAVES>
 static const void* sweep_fn(int levels) {
   switch (levels) {
@@ -124,7 +163,8 @@ static void sweep_layout(const int64_t* rows, int L, size_t* grad_stride_f, size
 
 // The chunks of cal_feature_importance as segments of a node-ordered pool: perm[j] = pool index of the sample at sorted position
 // j.  idx_out[chunk_begin[c] .. chunk_begin[c + 1]) = the sorted positions of chunk c's members, ascending (= node order inside
-// a chunk): one stable radix pass over the chunk ids.  chunk_begin (HOST, n_chunks + 1 entries) follows from the sizes alone.
+// a chunk).  chunk_begin (HOST, n_chunks + 1 entries) follows from the sizes alone.  bs <= 16384: two launches (place + per-chunk
+// LDS sort); larger chunks: one stable radix pass over the chunk ids.
 extern "C" int shine_importance_chunks(const int32_t* perm, int64_t n, int64_t bs, int32_t down_rate, int32_t* idx_out,
                                        int64_t* chunk_begin, int32_t n_chunks, void* workspace, size_t* workspace_bytes,
                                        void* stream) {
@@ -139,9 +179,10 @@ extern "C" int shine_importance_chunks(const int32_t* perm, int64_t n, int64_t b
   while ((1ll << end_bit) <= (long long)n_chunks) ++end_bit;  // keys 0 .. n_chunks
   const size_t ab = ((size_t)n * 8 + 255) & ~(size_t)255;
   size_t tmp_bytes = 0;
-  SHINE_HIP_CHECK(prim_sort_pairs_u64(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)(n > 0 ? n : 1), 0u,
-                                      end_bit, (hipStream_t)stream));
-  const size_t need = 4 * ab + tmp_bytes;
+  if (bs > SWEEP_SORT_MAX)
+    SHINE_HIP_CHECK(prim_sort_pairs_u64(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)(n > 0 ? n : 1), 0u,
+                                        end_bit, (hipStream_t)stream));
+  const size_t need = bs <= SWEEP_SORT_MAX ? 256 : 4 * ab + tmp_bytes;  // (the two-launch form needs none)
   if (!workspace) {
     *workspace_bytes = need;
     return SHINE_OK;
@@ -156,10 +197,21 @@ extern "C" int shine_importance_chunks(const int32_t* perm, int64_t n, int64_t b
     chunk_begin[c + 1] = kept;
   }
   if (n == 0) return SHINE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (bs <= SWEEP_SORT_MAX) {  // a chunk fits a workgroup's LDS: place, then sort every chunk's segment where it lies
+    int pow2 = 2;
+    while (pow2 < bs) pow2 <<= 1;
+    hipLaunchKernelGGL(k_sweep_place, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, perm, (long long)n, interval,
+                       (int)down_rate, (long long)bs, (int*)idx_out);
+    SHINE_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_sweep_sort_chunks, dim3((unsigned)n_chunks), dim3(1024), (size_t)pow2 * sizeof(int), st, (int*)idx_out,
+                       (long long)bs, kept, pow2);
+    SHINE_HIP_CHECK(hipGetLastError());
+    return SHINE_OK;
+  }
   char* w = (char*)workspace;
   unsigned long long *k0 = (unsigned long long*)w, *k1 = (unsigned long long*)(w + ab);
   unsigned long long *v0 = (unsigned long long*)(w + 2 * ab), *v1 = (unsigned long long*)(w + 3 * ab);
-  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_sweep_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, perm, (long long)n, interval,
                      (int)down_rate, (int)n_chunks, k0, v0);
   SHINE_HIP_CHECK(hipGetLastError());

@@ -6,6 +6,8 @@ namespace shine {
 
 constexpr int SWEEP_GROUP = 64;  // chunks of one launch (their private gradient tables live side by side in the scratch)
 
+constexpr long long SWEEP_SORT_MAX = 16384;  // largest chunk (bs) one workgroup sorts in LDS (64 KB of positions)
+
 struct SweepArgs {
   V1Args a;                         // what all chunks share; a.lv[].grad / a.touched[] = the FIRST chunk's tables / flags
   long long begin[SWEEP_GROUP + 1];  // the group's chunk boundaries in a.perm

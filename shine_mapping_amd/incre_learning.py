@@ -77,19 +77,22 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
         p = perm.long()
         coord_s = octree._check_coord(coord_pool)[p].contiguous()
         label_s = label_pool[p].contiguous()
-    perm = perm.to(torch.int32).contiguous()
     lib = _lib.lib()
-    # the chunks as segments of node-ordered positions: one radix pass over the chunk ids (csrc/shine_sweep.hip)
-    idx = torch.empty(sample_count, dtype=torch.int32, device=dev)
-    begin = (C.c_int64 * (iter_n + 1))()
-    need = C.c_size_t()
-    _lib.check(lib.shine_importance_chunks(None, sample_count, bs, down_rate, None, None, iter_n, None, C.byref(need), None),
-               "shine_importance_chunks")
-    part_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
-    _lib.check(lib.shine_importance_chunks(perm.data_ptr(), sample_count, bs, down_rate, idx.data_ptr(), begin, iter_n,
-                                           part_ws.data_ptr(), C.byref(need), _lib.current_stream_handle()),
-               "shine_importance_chunks")
-    max_chunk = max(begin[c + 1] - begin[c] for c in range(iter_n))
+    if pool is not None:
+        idx, begin, _, max_chunk = pool.importance_chunks(bs, down_rate)  # (cached: a loop may have asked for it already)
+    else:
+        # the chunks as segments of node-ordered positions: one radix pass over the chunk ids (csrc/shine_sweep.hip)
+        perm = perm.to(torch.int32).contiguous()
+        idx = torch.empty(sample_count, dtype=torch.int32, device=dev)
+        begin = (C.c_int64 * (iter_n + 1))()
+        need = C.c_size_t()
+        _lib.check(lib.shine_importance_chunks(None, sample_count, bs, down_rate, None, None, iter_n, None, C.byref(need), None),
+                   "shine_importance_chunks")
+        part_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        _lib.check(lib.shine_importance_chunks(perm.data_ptr(), sample_count, bs, down_rate, idx.data_ptr(), begin, iter_n,
+                                               part_ws.data_ptr(), C.byref(need), _lib.current_stream_handle()),
+                   "shine_importance_chunks")
+        max_chunk = max(begin[c + 1] - begin[c] for c in range(iter_n))
     opts = StepOptions(sigma=float(sigma), loss_reduction=loss_reduction, decoder_grad_on=False)
     cfg = octree.step_config(sigma=float(sigma), weight_e=0.0, eikonal_on=0,
                              reduction_sum=1 if loss_reduction == "sum" else 0, decoder_grad_on=0, sorted_input=2,

@@ -53,6 +53,7 @@ class SortedPool:
         self.sdf_label = sdf_label[p].contiguous()
         self.weight = weight[p].contiguous()
         self._surf_bits = None
+        self._chunks = {}  # (bs, down_rate) -> importance_chunks(...)
         self.slots = slots  # already in pool (= visiting) order
         self.size = int(coord.shape[0])
         self.tables_epoch = self.octree._tables_epoch
@@ -60,6 +61,36 @@ class SortedPool:
         # tables epoch moved); without this an object rebuilt every frame pins one buffer per distinct frame size
         for k in [k for k in self._ws if k[1] != self.size]:
             del self._ws[k]
+
+    def importance_chunks(self, bs, down_rate=1):
+        """The chunks of cal_feature_importance (utils/incre_learning.py:27-31: chunk c = pool[c * bs * down_rate : (c + 1) * bs *
+        down_rate : down_rate] of the ORIGINAL pool order) as segments of this pool's sorted positions: (idx int32 [kept] on the
+        device, begin = host int64[n_chunks + 1], n_chunks, largest chunk).  One radix pass over the chunk ids
+        (shine_importance_chunks); depends on the plan only, so an incremental loop can ask for it right after the pool is
+        built — the device does it while the host prepares the iterations — and incre_learning.cal_feature_importance(pool=...)
+        finds it here."""
+        import ctypes as C
+        import math
+
+        key = (int(bs), int(down_rate))
+        hit = self._chunks.get(key)
+        if hit is not None:
+            return hit
+        n = self.size
+        n_chunks = math.ceil(n / (key[0] * key[1]))
+        lib = _lib.lib()
+        perm = self.perm.to(torch.int32).contiguous()
+        idx = torch.empty(n, dtype=torch.int32, device=perm.device)
+        begin = (C.c_int64 * (n_chunks + 1))()
+        need = C.c_size_t()
+        _lib.check(lib.shine_importance_chunks(None, n, key[0], key[1], None, None, n_chunks, None, C.byref(need), None),
+                   "shine_importance_chunks")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=perm.device)
+        _lib.check(lib.shine_importance_chunks(perm.data_ptr(), n, key[0], key[1], idx.data_ptr(), begin, n_chunks, ws.data_ptr(),
+                                               C.byref(need), _lib.current_stream_handle()), "shine_importance_chunks")
+        largest = max((begin[c + 1] - begin[c] for c in range(n_chunks)), default=0)
+        hit = self._chunks[key] = (idx, begin, n_chunks, largest)
+        return hit
 
     def draw(self, n, out=None, zero=None, graph_safe=False, n_global=None, slice_begin=0, surf_parts=None,
              pass1_done=False):

@@ -481,9 +481,10 @@ def test_device_update_appends_rows_like_the_torch_loop():
 
 
 @pytest.mark.parametrize("n,bs,down_rate", [(1, 4, 1), (1000, 64, 1), (1001, 100, 3), (70000, 4096, 2), (4096, 4096, 1),
-                                            (300001, 512, 5)])
+                                            (300001, 512, 5), (100000, 16384, 1), (100001, 5000, 3),
+                                            (200000, 20000, 2)])  # (the last one: chunks beyond a workgroup's LDS, radix path)
 def test_importance_chunks_match_the_torch_partition(n, bs, down_rate):
-    """shine_importance_chunks (one radix pass over the chunk ids) == the torch form of the same partition: members of chunk c =
+    """shine_importance_chunks (place + per-chunk LDS sort; one radix pass over the chunk ids for bs > 16384) == the torch form of the same partition: members of chunk c =
     pool[c * bs * down_rate : (c + 1) * bs * down_rate : down_rate] (utils/incre_learning.py:27-31), as ascending sorted positions."""
     import ctypes as C
     import math
