@@ -214,6 +214,16 @@ def gpu_iteration_n4096(wl, spool_seed, iters=300, n=4096, active_rows=True):
     opts = StepOptions(sigma=cfg.sigma_sigmoid, loss_reduction=cfg.loss_reduction, ekional_loss_on=cfg.ekional_loss_on,
                        weight_e=cfg.weight_e)
     unroll = 4  # iterations per HIP graph: the graph lives for hundreds of replays here, so its ~8 us boundary gap is worth folding
+    # This leg runs right after the CPU baseline (tens of seconds with an idle GPU): without a stretch of device work in front, its
+    # first window reads the clock ramp (59 instead of 38 us per iteration on one box of the pool).  The stretch must not be
+    # iterations of THIS loop — the active-row tail's time depends on how many it has taken — so it is plain device work.
+    busy = torch.empty(2048, 2048, device=spool.coord.device).normal_()
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.06:
+        for _ in range(20):
+            busy = torch.tanh(busy @ busy * 1e-3)
+        torch.cuda.synchronize()
+    del busy
     it = GraphedIteration(octree, decoder, spool, adam, opts, n, unroll=unroll, active_rows=active_rows)
     it.run(20)
     torch.cuda.synchronize()
