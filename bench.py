@@ -282,20 +282,36 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
 
     gc.collect()
     gc.freeze()
-    # ONE host synchronisation per frame, at its end (the next frame's octree.update reads counts on the host anyway): the phases
-    # of a frame are delimited by events on the stream, so the host prepares the iterations (optimiser state, graph binding)
-    # while the GPU is still growing the tree and planning the pool — as in the reference's loop, which has no synchronisation
-    # between its phases either.  `split` = GPU time between the phase events; `host` = when the host was done issuing a phase.
+    # The phases of a frame are delimited by events on the stream, so the host prepares the iterations (optimiser state, graph
+    # binding) while the GPU is still growing the tree and planning the pool — as in the reference's loop, which has no
+    # synchronisation between its phases either.  `split` = GPU time between the phase events; `host` = when the host was done
+    # issuing a phase.
+    # Default (round 4, second pass): NO synchronisation between frames either.  octree.update() is the one place where the host
+    # reads the device (the counts of new nodes / corners); with FeatureOctree.enable_async_growth() the growth runs on a stream
+    # of its own — it touches the hash tables only, which the queued iterations read through memoised slots — so the host binds
+    # frame k + 1 while the device still trains frame k (two iteration graphs alternate: re-binding one waits for its own last
+    # replay).  --sync-frames: one host synchronisation at the end of every frame (the round-3 form: a frame's latency).
+    pipelined = not args.sync_frames
+    if pipelined:
+        octree.enable_async_growth()
     host = np.zeros((n_frames, 4))
+    evs = []
+    wall = np.zeros(n_frames)
     for fi, (coord, label, weight) in enumerate(frames):
         if fi == warmup:
             torch.cuda.synchronize()
             t_start = time.perf_counter()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        evs.append(ev)
         t0 = time.perf_counter()
         ev[0].record()
-        octree.update(coord[weight > 0], incremental_on=True)
-        octree._require_tables(with_ranks=True)
+        if pipelined:  # (the frame's surface points come from static scan data: selected on the growth's stream, update()'s contract)
+            with torch.cuda.stream(octree.growth_stream):
+                surf = coord[weight > 0]
+        else:
+            surf = coord[weight > 0]
+        octree.update(surf, incremental_on=True)
+        octree._require_tables(with_ranks=True, probe=False)
         ev[1].record()
         t1 = time.perf_counter()
         if fi == 20:  # shine_incre.py:100-104: the decoder is frozen after the first frames
@@ -308,7 +324,7 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
         t2 = time.perf_counter()
         # frame 0: the constructor runs iteration 1 eagerly; later frames capture straight away and replay all of them
         step = GraphedIteration(octree, dec, pool, opt, opts, bs, lambda_forget=cfg.lambda_forget, unroll=args.unroll,
-                                eager_first=fi == 0)
+                                eager_first=fi == 0, graph_slot=fi % 2 if pipelined else 0)
         loss = step.run(iters - 1 if step.ran_eager else iters)
         ev[3].record()
         t3 = time.perf_counter()
@@ -316,12 +332,18 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
         cal_feature_importance(data, octree, dec, cfg.sigma_sigmoid, bs, 2, "sum", pool=pool)  # (re-uses the frame's plan)
         ev[4].record()
         t4h = time.perf_counter()
-        torch.cuda.synchronize()
-        t4 = time.perf_counter()
-        split[fi] = tuple(ev[k].elapsed_time(ev[k + 1]) * 1e-3 for k in range(4)) + (t4 - t0,)
+        if not pipelined:
+            torch.cuda.synchronize()
+        wall[fi] = time.perf_counter() - t0
         host[fi] = (t1 - t0, t2 - t1, t3 - t2, t4h - t3)
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t_start
     gc.unfreeze()
+    for fi, ev in enumerate(evs):
+        # the frame's span: sequential form = the host's clock around the frame; pipelined = from the end of the previous frame's
+        # last kernel to the end of this one's on the stream (the frame PERIOD: frames overlap on the host side)
+        span = wall[fi] if (not pipelined or fi == 0) else evs[fi - 1][4].elapsed_time(ev[4]) * 1e-3
+        split[fi] = tuple(ev[k].elapsed_time(ev[k + 1]) * 1e-3 for k in range(4)) + (span,)
     med = np.median(split[warmup:], axis=0) * 1e3
     wl = type("WL", (), {})()
     wl.cfg, wl.octree, wl.decoder = cfg, octree, dec
@@ -344,8 +366,12 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
         "per_frame_ms_median": {"update+ranks": med[0], "optimiser+pool plan": med[1],
                                 "%d iterations (incl. graph binding)" % iters: med[2], "importance sweep": med[3],
                                 "total": med[4],
-                                "note": "phases: time between events on the stream (the host runs ahead: one synchronisation "
-                                        "per frame, at its end); total: host clock"},
+                                "note": ("phases: time between events on the stream; total: the frame period on the stream (no host "
+                                         "synchronisation between frames: the host binds frame k + 1 while the device trains frame k)"
+                                         if pipelined else
+                                         "phases: time between events on the stream (the host runs ahead: one synchronisation "
+                                         "per frame, at its end); total: host clock")},
+        "frame_sync": not pipelined,
         "per_frame_host_issue_ms_median": dict(zip(("update+ranks", "optimiser+pool plan", "iterations", "importance sweep"),
                                                    [float(x) for x in np.median(host[warmup:], axis=0) * 1e3])),
         "us_per_iteration": med[2] / iters * 1e3,
@@ -991,6 +1017,9 @@ def main():
                          "(two parameter updates per iteration held, on the host's critical path) against ~16 us of idle GPU per "
                          "graph boundary: measured 351 / 390 / 378 frames/s at 2 / 5 / 10 (profiles/r04_ab_experiments.txt "
                          "blocks 3 and 9)")
+    ap.add_argument("--sync-frames", action="store_true",
+                    help="ncd-incre: one host synchronisation at the end of every frame (a frame's latency) instead of letting the "
+                         "host run a frame ahead of the device (throughput)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of exactly --steps steps each; the line reports the median window")
     ap.add_argument("--no-cpu-baseline", action="store_true")

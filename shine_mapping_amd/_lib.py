@@ -237,6 +237,21 @@ def i64_array(vals):
     return arr
 
 
+def device_constants(values, dtype, device):
+    """A small device tensor holding `values`, WITHOUT a host-synchronous copy: torch.tensor(values, device=...) goes through
+    pageable memory, and that copy waits for everything queued on the stream in front of it — a loop that runs the host ahead of
+    the device (incremental mapping re-creates its optimiser every frame) would stall there once per frame.  Equal values are a
+    fill launch; anything else goes through pinned memory as a non-blocking copy."""
+    import torch
+
+    vals = list(values)
+    if not vals:
+        return torch.empty(0, dtype=dtype, device=device)
+    if all(v == vals[0] for v in vals):
+        return torch.full((len(vals),), vals[0], dtype=dtype, device=device)
+    return torch.tensor(vals, dtype=dtype).pin_memory().to(device, non_blocking=True)
+
+
 def current_stream_handle():
     """Raw hipStream_t of torch's current stream on the current device.  The private fast path costs ~1 us,
     torch.cuda.current_stream().cuda_stream ~8 us — several of those per small-batch iteration add up."""

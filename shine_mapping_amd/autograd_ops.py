@@ -335,7 +335,7 @@ class FusedInterpSdf(torch.autograd.Function):
         need_m = any(ctx.needs_input_grad[5 + L:])
         if g is None and q is None:
             return (None,) * (5 + len(params))
-        t = octree._require_tables(with_ranks=True)
+        t = octree._require_tables(with_ranks=True, probe=False)  # (plan_batch below is the probe, and records itself)
         c = octree._check_coord(coord.detach())
         n = c.shape[0]
         dev = c.device

@@ -155,6 +155,7 @@ def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None, _debug_va
                              ws.data_ptr(), C.byref(need), stream),
         "shine_plan_batch",
     )
+    octree._tables_read_done()  # (asynchronous growth, FeatureOctree.enable_async_growth: the plan is a probe of the tables)
     return perm, slots
 
 
@@ -162,7 +163,7 @@ def mark_touched(octree, pool, idx: torch.Tensor, flags=None):
     """Byte flags (one uint8 tensor [rows_s + 1] per level, top-down) of the feature rows the pool samples `idx` address:
     shine_mark_touched on the node-ordered pool's slot table.  Under data parallelism every rank calls this on the
     GLOBAL draw (same seed everywhere), so all ranks hold the same row set without a collective."""
-    t = octree._require_tables()
+    t = octree._require_tables(probe=False)  # (memoised slots)
     if flags is None:
         flags = [torch.zeros(p.shape[0], dtype=torch.uint8, device=p.device) for p in octree.hier_features]
     cfg = octree.step_config(sorted_input=2)

@@ -144,6 +144,10 @@ class FeatureOctree(nn.Module):
         # every frame, not yet merged into the host copies above (_sync_host does that when a host view is needed)
         self._dev_log = [[] for _ in range(L)]
         self._dev_frames = []  # (flat copy, fresh counts, added counts) per frame, not yet split into _dev_log
+        self._growth_stream = None  # enable_async_growth(): update() grows the tree on this stream
+        self._probe_pending = False
+        self._ev_read = self._ev_grown = None
+        self._ev_read_valid = False
         self._corners_on_device = False  # the handle's corner tables hold every corner of every level
         self._box = None  # running (lo, hi) of the coarsest featured level's node coords, for _sort_box
         self._box_pending = []  # device tensors of coarse node keys not yet folded into _box
@@ -333,18 +337,41 @@ class FeatureOctree(nn.Module):
         cfg = _lib.StepConfig()
         cfg.n_levels, cfg.max_level = L, self.max_level
         lib = _lib.lib()
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.shine_tables_grow(t.handle, C.byref(cfg), pts.data_ptr(), pts.shape[0], fresh, added, stream),
-                   "shine_tables_grow")
-        nf, na = [int(v) for v in fresh], [int(v) for v in added]
-        grown = [s for s in range(L) if nf[s]]  # (a level without new nodes has no new corners: :129-130)
-        if not grown:
-            return
-        # what the device added — node keys, corner ids, new corner keys of every level — in ONE copy; it is split per level
-        # only when a host view is asked for (_drain_dev_frames)
-        words = sum(5 * nf[s] + na[s] for s in range(L))
-        flat = torch.empty(words, dtype=torch.int64, device=dev)
-        _lib.check(lib.shine_tables_grow_fetch_all(t.handle, flat.data_ptr(), words, stream), "shine_tables_grow_fetch_all")
+        main = torch.cuda.current_stream(dev)
+        side = self._growth_stream if self._growth_stream is not None else main
+        if side is not main:
+            # asynchronous growth (enable_async_growth): the growth's kernels and its two host reads use a stream of their own, so
+            # this call does not wait for what the caller has queued (the previous frame's iterations).  Growth writes the hash
+            # tables — which the queued steps read only through slots they memoised, never by probing — so the one thing it has
+            # to wait for is the last PROBE of the tables (a pool plan, a query): _tables_read_done() recorded it; a probe nobody
+            # recorded (self._probe_pending) falls back to waiting for everything queued so far.
+            if self._probe_pending:
+                self._ev_read.record(main)
+                self._ev_read_valid = True
+                self._probe_pending = False
+            if self._ev_read_valid:
+                side.wait_event(self._ev_read)
+        with torch.cuda.stream(side):
+            stream = side.cuda_stream
+            _lib.check(lib.shine_tables_grow(t.handle, C.byref(cfg), pts.data_ptr(), pts.shape[0], fresh, added, stream),
+                       "shine_tables_grow")
+            nf, na = [int(v) for v in fresh], [int(v) for v in added]
+            grown = [s for s in range(L) if nf[s]]  # (a level without new nodes has no new corners: :129-130)
+            if not grown:
+                return
+            # what the device added — node keys, corner ids, new corner keys of every level — in ONE copy; it is split per
+            # level only when a host view is asked for (_drain_dev_frames)
+            words = sum(5 * nf[s] + na[s] for s in range(L))
+            flat = torch.empty(words, dtype=torch.int64, device=dev)
+            _lib.check(lib.shine_tables_grow_fetch_all(t.handle, flat.data_ptr(), words, stream), "shine_tables_grow_fetch_all")
+            if side is not main:
+                # the node ranks (what the next pool plan sorts by) on the growth's stream too: they share the handle's scratch
+                self._ranks_uploaded = False
+                self._upload_ranks(dev)
+        if side is not main:
+            self._ev_grown.record(side)
+            main.wait_event(self._ev_grown)  # the appends, plans and steps queued from here on see the grown tables
+        stream = main.cuda_stream
         self._dev_frames.append((flat, nf, na))
         self._sort_box_cache = None
         first = [self._corner_count[s] == 0 for s in range(L)]
@@ -356,8 +383,33 @@ class FeatureOctree(nn.Module):
         else:
             self._append_rows_fused(grown, [na[s] for s in grown], incremental_on, dev, stream)
         self._dict_cache = None
-        self._ranks_uploaded = False
+        if side is main:
+            self._ranks_uploaded = False
         self._tables_epoch += 1
+
+    def enable_async_growth(self, stream=None):
+        """Let update() grow the tree on a stream of its own (`growth_stream`), so that a loop which keeps the host ahead of the
+        device — no synchronisation between frames — does not stall in update()'s two host reads behind the previous frame's
+        iterations.  Contract: the surface points handed to update() must not depend on work still queued on another stream
+        (produce them under `with torch.cuda.stream(octree.growth_stream)`, or synchronise first).  Everything else stays ordered
+        by events: growth waits for the last probe of the tables, and the caller's stream waits for the growth."""
+        dev = self.hier_features[0].device if len(self.hier_features) else torch.device(self.device)
+        self._growth_stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self._ev_read, self._ev_grown = torch.cuda.Event(), torch.cuda.Event()
+        self._ev_read_valid = False
+        self._probe_pending = True  # (whatever was queued before this call counts as a probe nobody recorded)
+        return self._growth_stream
+
+    @property
+    def growth_stream(self):
+        return self._growth_stream
+
+    def _tables_read_done(self):
+        """Called by the entry points that PROBE the hash tables, right after their launch (asynchronous growth waits for it)."""
+        if self._growth_stream is not None:
+            self._ev_read.record(torch.cuda.current_stream())
+            self._ev_read_valid = True
+            self._probe_pending = False
 
     def _append_rows_fused(self, levels, added, incremental_on, dev, stream):
         """_append_rows' second branch (:147-160) for all levels that grew, ONE launch (shine_append_rows): the random rows come
@@ -459,9 +511,13 @@ class FeatureOctree(nn.Module):
         self._corners_on_device = True
 
     # ------------------------------------------------------------------ hot path plumbing
-    def _require_tables(self, with_ranks=False):
+    def _require_tables(self, with_ranks=False, probe=True):
+        """`probe=False`: the caller reads the tables only through hash slots it memoised (the fused step on a planned batch or a
+        pool, the importance sweep) — asynchronous growth need not wait for it."""
         if len(self.hier_features) != self.featured_level_num:
             raise RuntimeError("FeatureOctree is empty: call update() before querying")
+        if probe and self._growth_stream is not None:
+            self._probe_pending = True
         dev = self.hier_features[0].device
         t = self._ensure_handle(dev)
         if with_ranks and not self._ranks_uploaded:
@@ -624,6 +680,9 @@ class FeatureOctree(nn.Module):
         state["_pending"] = None
         state["_dev_log"] = None
         state["_dev_frames"] = None
+        for k in ("_growth_stream", "_ev_read", "_ev_grown"):
+            state[k] = None
+        state["_probe_pending"] = state["_ev_read_valid"] = False
         state.pop("_feat_list", None)
         return state
 

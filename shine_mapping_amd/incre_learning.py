@@ -65,7 +65,7 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
     iter_n = math.ceil(sample_count / batch_interval)
     if iter_n == 0:
         return
-    t = octree._require_tables(with_ranks=True)
+    t = octree._require_tables(with_ranks=True, probe=False)  # (the sweep reads memoised slots; a plan below records itself)
     if pool is not None:
         if pool.size != sample_count or pool.tables_epoch != octree._tables_epoch or pool.coord.device != dev:
             raise ValueError("cal_feature_importance(pool=...): the pool must be the SortedPool of this frame's data, planned "

@@ -78,9 +78,11 @@ class IterationGraph:
         _lib.check(_lib.lib().shine_iter_graph_create(self.unroll, C.byref(self.handle)), "shine_iter_graph_create")
 
     @classmethod
-    def shared(cls, device, unroll):
-        """one graph per (device, unroll) for the life of the process: incremental mapping builds a GraphedIteration per frame"""
-        key = (str(device), int(unroll))
+    def shared(cls, device, unroll, slot=0):
+        """one graph per (device, unroll, slot) for the life of the process: incremental mapping builds a GraphedIteration per
+        frame.  `slot`: a loop that lets the host run a frame ahead of the device alternates two slots — re-binding a graph waits
+        for that graph's own last replay (shine_iter_graph_commit), and the other slot's replays are the ones still running"""
+        key = (str(device), int(unroll), int(slot))
         g = cls._cache.get(key)
         if g is None:
             g = cls._cache[key] = cls(unroll)
@@ -115,9 +117,10 @@ class GraphedIteration:
     object every frame: the eager iteration costs ~0.1 ms of launches that a replay does in a third of the time)."""
 
     def __init__(self, octree, decoder, pool, opt, opts: StepOptions, n: int, lambda_forget: float = 0.0, unroll: int = 1,
-                 fold: bool = True, eager_first: bool = True, active_rows: bool = True, native: bool = True):
+                 fold: bool = True, eager_first: bool = True, active_rows: bool = True, native: bool = True, graph_slot: int = 0):
         self.octree, self.decoder, self.pool, self.opt, self.opts, self.n = octree, decoder, pool, opt, opts, int(n)
         self.lambda_forget = float(lambda_forget)
+        self.graph_slot = int(graph_slot)
         self.fold = bool(fold)  # the iteration's tail as one launch (False: reduction, regulariser and Adam as three)
         self.regularize = self.lambda_forget != 0.0
         can_fold = self.fold and hasattr(opt, "finish_iteration") and hasattr(opt, "prepare_graph_safe")
@@ -190,7 +193,7 @@ class GraphedIteration:
     def _bound(self, unroll):
         """the library-built graph of `unroll` iterations, its kernel nodes naming this object's buffers"""
         ent = self._native.get(unroll)
-        g = ent[0] if ent is not None else IterationGraph.shared(self.pool.coord.device, unroll)
+        g = ent[0] if ent is not None else IterationGraph.shared(self.pool.coord.device, unroll, self.graph_slot)
         if ent is None or g.owner is not self:
             keep = {}
             out = self._body(graph=g, keep=keep)

@@ -91,6 +91,7 @@ def forward_sdf(octree, decoder, coord, want_feat=False, want_indices=False, wan
         ),
         "shine_forward",
     )
+    octree._tables_read_done()
     if idx is not None:
         octree.hierarchical_indices = idx
     return dict(pred=pred, feat=feat, indices=idx, grad_x=gx)
@@ -142,7 +143,8 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
                   graph=None):
     """shine_train_step on explicit gradient buffers (gfeat: L tensors or None entries, gmlp: 6 tensors; default: the
     parameters' own dense `.grad`)."""
-    t = octree._require_tables()
+    # (the fused kernel reads the tables through the batch's memoised hash slots; only the check library's v0 probes in-kernel)
+    t = octree._require_tables(probe=(int(opts.kernel_variant) & 0xff) == 1)
     pool_mode = pool is not None
     if pool_mode:  # batch = pool[idx] with idx sorted (sampler.SortedPool.draw): read straight out of the pool
         if idx is None or not (idx.is_cuda and idx.dtype == torch.int32):

@@ -76,8 +76,10 @@ class FusedAdam:
             return struct.unpack("<q", struct.pack("<d", x))[0]
 
         t = self.step_count
-        return torch.tensor([t, 0, bits(float(self.betas[0]) ** t), bits(float(self.betas[1]) ** t), 0, 0, 0, 0],
-                            dtype=torch.int64, device=dev)
+        if t == 0:  # zeros mean "not initialised" to adam_advance: it derives the running products itself (no host copy)
+            return torch.zeros(8, dtype=torch.int64, device=dev)
+        return _lib.device_constants([t, 0, bits(float(self.betas[0]) ** t), bits(float(self.betas[1]) ** t), 0, 0, 0, 0],
+                                     torch.int64, dev)
 
     def _fold_device_steps(self):
         """Fold the steps a graph took on the device back into the host counters (before the device state is dropped or
@@ -125,7 +127,7 @@ class FusedAdam:
                                               "(a parameter that started receiving grads later: use eager steps)")
             if self._dev is None:
                 # int64[8]: [0] steps taken, [1] the step's bias corrections; the rest is reserved (zeros)
-                self._dev = (self._make_dev_state(dev), torch.tensor([t[3] for t in ts], dtype=torch.float32, device=dev))
+                self._dev = (self._make_dev_state(dev), _lib.device_constants([t[3] for t in ts], torch.float32, dev))
                 self._dev_params = [t[0] for t in ts]
             for p, m, v, _, _ in ts:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
@@ -239,7 +241,7 @@ def _prepare_graph_safe(self):
         if self._dev is not None:
             self._fold_device_steps()
         dev = ts[0][0].device
-        self._dev = (self._make_dev_state(dev), torch.tensor([t[3] for t in ts], dtype=torch.float32, device=dev))
+        self._dev = (self._make_dev_state(dev), _lib.device_constants([t[3] for t in ts], torch.float32, dev))
         self._dev_params = [t[0] for t in ts]
     return self._dev[0]
 

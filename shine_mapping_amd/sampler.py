@@ -139,7 +139,7 @@ class SortedPool:
         state = None
         if graph_safe:
             if self._stream_state is None:
-                self._stream_state = torch.tensor([self.draws, 0, self.draws, 0], dtype=torch.int64, device=dev)
+                self._stream_state = _lib.device_constants([self.draws, 0, self.draws, 0], torch.int64, dev)
             state = self._stream_state.data_ptr()
         if pass1_done:
             _lib.check(lib.shine_sample_sorted_finish(self.size, nd, int(slice_begin) if sliced else 0, n, self.seed, state,
@@ -179,7 +179,7 @@ class SortedPool:
         if out is None:
             out = torch.empty(int(n), dtype=torch.int32, device=dev)  # (the step's rider does not write indices)
         if self._stream_state is None:
-            self._stream_state = torch.tensor([self.draws, 0, self.draws, 0], dtype=torch.int64, device=dev)
+            self._stream_state = _lib.device_constants([self.draws, 0, self.draws, 0], torch.int64, dev)
         if not (out.is_cuda and out.dtype == torch.int32 and out.is_contiguous() and out.numel() == int(n)):
             raise ValueError("next_draw: out must be a contiguous CUDA int32 tensor of n entries")
         if surf_parts is not None and (surf_parts.dtype != torch.int64 or surf_parts.numel() != SURF_PARTS):

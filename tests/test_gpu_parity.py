@@ -7,6 +7,7 @@ gradient tensors <= 1e-4 of the tensor's max-abs (fp32 atomics reorder the sums)
 """
 import pytest
 import torch
+import numpy as np
 
 from conftest import feat_grads_of_the_fused_terms, load_golden, oracle_from_golden, product_from_golden
 
@@ -802,6 +803,68 @@ def test_incremental_loop_end_to_end():
         codes = kal.points_to_morton(kal.quantize_points(frames[-1][0][:512].cpu(), lvl)).tolist()
         want = torch.tensor([tab[lvl].get(m, [-1] * 8) for m in codes])
         assert torch.equal(ix.cpu(), want)
+
+
+def test_pipelined_incremental_frames_equal_the_sequential_loop():
+    """FeatureOctree.enable_async_growth(): update() grows the tree on a stream of its own, so a loop without any synchronisation
+    between frames binds frame k + 1 while the device still trains frame k (bench.py's ncd-incre leg).  The same four frames
+    {update, new Adam, pool plan, K graphed iterations with the regulariser, importance sweep}
+      * sequentially, with a synchronisation after every frame,
+      * pipelined: growth stream, two alternating iteration graphs, no synchronisation, and ~20 ms of unrelated work queued on
+        the main stream in front of every update so that the growth certainly runs while earlier work is still pending,
+    must end in the same tables, features, decoder, importance and last-frame copies (the training runs in the deterministic
+    accumulation mode; the sweep's atomics are unordered: 1e-5)."""
+    from shine_mapping_amd import Decoder, FeatureOctree, StepOptions, synth
+    from shine_mapping_amd.incre_learning import cal_feature_importance
+    from shine_mapping_amd.loop import GraphedIteration
+    from shine_mapping_amd.optim import setup_optimizer
+    from shine_mapping_amd.sampler import SortedPool
+
+    K, N, BS = 6, 1024, 1024
+    cfg = synth.make_config("ncd", device="cuda", lr=0.01, opt_adam=True, adam_eps=1e-15, lr_level_reduce_ratio=1.0)
+    frames = list(synth.make_frames(cfg, frames=4, beams=16, azimuths=120, seed=9, device="cuda"))
+    opts = StepOptions(sigma=cfg.sigma_sigmoid, loss_reduction="sum", deterministic=True)
+
+    def run(pipelined):
+        torch.manual_seed(0)
+        octree, dec = FeatureOctree(cfg), Decoder(cfg).cuda()
+        if pipelined:
+            octree.enable_async_growth()
+        busy = torch.randn(2048, 2048, device="cuda")
+        keep = []
+        for fi, (coord, label, weight) in enumerate(frames):
+            if pipelined:
+                for _ in range(30):  # the main stream stays busy while update() returns
+                    busy = torch.tanh(busy @ busy * 1e-3)
+                with torch.cuda.stream(octree.growth_stream):
+                    surf = coord[weight > 0]
+            else:
+                surf = coord[weight > 0]
+            octree.update(surf, incremental_on=True)
+            opt = setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())
+            pool = SortedPool(octree, coord, label, weight, seed=fi, canonical=True)
+            it = GraphedIteration(octree, dec, pool, opt, opts, N, lambda_forget=cfg.lambda_forget, unroll=2, eager_first=False,
+                                  graph_slot=fi % 2 if pipelined else 0)
+            it.run(K)
+            data = type("Pool", (), {"coord_pool": coord, "sdf_label_pool": label})()
+            cal_feature_importance(data, octree, dec, cfg.sigma_sigmoid, BS, 2, "sum", pool=pool)
+            keep.append((opt, pool, it))  # (a pipelined loop's objects outlive the frame in bench.py too: one frame)
+            keep = keep[-2:]
+            if not pipelined:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        octree._sync_host()
+        return dict(feat=[p.detach().clone() for p in octree.hier_features], dec=[p.detach().clone() for p in dec.fused_params()],
+                    imp=[t.clone() for t in octree.importance_weight], last=[t.detach().clone() for t in octree.features_last_frame],
+                    keys=[k.copy() for k in octree._node_keys], ids=[k.copy() for k in octree._node_ids], loss=float(it.loss))
+
+    a, b = run(False), run(True)
+    for x, y in zip(a["keys"] + a["ids"], b["keys"] + b["ids"]):
+        assert np.array_equal(x, y)
+    for key in ("feat", "dec", "imp", "last"):
+        for x, y in zip(a[key], b[key]):
+            assert x.shape == y.shape and rel_err(y, x) <= 1e-5, key
+    assert abs(a["loss"] - b["loss"]) <= 1e-5 * abs(a["loss"])
 
 
 def test_incremental_trajectory_matches_oracle():
