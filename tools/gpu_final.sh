@@ -7,6 +7,7 @@ timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $O/smoke.log
 for w in maicity kitti ncd-incre kitti-large; do
   timeout 900 python bench.py --workload $w --no-extra-configs > $O/bench_$w.json.log 2> $O/bench_$w.err
 done
+timeout 600 python bench.py --workload ncd-incre --sync-frames --no-extra-configs --no-cpu-baseline > $O/bench_ncd-incre_sync_frames.json.log 2>/dev/null
 timeout 600 python bench.py --workload maicity --levels 3 --no-extra-configs --no-cpu-baseline > $O/bench_maicity_L3.json.log 2>/dev/null
 timeout 600 python bench.py --workload maicity --points 4096 --no-extra-configs --no-cpu-baseline > $O/bench_maicity_4096.json.log 2>/dev/null
 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --force-dist --no-extra-configs --no-cpu-baseline > $O/bench_dist1.json.log 2>/dev/null

@@ -26,7 +26,9 @@ if os.environ.get("TIER_A_SINGLE_THREAD_AUTOGRAD"):  # experiment: backward on t
 CASES = (("maicity", 3, 4096), ("kitti", 3, 4096), ("maicity", 3, 1 << 16), ("kitti", 3, 1 << 16))
 if os.environ.get("TIER_A_SMALL"):
     CASES = CASES[:2]
-for kind, lv, n in CASES:
+# the first case of a process reads the host's own warm-up (allocator, clocks: 0.53 against 0.31 ms for the same loop run second):
+# one discarded pass of the first case in front
+for case_i, (kind, lv, n) in enumerate((CASES[0],) + tuple(CASES)):
     wl = synth.build_workload(kind, frames=30, device="cuda", seed=42, tree_level_feat=lv)
     octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
     cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio = True, 1e-15, 1.0
@@ -88,5 +90,7 @@ for kind, lv, n in CASES:
             torch.cuda.synchronize()
             times[name].append((time.perf_counter() - t0) / 30 * 1e3)
     autograd_ops.FUSE_WITH_COORD_GRAD = False
+    if case_i == 0:
+        continue
     print(kind, "L%d" % lv, "N=%d" % n, "BCE+eikonal" if eik else "BCE",
           {k: "%.3f ms (min %.3f)" % (statistics.median(v), min(v)) for k, v in times.items()}, flush=True)
