@@ -214,9 +214,10 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         gmlp = [_dense_grad(p) for p in params] if dec_grad else [None] * 6
     if perm is not None and not (perm.is_cuda and perm.dtype == torch.int32 and perm.numel() == n):
         raise ValueError("perm must be a CUDA int32 tensor of N entries")
-    if slots is not None and not pool_mode and not (perm is not None and slots.is_cuda and slots.dtype == torch.int32
+    # (slots without perm: a batch that already IS in visiting order — e.g. gathered from a node-ordered pool — with its hash slots)
+    if slots is not None and not pool_mode and not (slots.is_cuda and slots.dtype == torch.int32
                                                     and slots.numel() == n * octree.featured_level_num):
-        raise ValueError("slots must come with perm from dp.plan_batch: CUDA int32 [N, L]")
+        raise ValueError("slots (from dp.plan_batch, or of a batch in visiting order): CUDA int32 [N, L]")
     ws = _workspace(dev, cfg)
     if pending is not None:
         if variant not in (0, 4) or slots is None:
