@@ -831,7 +831,7 @@ def test_pipelined_incremental_frames_equal_the_sequential_loop():
         if pipelined:
             octree.enable_async_growth()
         busy = torch.randn(2048, 2048, device="cuda")
-        keep = []
+        keep, caps = [], []
         for fi, (coord, label, weight) in enumerate(frames):
             if pipelined:
                 for _ in range(30):  # the main stream stays busy while update() returns
@@ -850,15 +850,20 @@ def test_pipelined_incremental_frames_equal_the_sequential_loop():
             cal_feature_importance(data, octree, dec, cfg.sigma_sigmoid, BS, 2, "sum", pool=pool)
             keep.append((opt, pool, it))  # (a pipelined loop's objects outlive the frame in bench.py too: one frame)
             keep = keep[-2:]
+            caps.append([octree._tables.stats(s)[0] for s in range(octree.featured_level_num)])
             if not pipelined:
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
         octree._sync_host()
         return dict(feat=[p.detach().clone() for p in octree.hier_features], dec=[p.detach().clone() for p in dec.fused_params()],
                     imp=[t.clone() for t in octree.importance_weight], last=[t.detach().clone() for t in octree.features_last_frame],
-                    keys=[k.copy() for k in octree._node_keys], ids=[k.copy() for k in octree._node_ids], loss=float(it.loss))
+                    keys=[k.copy() for k in octree._node_keys], ids=[k.copy() for k in octree._node_ids], loss=float(it.loss),
+                    caps=caps)
 
     a, b = run(False), run(True)
+    # the case that matters most: a hash table was re-built (new arrays, the old ones retired) by a growth that ran while the
+    # previous frame's iterations — bound to the old arrays — were still queued
+    assert any(later != b["caps"][0] for later in b["caps"][1:]), b["caps"]
     for x, y in zip(a["keys"] + a["ids"], b["keys"] + b["ids"]):
         assert np.array_equal(x, y)
     for key in ("feat", "dec", "imp", "last"):
