@@ -35,8 +35,14 @@ __global__ __launch_bounds__(256) void k_finish(const FinArgs a, int fb, int db)
   __shared__ float s_lr[FIN_MAX_SEG];
   __shared__ double s_red[4];
   __shared__ SampleShared s_sample;
-  if ((int)blockIdx.x > fb + db) {  // (nothing of this iteration reads the index buffer any more: the fused kernel is done)
-    sample_fused_block(s_sample, (int)blockIdx.x - (fb + db + 1), a.nd_blocks, a.nd_n, a.nd_pool, a.nd_seed, 0ull, a.nd_stream,
+  // Workgroups are dispatched in index order, so the next draw's blocks go FIRST: every one of them recomputes the block sums of
+  // all spacings, the longest dependent chain of the launch — started last they were the last to finish, 1.5 us of a 10 us
+  // launch (profiles/r04_ab_experiments.txt block 13).  vb = the index the code below is written in: rows [0, fb), decoder
+  // units [fb, fb + db), loss fb + db, draw beyond.
+  int vb = (int)blockIdx.x;
+  vb = vb < a.nd_blocks ? fb + db + 1 + vb : vb - a.nd_blocks;
+  if (vb > fb + db) {  // (nothing of this iteration reads the index buffer any more: the fused kernel is done)
+    sample_fused_block(s_sample, vb - (fb + db + 1), a.nd_blocks, a.nd_n, a.nd_pool, a.nd_seed, 0ull, a.nd_stream,
                        a.nd_idx, a.nd_bits, a.nd_surf);
     return;
   }
@@ -45,12 +51,12 @@ __global__ __launch_bounds__(256) void k_finish(const FinArgs a, int fb, int db)
   if (threadIdx.x < a.n_seg) s_lr[threadIdx.x] = a.lr_dev[a.seg[threadIdx.x].lr_idx];
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  if ((int)blockIdx.x < fb) {
+  if (vb < fb) {
     double acc = 0.0;
     // Rows are dealt round-robin to the launch's threads; a thread's (up to 4) flag bytes of one pass are requested together,
     // before any row is touched: on a map of 10^7 rows a thread walks ~10 rows, and flag -> row is a dependent round trip each.
     const long long stride = (long long)fb * 256;
-    for (long long u0 = (long long)blockIdx.x * 256 + threadIdx.x; u0 < a.feat_units; u0 += 4 * stride) {
+    for (long long u0 = (long long)vb * 256 + threadIdx.x; u0 < a.feat_units; u0 += 4 * stride) {
       int sv[4];
       long long rv[4];
       unsigned char tv[4];
@@ -124,11 +130,11 @@ __global__ __launch_bounds__(256) void k_finish(const FinArgs a, int fb, int db)
     }
     return;
   }
-  if ((int)blockIdx.x < fb + db) {
+  if (vb < fb + db) {
     // wave = unit of 8 consecutive elements whose gradient is a sum over the workgroups' partial vectors: units [0, L) the
     // trash rows of the feature tables (every miss of the step lands there), then the decoder tensors, 8 elements each;
     // lane = (element q = lane & 7, share c = lane >> 3 of the partial vectors)
-    const long long u = ((long long)blockIdx.x - fb) * 4 + (threadIdx.x >> 6);
+    const long long u = ((long long)vb - fb) * 4 + (threadIdx.x >> 6);
     if (u >= a.dec_units) return;
     const int q = lane & 7;
     int s, poff;
