@@ -91,6 +91,50 @@ def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n, variant
     assert all(float(p[-1].abs().max()) == 0.0 for p in octree.hier_features)
 
 
+@pytest.mark.parametrize("bs,down_rate", [(4096, 2), (1500, 1)])
+def test_importance_sweep_at_frame_scale_matches_oracle(bs, down_rate):
+    """cal_feature_importance at the size bench.py's ncd-incre leg runs it: one frame's whole pool (~10^5 samples), chunks of
+    `bs` kept samples — 64 workgroups per chunk, all chunks of the frame in ONE launch of the sliced step (shine_sweep.hip), one
+    fold launch — against the CPU oracle's chunk loop (the reference's loop, utils/incre_learning.py:8-40) on the same pool."""
+    from oracle import shine_oracle as so
+    from shine_mapping_amd import Decoder, FeatureOctree, synth
+    from shine_mapping_amd.incre_learning import cal_feature_importance
+    from shine_mapping_amd.sampler import SortedPool
+
+    cfg = synth.make_config("ncd", device="cuda", tree_level_feat=3)
+    frames = list(synth.make_frames(cfg, frames=2, beams=64, azimuths=300, seed=42, device="cuda"))
+    torch.manual_seed(3)
+    octree, dec = FeatureOctree(cfg), Decoder(cfg).cuda()
+    for coord, label, weight in frames:
+        octree.update(coord[weight > 0], incremental_on=True)
+    with torch.no_grad():
+        for p in octree.hier_features:
+            p[:-1].mul_(5.0)
+    coord, label, weight = frames[-1]
+    for t in octree.importance_weight:
+        t.zero_()
+    ocfg, oct_, mlp = oracle_from_product(octree, dec, cfg)
+    ocfg.loss_reduction = "sum"
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    so.importance_sweep(oct_, mlp, coord.cpu(), label.cpu(), ocfg, bs, down_rate)
+    octree._require_tables(with_ranks=True)
+    pool = SortedPool(octree, coord, label, weight, seed=1)
+    data = type("Pool", (), {"coord_pool": coord, "sdf_label_pool": label})()
+    cal_feature_importance(data, octree, dec, cfg.sigma_sigmoid, bs, down_rate, "sum", pool=pool)
+    torch.cuda.synchronize()
+    n_chunks = -(-coord.shape[0] // (bs * down_rate))
+    assert n_chunks >= 10 and coord.shape[0] >= 50000, (n_chunks, coord.shape)
+    for k, (a, b) in enumerate(zip(octree.importance_weight, oct_.importance_weight)):
+        assert float(b.abs().max()) > 0
+        assert rel_err(a, b) <= TOL, "importance level %d" % k
+        assert float(a[-1].abs().max()) == 0.0
+    # a second sweep accumulates on top (the scratch was left zero): twice the first
+    cal_feature_importance(data, octree, dec, cfg.sigma_sigmoid, bs, down_rate, "sum", pool=pool)
+    torch.cuda.synchronize()
+    for a, b in zip(octree.importance_weight, oct_.importance_weight):
+        assert rel_err(a, 2.0 * b) <= TOL
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_every_kernel_is_pinned_to_the_goldens(golden, variant):
     """kernel_variant 1 (the check library's lane-per-point kernel) is the on-device cross-check of other tests: it must itself
