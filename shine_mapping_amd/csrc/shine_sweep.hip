@@ -15,8 +15,11 @@
 
 namespace shine {
 
-template <int L, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_sweep(SweepArgs s) {
+// (4-wave workgroups whatever the chunk size: a chunk is the reference's batch size, a few thousand samples)
+constexpr int SWEEP_WAVES = 4;
+template <int L>
+__global__ __launch_bounds__(SWEEP_WAVES * 64, 2) void k_step_sweep(SweepArgs s) {
+  constexpr int WAVES = SWEEP_WAVES;
   __shared__ StepShared<WAVES> sm;
   const int c = (int)blockIdx.x / s.bpc, b = (int)blockIdx.x - c * s.bpc;
   const long long first = s.begin[c], n = s.begin[c + 1] - first;
@@ -136,14 +139,24 @@ __global__ __launch_bounds__(1024) void k_sweep_sort_chunks(int* __restrict__ id
   for (int i = threadIdx.x; i < cnt; i += 1024) idx[first + i] = s_v[i];
 }
 
-template <int WAVES>
 static const void* sweep_fn(int levels) {
   switch (levels) {
-    case 1: return (const void*)k_step_sweep<1, WAVES>;
-    case 2: return (const void*)k_step_sweep<2, WAVES>;
-    case 3: return (const void*)k_step_sweep<3, WAVES>;
-    default: return (const void*)k_step_sweep<4, WAVES>;
+    case 1: return (const void*)k_step_sweep<1>;
+    case 2: return (const void*)k_step_sweep<2>;
+    case 3: return (const void*)k_step_sweep<3>;
+    default: return (const void*)k_step_sweep<4>;
   }
+}
+
+// workgroups of one chunk's step: one tile per wave up to 256 workgroups (beyond that the waves walk several tiles)
+static V2Geometry sweep_geometry(long long n) {
+  V2Geometry g = v3_geometry(n > 0 ? n : 1);
+  g.wg_waves = SWEEP_WAVES;
+  long long blocks = (g.tiles + SWEEP_WAVES - 1) / SWEEP_WAVES;
+  if (blocks > 256) blocks = 256;
+  g.blocks = blocks;
+  g.waves = blocks * SWEEP_WAVES;
+  return g;
 }
 
 }  // namespace shine
@@ -233,7 +246,7 @@ extern "C" int shine_importance_sweep_sizes(int32_t n_levels, const int64_t* row
   long long group = n_chunks < SWEEP_GROUP ? n_chunks : SWEEP_GROUP;
   if (budget_bytes && per_chunk && (long long)(budget_bytes / per_chunk) < group) group = (long long)(budget_bytes / per_chunk);
   if (group < 1) group = 1;
-  const V2Geometry g = v3_geometry(max_chunk > 0 ? max_chunk : 1);
+  const V2Geometry g = sweep_geometry(max_chunk);
   *group_out = (int32_t)group;
   *scratch_bytes = (size_t)group * per_chunk;
   *workspace_bytes = (size_t)group * (size_t)g.blocks * PART_STRIDE * sizeof(float);
@@ -299,7 +312,7 @@ extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_co
   int rc = fill_step_args(&sa.a, t, &cc, coord, sdf_label, weight, idx, slots, nullptr, max_chunk, feats, rows, mlp, nullptr,
                           nullptr, grad_l, nullptr, nullptr, flag_l);
   if (rc != SHINE_OK) return rc;
-  V2Geometry g = v3_geometry(max_chunk);
+  V2Geometry g = sweep_geometry(max_chunk);
   if (sa.a.ablate & 64) {  // the test suite's deterministic accumulation: one wave per chunk
     g.blocks = 1;
     g.wg_waves = 4;
@@ -313,7 +326,7 @@ extern "C" int shine_importance_sweep(const shine_tables* t, const shine_step_co
   sa.flag_stride = (long long)fb;
   if (!workspace || workspace_bytes < (size_t)group * (size_t)g.blocks * PART_STRIDE * sizeof(float))
     return set_error(SHINE_E_INVALID, "shine_importance_sweep: workspace too small (shine_importance_sweep_sizes)");
-  const void* fn = g.wg_waves == V3_BIG ? sweep_fn<V3_BIG>(L) : sweep_fn<4>(L);
+  const void* fn = sweep_fn(L);
 
   long long max_rows = 0;
   for (int s = 0; s < L; ++s) max_rows = std::max(max_rows, (long long)rows[s] + 1);

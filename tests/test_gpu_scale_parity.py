@@ -91,7 +91,7 @@ def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n, variant
     assert all(float(p[-1].abs().max()) == 0.0 for p in octree.hier_features)
 
 
-@pytest.mark.parametrize("bs,down_rate", [(4096, 2), (1500, 1)])
+@pytest.mark.parametrize("bs,down_rate", [(4096, 2), (1500, 1), (40000, 1)])  # (the last: several tiles per wave, radix partition)
 def test_importance_sweep_at_frame_scale_matches_oracle(bs, down_rate):
     """cal_feature_importance at the size bench.py's ncd-incre leg runs it: one frame's whole pool (~10^5 samples), chunks of
     `bs` kept samples — 64 workgroups per chunk, all chunks of the frame in ONE launch of the sliced step (shine_sweep.hip), one
@@ -123,7 +123,7 @@ def test_importance_sweep_at_frame_scale_matches_oracle(bs, down_rate):
     cal_feature_importance(data, octree, dec, cfg.sigma_sigmoid, bs, down_rate, "sum", pool=pool)
     torch.cuda.synchronize()
     n_chunks = -(-coord.shape[0] // (bs * down_rate))
-    assert n_chunks >= 10 and coord.shape[0] >= 50000, (n_chunks, coord.shape)
+    assert n_chunks >= (10 if bs < 10000 else 2) and coord.shape[0] >= 50000, (n_chunks, coord.shape)
     for k, (a, b) in enumerate(zip(octree.importance_weight, oct_.importance_weight)):
         assert float(b.abs().max()) > 0
         assert rel_err(a, b) <= TOL, "importance level %d" % k
