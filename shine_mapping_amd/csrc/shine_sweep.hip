@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256) void k_sweep_fold(SweepFoldArgs a) {
       continue;
     }
     unsigned long long m = 0ull;
+    const unsigned char* fp = flags + r;  // (a running per-lane pointer: 64 scalar base addresses would spill the SGPR file)
 #pragma unroll
     for (int c = 0; c < SWEEP_GROUP; ++c) {
-      const unsigned char f = c < a.chunks ? flags[(long long)c * a.flag_stride + r] : (unsigned char)0;
+      const unsigned char f = c < a.chunks ? *fp : (unsigned char)0;
+      fp += a.flag_stride;
       m |= f ? 1ull << c : 0ull;
     }
     if (!m) continue;
