@@ -14,6 +14,7 @@
 // decoder): the lanes split the partial vectors.
 #include "shine_finish_args.hpp"
 #include "shine_sampler_dev.hpp"
+#include "shine_tile16.hpp"
 
 namespace shine {
 
@@ -167,6 +168,12 @@ __global__ __launch_bounds__(256) void k_finish(const FinArgs a, int fb, int db)
       S.m[e] = m;
       S.v[e] = v;
       S.g[e] = 0.f;
+      if (a.op_image && u >= a.n_levels) {  // a decoder element: also where the fused kernel's operand image holds it
+        int i0, i1;
+        operand_image_slots(S.part_off, (int)e, i0, i1);
+        if (i0 >= 0) a.op_image[i0] = p;
+        if (i1 >= 0) a.op_image[i1] = p;
+      }
     }
     return;
   }

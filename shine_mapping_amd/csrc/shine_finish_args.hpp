@@ -56,6 +56,9 @@ struct FinArgs {
   int* nd_idx;
   const unsigned int* nd_bits;
   long long* nd_surf;
+  // the decoder's MFMA operand image (shine_tile16.hpp: V3_IMAGE_FLOATS floats) or null: every decoder element this launch
+  // updates is also written to its place(s) in the image, which the next small-batch step copies instead of rebuilding it
+  float* op_image;
 };
 
 // a tail launch, prepared but not launched (shine_finish.hip prepare_finish)

@@ -11,9 +11,11 @@
 // kernel parameters in the instantiated graph (hipGraphExecKernelNodeSetParams): no capture, no instantiation, and all copies
 // of the iteration share one parameter block, because what changes from one iteration to the next — the sampler's stream id,
 // Adam's step count — lives in device memory and is advanced by the kernels themselves.
+#include <cstdlib>
 #include <vector>
 
 #include "shine_finish_args.hpp"
+#include "shine_tile16.hpp"
 
 struct shine_iter_graph {
   int unroll = 0;
@@ -30,6 +32,9 @@ struct shine_iter_graph {
   // replay still queued keeps the old ones (this runtime keeps a graph's kernel arguments in memory the exec owns)
   hipEvent_t last_replay = nullptr;
   bool replayed = false;
+  // the decoder's MFMA operand image for the small-batch builds of the step (V1Args::op_image): built at the head of every
+  // launch() from the decoder as it is then, kept current by the graph's own tail nodes
+  float* image = nullptr;
 };
 
 namespace shine {
@@ -108,6 +113,7 @@ extern "C" int shine_iter_graph_destroy(shine_iter_graph* g) {
   if (!g) return SHINE_OK;
   graph_drop(g);
   if (g->last_replay) (void)hipEventDestroy(g->last_replay);
+  if (g->image) (void)hipFree(g->image);
   delete g;
   return SHINE_OK;
 }
@@ -129,6 +135,12 @@ extern "C" int shine_iter_graph_set_step(shine_iter_graph* g, const shine_tables
   if (sl.mark_pass || sl.a.prof)
     return set_error(SHINE_E_INVALID, "shine_iter_graph_set_step: touched flags need a gradient table on every level (the "
                                       "marking pass in front of the step is not part of the graph); no profiling build");
+  // (SHINE_NO_OPERAND_IMAGE=1 in the environment switches it off: same-box A/B, profiles/r04_ab_experiments.txt block 14)
+  static const bool image_off = std::getenv("SHINE_NO_OPERAND_IMAGE") != nullptr;
+  if (sl.block.x == 256 && !image_off) {  // a small batch (4-wave workgroups): the step copies the operand image instead of building it
+    if (!g->image) SHINE_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->image), V3_IMAGE_FLOATS * sizeof(float)));
+    sl.a.op_image = g->image;
+  }
   g->step = sl;
   g->have_step = true;
   g->dirty = true;
@@ -161,6 +173,7 @@ extern "C" int shine_iter_graph_commit(shine_iter_graph* g) {
     return set_error(SHINE_E_STATE, "shine_iter_graph_commit: set_step and set_finish first");
   if (g->fin.a.partials != g->step.a.partials || g->fin.a.nblocks != g->step.blocks)
     return set_error(SHINE_E_INVALID, "shine_iter_graph_commit: the tail must consume the step's workspace (same buffer, same batch size)");
+  g->fin.a.op_image = g->step.a.op_image ? g->image : nullptr;  // (the tail keeps current what the step copies)
   ++g->commits;
   g->dirty = false;
   if (g->replayed) {
@@ -188,6 +201,10 @@ extern "C" int shine_iter_graph_launch(shine_iter_graph* g, int32_t replays, voi
   if (!g || !g->exec || g->dirty) return set_error(SHINE_E_STATE, "shine_iter_graph_launch: commit first");
   if (replays < 1) return SHINE_OK;
   if (!g->last_replay) SHINE_HIP_CHECK(hipEventCreateWithFlags(&g->last_replay, hipEventDisableTiming));
+  if (g->step.a.op_image) {  // the decoder may have been written by anybody since the last replay: the image starts from what it is now
+    const int rc = launch_operand_image(g->step.a, g->image, (hipStream_t)stream);
+    if (rc != SHINE_OK) return rc;
+  }
   for (int r = 0; r < replays; ++r) SHINE_HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)stream));
   SHINE_HIP_CHECK(hipEventRecord(g->last_replay, (hipStream_t)stream));
   g->replayed = true;

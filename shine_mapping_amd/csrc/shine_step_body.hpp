@@ -97,8 +97,21 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
 
   // ---- per-workgroup setup: A operands in 16x16x4 lane order (lane l: row i = l & 15, k = l >> 4), biases.
   // Branch-free source select and a fully unrolled loop: the (up to 11) loads of a thread are all in flight together.
+  // Small-batch builds (4 waves) may be handed the operand image ready-made (a.op_image: kept current by the iteration tail,
+  // shine_graph.hip): three 16-byte loads per thread instead of eleven permuted ones with their address arithmetic — at one
+  // tile per wave the prologue's instructions are a fifth of the kernel (profiles/r04_ab_experiments.txt block 12).
   OperandRegs<NT> opr;
-  decoder_operands_issue<NT>(a, opr, tid);
+  float4 img[3];
+  const bool use_img = WAVES == 4 && a.op_image != nullptr;
+  if (WAVES == 4 && use_img) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      img[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tid + k * NT < V3_IMAGE_FLOATS / 4) img[k] = reinterpret_cast<const float4*>(a.op_image)[tid + k * NT];
+    }
+  } else {
+    decoder_operands_issue<NT>(a, opr, tid);
+  }
 
   float inv_nsurf = 0.f;
   if (EIK) {  // the batch's surface count: one number, or the sampler's per-block parts (cfg->n_surf_parts) added up here
@@ -130,7 +143,13 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     if ((EIK && !EXT) || a.weighted) nweight = a.weight[np];
   }
 
-  decoder_operands_store<NT>(opr, s_opA, s_bias, tid);
+  if (WAVES == 4 && use_img) {  // (opA and bias are adjacent in StepShared: the image is their concatenation)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (tid + k * NT < V3_IMAGE_FLOATS / 4) reinterpret_cast<float4*>(s_opA)[tid + k * NT] = img[k];
+  } else {
+    decoder_operands_store<NT>(opr, s_opA, s_bias, tid);
+  }
   if (tid == 0) s_loss[0] = s_loss[1] = s_loss[2] = s_loss[3] = 0.0;
   __syncthreads();
 

@@ -51,7 +51,11 @@ struct V1Args {
   float adam_b1, adam_b2;
   long long* prof;  // debug: per-wave phase cycle counters [waves][8] (shine_debug_set_profile_buffer) or null
   long long n;
-  long long chunk;
+  // The decoder's MFMA operand image in LDS order (V3_OPTOTAL + 100 floats: what decoder_operands_issue / _store build per
+  // workgroup), kept current by the iteration tail, or null: built in-kernel.  Read by the 4-wave (small-batch) builds only; set by
+  // the iteration graph only (shine_graph.hip), which owns the buffer.  (In the place of a retired 8-byte field: the argument
+  // block keeps its size, so the hidden arguments behind it — and with them every kernel's code — stay where they were.)
+  const float* op_image;
   long long tiles;        // tiles of the launch (16 points each) ...
   long long waves_total;  // ... dealt evenly to this many waves: wave w owns tiles [w T / W, (w + 1) T / W)
   int n_levels;
@@ -146,6 +150,7 @@ struct Pass1Args {
 __global__ void k_reduce_partials(V1Args a, int nblocks, Pass1Args p1);
 int fill_pass1_args(Pass1Args* p1, const shine_step_config* cfg);  // shine_step_support.hip
 __global__ void k_mark_touched(V1Args a);
+int launch_operand_image(const V1Args& a, float* image, hipStream_t st);  // shine_step_support.hip (image: V3_IMAGE_FLOATS floats)
 
 // host: fill everything of V1Args that does not depend on the launch geometry (argument checks included)
 inline int fill_step_args(V1Args* a, const shine_tables* t, const shine_step_config* cfg, const float* coord,

@@ -8,6 +8,20 @@ namespace shine {
 
 // rows that receive gradient from this batch (= unique(hierarchical_indices) without -1, feature_octree.py:250):
 // one byte flag per row for shine_regularize.  Kept out of the fused kernel's hot loop (only config 4 needs it).
+// The decoder's MFMA operand image in global memory (what decoder_operands_issue / _store build in LDS): built here once per
+// shine_iter_graph_launch, kept current by k_finish afterwards (FinArgs::op_image), copied by the small-batch builds of the step.
+__global__ __launch_bounds__(256) void k_operand_image(V1Args a, float* image) {
+  OperandRegs<256> R;
+  decoder_operands_issue<256>(a, R, (int)threadIdx.x);
+  decoder_operands_store<256>(R, image, image + V3_OPTOTAL, (int)threadIdx.x);
+}
+
+int launch_operand_image(const V1Args& a, float* image, hipStream_t st) {
+  hipLaunchKernelGGL(k_operand_image, dim3(1), dim3(256), 0, st, a, image);
+  SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
+}
+
 __global__ __launch_bounds__(256) void k_mark_touched(V1Args a) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;

@@ -55,8 +55,8 @@ __device__ __forceinline__ int row_prev(int v, int first) { return __builtin_amd
 // region per wave (which ends its life as the wave's partial vector).
 template <int WAVES>
 struct StepShared {
-  float opA[V3_OPTOTAL];
-  float bias[100];
+  alignas(16) float opA[V3_OPTOTAL];
+  float bias[100];  // (directly behind opA: the operand image is copied over both)
   double loss[4];
   float wave[WAVES][V3_WAVE_FLOATS];
 };
@@ -122,5 +122,31 @@ __device__ __forceinline__ void decoder_operands_store(const OperandRegs<NT>& R,
   }
   if (tid == 0) s_bias[96] = R.b3;
 }
+
+// The inverse of decoder_operands_issue's map, for the launch that UPDATES the decoder (k_finish): where element e of a decoder
+// tensor lives in the operand image (opA then the 100 bias floats).  part_off = the tensor's offset in the flat parameter order
+// (MLP_W1, MLP_B1, ...).  Up to two places (a weight matrix appears as itself and transposed); -1: none.
+__device__ __forceinline__ void operand_image_slots(int part_off, int e, int& i0, int& i1) {
+  i0 = i1 = -1;
+  if (part_off == MLP_W1) {  // [H][F]: row R, column C
+    const int R = e >> 3, C = e & 7;
+    i0 = ((R >> 4) * 2 + (C & 1)) * 64 + (C >> 1) * 16 + (R & 15);
+    i1 = (36 + (R >> 4) * 4 + (R & 3)) * 64 + ((R >> 2) & 3) * 16 + 4 * (C >> 1) + (C & 1);
+  } else if (part_off == MLP_W2) {  // [H][H]: row r, column c
+    const int r = e >> 5, c = e & 31;
+    i0 = (4 + (r >> 4) * 8 + (c >> 4) * 4 + (c & 3)) * 64 + ((c >> 2) & 3) * 16 + (r & 15);
+    i1 = (20 + (c >> 4) * 8 + (r >> 4) * 4 + (r & 3)) * 64 + ((r >> 2) & 3) * 16 + (c & 15);
+  } else if (part_off == MLP_B1) {
+    i0 = V3_OPTOTAL + e;
+  } else if (part_off == MLP_B2) {
+    i0 = V3_OPTOTAL + 32 + e;
+  } else if (part_off == MLP_W3) {
+    i0 = V3_OPTOTAL + 64 + e;
+  } else if (part_off == MLP_B3) {
+    i0 = V3_OPTOTAL + 96;
+  }
+}
+constexpr int V3_IMAGE_FLOATS = V3_OPTOTAL + 100;  // 2916 = 729 float4
+static_assert(V3_IMAGE_FLOATS % 4 == 0, "the image is copied as float4");
 
 }  // namespace shine
