@@ -473,7 +473,9 @@ int shine_finish_iteration(const shine_step_config* cfg, int64_t n, const void* 
  *      shine_incre.py:107-109) costs no stream capture and no instantiation.  launch replays it `replays` times on the
  *      stream (= replays * unroll iterations; the per-iteration scalars — sampler stream id, Adam step count — live in device
  *      memory and are advanced by the kernels).  The argument arrays are read inside set_*; the DEVICE buffers they name
- *      must stay alive while the graph is launched.  commit waits (on the host) for the graph's own last replay before it touches
+ *      must stay alive while the graph is launched.  For small batches (< 32768 points) the graph also owns the decoder's MFMA
+ *      operand image: launch rebuilds it first from the decoder tensors as they are then, the tail nodes keep it current, the step
+ *      nodes copy it instead of building it per workgroup.  commit waits (on the host) for the graph's own last replay before it touches
  *      the instantiated graph, not for other work queued since.  stats: commits so far, and how many of them built the graph. */
 typedef struct shine_iter_graph shine_iter_graph;
 int shine_iter_graph_create(int32_t unroll, shine_iter_graph** out);

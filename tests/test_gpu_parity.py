@@ -1301,6 +1301,53 @@ def test_graphed_iteration_matches_eager_loop(mode, native):
         step()
 
 
+def test_iteration_graph_sees_decoder_weights_written_between_its_launches():
+    """Inside the library-built graph the small-batch kernel copies the decoder's MFMA operand image instead of building it
+    (V1Args::op_image): the graph's tail nodes keep the image current, and every launch rebuilds it first from the decoder as it
+    is then.  So weights written by somebody else between two run() calls — torch, a checkpoint load — must be what the next
+    iterations use: same parameters as the eager loop (which builds the image in-kernel every step) that got the same writes."""
+    from shine_mapping_amd import StepOptions, fused_train_step
+    from shine_mapping_amd.loop import GraphedIteration
+    from shine_mapping_amd.optim import setup_optimizer
+    from shine_mapping_amd.sampler import SortedPool
+
+    N = 4096
+
+    def make():
+        fx = load_golden("maicity_bce_L3")
+        cfg, octree, dec = product_from_golden(fx)
+        dec = dec.cuda()
+        cfg.lr, cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio, cfg.weight_decay = 0.01, True, 1e-15, 1.0, 1e-7
+        opt = setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())
+        octree._require_tables(with_ranks=True)
+        pool = SortedPool(octree, fx["coord"].cuda().repeat(8, 1), fx["sdf_label"].cuda().repeat(8),
+                          fx["weight"].cuda().repeat(8), seed=5, canonical=True)
+        return octree, dec, opt, pool, StepOptions(sigma=fx["sigma"], deterministic=True)
+
+    def perturb(dec, k):
+        with torch.no_grad():
+            for j, p in enumerate(dec.fused_params()):
+                p.mul_(1.0 + 0.01 * (k + 1)).add_(0.003 * (j + 1))
+
+    octree, dec, opt, pool, opts = make()
+    for k in range(3):  # eager: 3 x {2 iterations, somebody rewrites the decoder}
+        for _ in range(2):
+            fused_train_step(octree, dec, None, None, None, opts, pool=pool, idx=pool.draw(N))
+            opt.step(zero_grad=True)
+        perturb(dec, k)
+    want = [p.detach().clone() for p in list(octree.hier_features) + dec.fused_params()]
+
+    octree2, dec2, opt2, pool2, opts2 = make()
+    it = GraphedIteration(octree2, dec2, pool2, opt2, opts2, N, unroll=2)
+    assert it.native
+    for k in range(3):
+        it.run(2)
+        perturb(dec2, k)
+    torch.cuda.synchronize()
+    for a, b in zip(want, list(octree2.hier_features) + dec2.fused_params()):
+        assert rel_err(b.detach(), a) <= 1e-6
+
+
 def test_iteration_graph_rebound_while_its_replays_are_still_queued():
     """Two maps share the library's iteration graph (one per device and unroll).  Map A's replays are queued behind a long
     kernel, map B binds the graph straight away — the commit must not rewrite kernel arguments that A's queued replays still
