@@ -29,8 +29,8 @@ def _zero_scratch(dev, nbytes):
 
 
 def chunk_partition(perm, sample_count, batch_interval, down_rate):
-    """(torch form of shine_importance_chunks, kept as its cross-check in the tests.)  The reference's chunks (pool[head:tail:down_rate] for head = n * batch_interval, utils/incre_learning.py:27-31) as
-    segments of node-ordered positions: perm[j] is the pool index of sorted position j.  Returns (idx int32 [kept],
+    """(The torch form of shine_importance_chunks, kept as its cross-check in the tests.)  The reference's chunks
+    (pool[head:tail:down_rate] for head = n * batch_interval, utils/incre_learning.py:27-31) as segments of node-ordered positions: perm[j] is the pool index of sorted position j.  Returns (idx int32 [kept],
     begin list[iter_n + 1]): chunk n = idx[begin[n]:begin[n+1]], ascending (= node order) inside a chunk."""
     iter_n = math.ceil(sample_count / batch_interval)
     p = perm.long()
@@ -81,18 +81,9 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
     if pool is not None:
         idx, begin, _, max_chunk = pool.importance_chunks(bs, down_rate)  # (cached: a loop may have asked for it already)
     else:
-        # the chunks as segments of node-ordered positions: one radix pass over the chunk ids (csrc/shine_sweep.hip)
-        perm = perm.to(torch.int32).contiguous()
-        idx = torch.empty(sample_count, dtype=torch.int32, device=dev)
-        begin = (C.c_int64 * (iter_n + 1))()
-        need = C.c_size_t()
-        _lib.check(lib.shine_importance_chunks(None, sample_count, bs, down_rate, None, None, iter_n, None, C.byref(need), None),
-                   "shine_importance_chunks")
-        part_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
-        _lib.check(lib.shine_importance_chunks(perm.data_ptr(), sample_count, bs, down_rate, idx.data_ptr(), begin, iter_n,
-                                               part_ws.data_ptr(), C.byref(need), _lib.current_stream_handle()),
-                   "shine_importance_chunks")
-        max_chunk = max(begin[c + 1] - begin[c] for c in range(iter_n))
+        from .sampler import importance_chunks
+
+        idx, begin, _, max_chunk = importance_chunks(perm, sample_count, bs, down_rate)
     opts = StepOptions(sigma=float(sigma), loss_reduction=loss_reduction, decoder_grad_on=False)
     cfg = octree.step_config(sigma=float(sigma), weight_e=0.0, eikonal_on=0,
                              reduction_sum=1 if loss_reduction == "sum" else 0, decoder_grad_on=0, sorted_input=2,
@@ -108,11 +99,15 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
                "shine_importance_sweep_sizes")
     scratch = _zero_scratch(dev, scratch_bytes.value)
     ws = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
-    _lib.check(
-        lib.shine_importance_sweep(
-            t.handle, C.byref(cfg), coord_s.data_ptr(), label_s.data_ptr(), None, idx.data_ptr(), slots.data_ptr(),
-            begin, iter_n, octree.feature_ptrs(), rows,
-            _lib.ptr_array([q.data_ptr() for q in mlp.fused_params()]),
-            _lib.ptr_array([w.data_ptr() for w in octree.importance_weight]), group.value, scratch.data_ptr(),
-            scratch.numel(), ws.data_ptr(), ws.numel(), _lib.current_stream_handle()),
-        "shine_importance_sweep")
+    try:
+        _lib.check(
+            lib.shine_importance_sweep(
+                t.handle, C.byref(cfg), coord_s.data_ptr(), label_s.data_ptr(), None, idx.data_ptr(), slots.data_ptr(),
+                begin, iter_n, octree.feature_ptrs(), rows,
+                _lib.ptr_array([q.data_ptr() for q in mlp.fused_params()]),
+                _lib.ptr_array([w.data_ptr() for w in octree.importance_weight]), group.value, scratch.data_ptr(),
+                scratch.numel(), ws.data_ptr(), ws.numel(), _lib.current_stream_handle()),
+            "shine_importance_sweep")
+    except Exception:
+        _SCRATCH.pop(dev, None)  # (a call that failed half-way may have left gradients in the scratch: it is not re-used)
+        raise

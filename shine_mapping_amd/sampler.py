@@ -26,6 +26,30 @@ def canonical_order(perm, slots):
 
 SURF_PARTS = 64  # include/shine_hip.h SHINE_SURF_PARTS
 
+def importance_chunks(perm, n, bs, down_rate=1):
+    """The chunks of cal_feature_importance (utils/incre_learning.py:27-31: chunk c = pool[c * bs * down_rate : (c + 1) * bs *
+    down_rate : down_rate] of the ORIGINAL pool order) as segments of a node-ordered pool's sorted positions; perm[j] = original
+    index of the sample at sorted position j.  -> (idx int32 [kept] on the device, begin = host int64[n_chunks + 1], n_chunks,
+    largest chunk).  shine_importance_chunks: every kept sample is placed at chunk * bs + k and each chunk's segment sorted by one
+    workgroup in LDS (bs <= 16384; a radix pass over the chunk ids beyond)."""
+    import math
+
+    n, bs, down_rate = int(n), int(bs), int(down_rate)
+    n_chunks = math.ceil(n / (bs * down_rate))
+    lib = _lib.lib()
+    perm = perm.to(torch.int32).contiguous()
+    idx = torch.empty(n, dtype=torch.int32, device=perm.device)
+    begin = (C.c_int64 * (n_chunks + 1))()
+    need = C.c_size_t()
+    _lib.check(lib.shine_importance_chunks(None, n, bs, down_rate, None, None, n_chunks, None, C.byref(need), None),
+               "shine_importance_chunks")
+    ws = torch.empty(need.value, dtype=torch.uint8, device=perm.device)
+    _lib.check(lib.shine_importance_chunks(perm.data_ptr(), n, bs, down_rate, idx.data_ptr(), begin, n_chunks, ws.data_ptr(),
+                                           C.byref(need), _lib.current_stream_handle()), "shine_importance_chunks")
+    largest = max((begin[c + 1] - begin[c] for c in range(n_chunks)), default=0)
+    return idx, begin, n_chunks, largest
+
+
 class SortedPool:
     def __init__(self, octree, coord, sdf_label, weight, seed=42, canonical=False):
         """`canonical`: order the samples of one node by their original pool index.  The plan's counting sort places the
@@ -63,33 +87,13 @@ class SortedPool:
             del self._ws[k]
 
     def importance_chunks(self, bs, down_rate=1):
-        """The chunks of cal_feature_importance (utils/incre_learning.py:27-31: chunk c = pool[c * bs * down_rate : (c + 1) * bs *
-        down_rate : down_rate] of the ORIGINAL pool order) as segments of this pool's sorted positions: (idx int32 [kept] on the
-        device, begin = host int64[n_chunks + 1], n_chunks, largest chunk).  One radix pass over the chunk ids
-        (shine_importance_chunks); depends on the plan only, so an incremental loop can ask for it right after the pool is
-        built — the device does it while the host prepares the iterations — and incre_learning.cal_feature_importance(pool=...)
-        finds it here."""
-        import ctypes as C
-        import math
-
+        """The chunks of cal_feature_importance as segments of this pool's sorted positions (importance_chunks below), cached: it
+        depends on the plan only, so an incremental loop may ask for it as soon as the pool is built and
+        incre_learning.cal_feature_importance(pool=...) finds it here."""
         key = (int(bs), int(down_rate))
         hit = self._chunks.get(key)
-        if hit is not None:
-            return hit
-        n = self.size
-        n_chunks = math.ceil(n / (key[0] * key[1]))
-        lib = _lib.lib()
-        perm = self.perm.to(torch.int32).contiguous()
-        idx = torch.empty(n, dtype=torch.int32, device=perm.device)
-        begin = (C.c_int64 * (n_chunks + 1))()
-        need = C.c_size_t()
-        _lib.check(lib.shine_importance_chunks(None, n, key[0], key[1], None, None, n_chunks, None, C.byref(need), None),
-                   "shine_importance_chunks")
-        ws = torch.empty(need.value, dtype=torch.uint8, device=perm.device)
-        _lib.check(lib.shine_importance_chunks(perm.data_ptr(), n, key[0], key[1], idx.data_ptr(), begin, n_chunks, ws.data_ptr(),
-                                               C.byref(need), _lib.current_stream_handle()), "shine_importance_chunks")
-        largest = max((begin[c + 1] - begin[c] for c in range(n_chunks)), default=0)
-        hit = self._chunks[key] = (idx, begin, n_chunks, largest)
+        if hit is None:
+            hit = self._chunks[key] = importance_chunks(self.perm, self.size, key[0], key[1])
         return hit
 
     def draw(self, n, out=None, zero=None, graph_safe=False, n_global=None, slice_begin=0, surf_parts=None,
