@@ -46,6 +46,20 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pt = lane & 15, g = lane >> 4;
   const bool poly = a.poly != 0;
+  // Small-batch builds (4 waves) may be handed the decoder's operand image ready-made (a.op_image: kept current by the iteration
+  // tail, shine_graph.hip): three 16-byte loads per thread instead of eleven permuted ones with their address arithmetic — at
+  // one tile per wave the prologue's instructions are a fifth of the kernel (profiles/r04_ab_experiments.txt blocks 12, 14).
+  // They are the FIRST loads of the kernel: their addresses need nothing but the thread id, and the tile split below (two
+  // 64-bit divisions) runs under their round trip.
+  float4 img[3];
+  const bool use_img = WAVES == 4 && a.op_image != nullptr;
+  if (WAVES == 4 && use_img) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      img[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tid + k * NT < V3_IMAGE_FLOATS / 4) img[k] = reinterpret_cast<const float4*>(a.op_image)[tid + k * NT];
+    }
+  }
   long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tk = PROF ? clk() : 0;
 #define SHINE_STAMP(k)            \
@@ -97,21 +111,8 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
 
   // ---- per-workgroup setup: A operands in 16x16x4 lane order (lane l: row i = l & 15, k = l >> 4), biases.
   // Branch-free source select and a fully unrolled loop: the (up to 11) loads of a thread are all in flight together.
-  // Small-batch builds (4 waves) may be handed the operand image ready-made (a.op_image: kept current by the iteration tail,
-  // shine_graph.hip): three 16-byte loads per thread instead of eleven permuted ones with their address arithmetic — at one
-  // tile per wave the prologue's instructions are a fifth of the kernel (profiles/r04_ab_experiments.txt block 12).
   OperandRegs<NT> opr;
-  float4 img[3];
-  const bool use_img = WAVES == 4 && a.op_image != nullptr;
-  if (WAVES == 4 && use_img) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      img[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tid + k * NT < V3_IMAGE_FLOATS / 4) img[k] = reinterpret_cast<const float4*>(a.op_image)[tid + k * NT];
-    }
-  } else {
-    decoder_operands_issue<NT>(a, opr, tid);
-  }
+  if (!(WAVES == 4 && use_img)) decoder_operands_issue<NT>(a, opr, tid);
 
   float inv_nsurf = 0.f;
   if (EIK) {  // the batch's surface count: one number, or the sampler's per-block parts (cfg->n_surf_parts) added up here
