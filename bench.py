@@ -213,7 +213,8 @@ def gpu_iteration_n4096(wl, spool_seed, iters=300, n=4096, active_rows=True):
     spool = SortedPool(octree, wl.pool.coord, wl.pool.sdf_label, wl.pool.weight, seed=spool_seed)
     opts = StepOptions(sigma=cfg.sigma_sigmoid, loss_reduction=cfg.loss_reduction, ekional_loss_on=cfg.ekional_loss_on,
                        weight_e=cfg.weight_e)
-    unroll = 4  # iterations per HIP graph: the graph lives for hundreds of replays here, so its ~8 us boundary gap is worth folding
+    unroll = 20  # iterations per HIP graph: the graph is built once and lives for hundreds of iterations here, so the ~16 us of idle
+    # GPU at every graph boundary are folded away (a library-built graph's nodes cost nothing once instantiated)
     # This leg runs right after the CPU baseline (tens of seconds with an idle GPU): without a stretch of device work in front, its
     # first window reads the clock ramp (59 instead of 38 us per iteration on one box of the pool).  The stretch must not be
     # iterations of THIS loop — the active-row tail's time depends on how many it has taken — so it is plain device work.
