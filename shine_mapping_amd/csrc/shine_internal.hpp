@@ -122,6 +122,7 @@ hipError_t prim_scan_int(void* tmp, size_t& bytes, const int* in, int* out, size
 hipError_t prim_scan_flags(void* tmp, size_t& bytes, const unsigned char* flags, int* out, size_t n, hipStream_t st);
 hipError_t prim_sort_keys_u64(void* tmp, size_t& bytes, const unsigned long long* k0, unsigned long long* k1, size_t n,
                               unsigned begin_bit, unsigned end_bit, hipStream_t st);
+hipError_t prim_sort_segments_4k(int* idx, long long seg, long long total, int n_seg, unsigned end_bit, hipStream_t st);
 hipError_t prim_warmup(hipStream_t st);  // once per process: loads rocPRIM's size-class kernels (shine_prims.hip)
 hipError_t prim_sort_pairs_u64(void* tmp, size_t& bytes, const unsigned long long* k0, unsigned long long* k1,
                                const unsigned long long* v0, unsigned long long* v1, size_t n, unsigned begin_bit,

@@ -3,6 +3,7 @@
 // templates, so each translation unit that names them gets its own copy of the code objects — shine_grow / shine_sort /
 // shine_plan / shine_exchange together carried 9 MB of duplicated scans and sorts (the .so < 6 MB).
 // Same calling convention as rocPRIM: tmp == nullptr returns the temporary-storage size in `bytes`.
+#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -51,6 +52,34 @@ hipError_t prim_sort_pairs_u64(void* tmp, size_t& bytes, const unsigned long lon
                                const unsigned long long* v0, unsigned long long* v1, size_t n, unsigned begin_bit,
                                unsigned end_bit, hipStream_t st) {
   return rocprim::radix_sort_pairs(tmp, bytes, k0, k1, v0, v1, n, begin_bit, end_bit, st);
+}
+
+// Segments of <= 4096 int32 values sorted ascending in place, one workgroup per segment (rocPRIM's block radix sort over the low
+// `end_bit` bits: three or four ranking passes against the 78 barrier stages of a bitonic network): segment s = idx[s * seg ..
+// min((s + 1) * seg, total)).  The importance sweep's chunks (shine_sweep.hip) — every shipped yaml has bs = 4096.
+__global__ __launch_bounds__(1024) void k_sort_segments_4k(int* __restrict__ idx, long long seg, long long total, unsigned end_bit) {
+  using sort_t = rocprim::block_radix_sort<unsigned int, 1024, 4>;
+  __shared__ typename sort_t::storage_type storage;
+  const long long first = (long long)blockIdx.x * seg;
+  const long long cnt = total - first < seg ? total - first : seg;
+  unsigned int keys[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = (long long)threadIdx.x * 4 + k;
+    keys[k] = i < cnt ? (unsigned int)idx[first + i] : 0xffffffffu;  // (padding sorts behind every position)
+  }
+  sort_t().sort(keys, storage, 0u, end_bit);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = (long long)threadIdx.x * 4 + k;
+    if (i < cnt) idx[first + i] = (int)keys[k];
+  }
+}
+
+hipError_t prim_sort_segments_4k(int* idx, long long seg, long long total, int n_seg, unsigned end_bit, hipStream_t st) {
+  if (seg > 4096 || n_seg < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_sort_segments_4k, dim3((unsigned)n_seg), dim3(1024), 0, st, idx, seg, total, end_bit);
+  return hipGetLastError();
 }
 
 // rocPRIM picks its kernels by problem size (single-block sorts, merge sort, onesweep radix passes: a dozen code objects), and

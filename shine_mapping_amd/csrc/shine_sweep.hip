@@ -219,6 +219,12 @@ extern "C" int shine_importance_chunks(const int32_t* perm, int64_t n, int64_t b
     hipLaunchKernelGGL(k_sweep_place, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, perm, (long long)n, interval,
                        (int)down_rate, (long long)bs, (int*)idx_out);
     SHINE_HIP_CHECK(hipGetLastError());
+    if (bs <= 4096) {  // (every shipped yaml) a block radix sort over the positions' bits: ~10 us against ~48 for the network below
+      unsigned pos_bits = 1;
+      while (pos_bits < 32 && (1ll << pos_bits) < (long long)n) ++pos_bits;
+      SHINE_HIP_CHECK(prim_sort_segments_4k((int*)idx_out, (long long)bs, kept, (int)n_chunks, pos_bits, st));
+      return SHINE_OK;
+    }
     hipLaunchKernelGGL(k_sweep_sort_chunks, dim3((unsigned)n_chunks), dim3(1024), (size_t)pow2 * sizeof(int), st, (int*)idx_out,
                        (long long)bs, kept, pow2);
     SHINE_HIP_CHECK(hipGetLastError());
