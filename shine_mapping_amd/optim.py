@@ -221,12 +221,15 @@ def _prepare_graph_safe(self):
         sizes = [(p.numel() + 3) // 4 * 4 for p in fresh]  # (16-byte aligned views)
         total = sum(sizes)
         flat = torch.zeros(3 * total, dtype=torch.float32, device=fresh[0].device)
-        off = 0
-        for p, sz in zip(fresh, sizes):
+        parts = flat.split(sizes * 3)  # (one call for the 3 x len(fresh) views: a slice + view each was ~120 us per frame)
+        k = len(fresh)
+        for i, (p, sz) in enumerate(zip(fresh, sizes)):
             n = p.numel()
-            p.grad = flat[off:off + n].view(p.shape)
-            self.state[p] = (flat[total + off:total + off + n].view(p.shape), flat[2 * total + off:2 * total + off + n].view(p.shape))
-            off += sz
+            g, m, v = parts[i], parts[k + i], parts[2 * k + i]
+            if n != sz:
+                g, m, v = g[:n], m[:n], v[:n]
+            p.grad = g.view(p.shape)
+            self.state[p] = (m.view(p.shape), v.view(p.shape))
     for g in self.param_groups:
         for p in g["params"]:
             if p.requires_grad and p.grad is None:
