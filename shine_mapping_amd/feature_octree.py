@@ -394,7 +394,9 @@ class FeatureOctree(nn.Module):
         (produce them under `with torch.cuda.stream(octree.growth_stream)`, or synchronise first).  Everything else stays ordered
         by events: growth waits for the last probe of the tables, and the caller's stream waits for the growth."""
         dev = self.hier_features[0].device if len(self.hier_features) else torch.device(self.device)
-        self._growth_stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        # (high priority: the growth is a few dozen tiny kernels the host WAITS for — twice — while the main stream is busy with
+        # the previous frame's iterations)
+        self._growth_stream = stream if stream is not None else torch.cuda.Stream(device=dev, priority=-1)
         self._ev_read, self._ev_grown = torch.cuda.Event(), torch.cuda.Event()
         self._ev_read_valid = False
         self._probe_pending = True  # (whatever was queued before this call counts as a probe nobody recorded)
