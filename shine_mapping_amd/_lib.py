@@ -249,6 +249,8 @@ def device_constants(values, dtype, device):
         return torch.empty(0, dtype=dtype, device=device)
     if all(v == vals[0] for v in vals):
         return torch.full((len(vals),), vals[0], dtype=dtype, device=device)
+    if torch.device(device).type != "cuda":
+        return torch.tensor(vals, dtype=dtype, device=device)
     return torch.tensor(vals, dtype=dtype).pin_memory().to(device, non_blocking=True)
 
 

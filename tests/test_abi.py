@@ -174,3 +174,17 @@ def test_committed_counter_files_belong_to_the_kernels_of_this_build():
         assert rec["hbm_bytes_per_launch"] > 0 and 0 < rec["mfma_util"] < 1 and 0 < rec["fp32_datapath_util"] < 1
         seen += 1
     assert seen == 3
+
+
+def test_device_constants_on_the_host():
+    """_lib.device_constants (the optimiser's step state / learning rates, the sampler's stream id): a fill for equal values, a plain
+    tensor on a CPU device (the pinned non-blocking copy is for CUDA devices only)."""
+    import torch
+
+    from shine_mapping_amd import _lib
+
+    a = _lib.device_constants([0.01, 0.01, 0.01], torch.float32, "cpu")
+    b = _lib.device_constants([3, 0, 3, 0], torch.int64, torch.device("cpu"))
+    assert a.tolist() == pytest.approx([0.01] * 3) and a.dtype == torch.float32
+    assert b.tolist() == [3, 0, 3, 0] and b.dtype == torch.int64
+    assert _lib.device_constants([], torch.float32, "cpu").numel() == 0
