@@ -179,6 +179,7 @@ def test_committed_counter_files_belong_to_the_kernels_of_this_build():
 def test_device_constants_on_the_host():
     """_lib.device_constants (the optimiser's step state / learning rates, the sampler's stream id): a fill for equal values, a plain
     tensor on a CPU device (the pinned non-blocking copy is for CUDA devices only)."""
+    import pytest
     import torch
 
     from shine_mapping_amd import _lib
