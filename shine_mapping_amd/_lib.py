@@ -131,6 +131,7 @@ _SIGNATURES = {
                                        C.POINTER(C.c_int64), C.POINTER(_P), _P, _P]),
     "shine_train_step_workspace_bytes": (C.c_size_t, [C.POINTER(StepConfig), C.c_int64]),
     "shine_train_step_info": (C.c_int, [C.POINTER(StepConfig), C.c_int64, C.POINTER(C.c_int64)]),
+    "shine_train_step_regime": (C.c_int, [C.POINTER(StepConfig), C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int32)]),
     "shine_mark_touched": (C.c_int, [_P, C.POINTER(StepConfig), _P, _P, _P, C.c_int64, C.POINTER(C.c_int64),
                                      C.POINTER(_P), _P]),
     "shine_morton_sort": (C.c_int, [C.POINTER(StepConfig), _P, C.c_int64, _P, _P, C.POINTER(C.c_size_t), _P]),

@@ -64,11 +64,12 @@ extern "C" int shine_train_step(const shine_tables* t, const shine_step_config* 
     return SHINE_OK;
   }
   // kernel_variant (low byte): 0 the product kernel (shine_step_v3.hip: planned / pool batches, <= 4 featured levels — every
-  // shipped yaml).  The check library adds 1 = the lane-per-point reference kernel (any batch, up to 8 levels; the
+  // shipped yaml; 5 / 6 force / forbid its build for tables beyond the Infinity Cache, which 0 picks by table size).  The check library adds 1 = the lane-per-point reference kernel (any batch, up to 8 levels; the
   // on-device cross-check of the tests).
   const int variant = cfg->kernel_variant & 0xff;
-  if (variant != 0 && variant != 1 && variant != 4)
-    return shine::set_error(SHINE_E_INVALID, "shine_train_step: unknown kernel_variant (0 / 4: fused step, 1: check library)");
+  if (variant != 0 && variant != 1 && variant != 4 && variant != 5 && variant != 6)
+    return shine::set_error(SHINE_E_INVALID, "shine_train_step: unknown kernel_variant (0 / 4: fused step, 5 / 6: its far / near "
+                                             "build whatever the table size, 1: check library)");
   if (cfg->defer_reduce && (variant == 1 || cfg->n_levels > shine::LCAP || !slots))
     return shine::set_error(SHINE_E_INVALID, "shine_train_step: defer_reduce is for the product kernel on a planned batch");
   if (cfg->n_surf_parts > 1 && (variant == 1 || cfg->n_levels > shine::LCAP || !slots))

@@ -30,7 +30,27 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 // configuration's 4096 points, where the extra launch is half the step (ncd-incre 172 -> 179 frames/s).
 // SLICED: the launch holds many independent steps (shine_sweep.hip); `sl` names this workgroup's one — sample indices, size,
 // normaliser, private gradient tables and flags — and bid / nbid count inside the slice.
-template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false, bool SLICED = false>
+// FAR: the build for feature tables that do not fit the Infinity Cache (the launch picks it by table size, shine_step_v3.hip).
+// There a tile's dependent chain  hash slot -> 8 corner ids -> 8 rows  and the scatter's atomics each cost an HBM round trip that
+// two waves per SIMD cannot cover (profiles/r04_pmc_kitti-large_*: waves parked 0.40, issue-stalled 0.38).  The FAR build runs the
+// chain one tile ahead: the slot arrives two tiles ahead, the corner ids of tile t + 1 are loaded under the decoder of tile t,
+// and — once they are back — every feature row and every gradient row of tile t + 1 is TOUCHED (one dword load per row into a
+// register nobody reads), so that the gather and the atomics of tile t + 1 find their lines in the L2.
+#ifndef SHINE_FAR_TOUCH
+#define SHINE_FAR_TOUCH 2  // 0: ids ahead only, 1: + touch the feature rows, 2: + touch the gradient rows
+#endif
+#ifndef SHINE_FAR_POS
+#define SHINE_FAR_POS 0  // where the touches are issued: 0 after the decoder's forward, 1 after its backward, 2 in front of the scatter
+#endif
+__device__ __forceinline__ void touch_line(const float* p, int& sink) {
+  // (not a compiler-visible load: nothing waits for it; `sink` stays allocated because every touch reads and writes it)
+  asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p));
+}
+__device__ __forceinline__ void touch_line_l2(const float* p, int& sink) {  // agent scope: allocates in the L2 only
+  asm volatile("global_load_dword %0, %1, off sc1" : "+v"(sink) : "v"(p));
+}
+
+template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false, bool SLICED = false, bool FAR = false>
 __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm, const int bid, const int nbid,
                                           const StepSlice* sl = nullptr) {
 // (spelled as expressions at every use, not as locals: the unsliced builds must stay the instruction streams the committed
@@ -108,6 +128,8 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
   int np2 = 0, np1 = 0;
   if (SL_PERM && second + pt < end) np2 = SL_PERM[second + pt];
   if (SL_PERM && nvalid) np1 = SL_PERM[begin + pt];
+  int np3 = 0;  // FAR: the sample index of the tile after that (its slot is loaded two tiles ahead)
+  if (FAR && SL_PERM && second + V3_TP + pt < end) np3 = SL_PERM[second + V3_TP + pt];
 
   // ---- per-workgroup setup: A operands in 16x16x4 lane order (lane l: row i = l & 15, k = l >> 4), biases.
   // Branch-free source select and a fully unrolled loop: the (up to 11) loads of a thread are all in flight together.
@@ -143,6 +165,9 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     nlabel = a.label[np];
     if ((EIK && !EXT) || a.weighted) nweight = a.weight[np];
   }
+  int fslot = -1;  // FAR: the hash slot of the tile after the one n* describes
+  if (FAR && lvl_on_i && second + pt < end)
+    fslot = __builtin_nontemporal_load(a.slots + (a.pool_mode ? (long long)np2 : second + pt) * L + g);
 
   if (WAVES == 4 && use_img) {  // (opA and bias are adjacent in StepShared: the image is their concatenation)
 #pragma unroll
@@ -182,6 +207,21 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
       lv_res = a.lv[s].res;
     }
 
+  const float* lv_grad = nullptr;  // FAR: this lane's level's gradient table (touched one tile ahead)
+  if (FAR && SHINE_FAR_TOUCH >= 2) {
+    lv_grad = SLICED ? sl->grad[0] : a.lv[0].grad;
+#pragma unroll
+    for (int s = 1; s < L; ++s)
+      if (gs == s) lv_grad = SLICED ? sl->grad[s] : a.lv[s].grad;
+  }
+  int4 fia = make_int4(0, 0, 0, 0), fib = fia;  // FAR: the corner ids of the tile n* describes, loaded one tile ahead
+  int sink = 0;
+  if (FAR) {
+    const unsigned int s0 = nvalid && nslot >= 0 ? (unsigned int)nslot : 0u;
+    fia = lv_vals[2u * s0];
+    fib = lv_vals[2u * s0 + 1u];
+  }
+
   f32x4 accW2[2][2], accW1[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -189,13 +229,13 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
 #pragma unroll
     for (int n = 0; n < 2; ++n) accW2[m][n] = zero4();
   }
-  float dw3c[8];
+  f32x2 dw3c[4];  // channel pairs (2 j, 2 j + 1) of this lane's eight (packed fp32: half the FMAs)
 #pragma unroll
-  for (int r = 0; r < 8; ++r) dw3c[r] = 0.f;
+  for (int j = 0; j < 4; ++j) dw3c[j] = splat2(0.f);
   float db2acc[2] = {0.f, 0.f};  // BCE build: db2 rides on the transposed operands of the dW2 pass
-  float db2c[EIK ? 8 : 1], db1c[EIK ? 8 : 1];  // eikonal build: sum_p delta_p v2 / v1 for this lane's channels
+  f32x2 db2c[EIK ? 4 : 1], db1c[EIK ? 4 : 1];  // eikonal build: sum_p delta_p v2 / v1 for this lane's channels
 #pragma unroll
-  for (int r = 0; r < (EIK ? 8 : 1); ++r) db2c[r] = db1c[r] = 0.f;
+  for (int j = 0; j < (EIK ? 4 : 1); ++j) db2c[j] = db1c[j] = splat2(0.f);
   float eik_acc = 0.f;
   float db3 = 0.f;
   float loss_acc = 0.f;  // per-lane sum over this wave's <= a few dozen tiles; widened to double at the flush
@@ -252,15 +292,23 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
 #pragma unroll
       for (int c = 0; c < 8; ++c) st_w[c * V3_WP] = w[c];
     }
-    float pf[8];
+    // Packed fp32 (v_pk_fma_f32, two FMAs per lane and instruction): the sums over a row's features are kept as feature PAIRS
+    // with the corner's weight broadcast to both halves (op_sel) — per feature the same fmaf chain over the corners, in the same
+    // order (model/feature_octree.py:231), half the instructions.
+    f32x2 pf[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) pf[q] = 0.f;
-    float Ag[EIK ? 8 : 1][3];  // eikonal build: this level's part of d f_q / d x_e
+    for (int q = 0; q < 4; ++q) pf[q] = splat2(0.f);
+    f32x2 Ag[EIK ? 4 : 1][3];  // eikonal build: this level's part of d f_q / d x_e, features (2 j, 2 j + 1)
 #pragma unroll
-    for (int q = 0; q < (EIK ? 8 : 1); ++q) Ag[q][0] = Ag[q][1] = Ag[q][2] = 0.f;
+    for (int q = 0; q < (EIK ? 4 : 1); ++q) Ag[q][0] = Ag[q][1] = Ag[q][2] = splat2(0.f);
     {  // every lane gathers the 8 ids and the 8 x 32-B rows of its own (point, level)
       const unsigned int sl = hit ? (unsigned int)slot : 0u;
-      const int4 ia = lv_vals[2u * sl], ib = lv_vals[2u * sl + 1u];  // the eight corner ids: two 16-B loads
+      int4 ia, ib;  // the eight corner ids: two 16-B loads (FAR: requested one tile ago)
+      if (FAR) {
+        ia = fia, ib = fib;
+      } else {
+        ia = lv_vals[2u * sl], ib = lv_vals[2u * sl + 1u];
+      }
       const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
       // staging for the scatter: a miss stages -1 (trash row), never the speculative ids
       const int mneg = hit ? 0 : -1;
@@ -277,24 +325,23 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
           r1[c] = *reinterpret_cast<const float4*>(row + 4);
         }
 #pragma unroll
-        for (int c = 0; c < V3_GB; ++c) {
-          const float wc = w[cb + c];
-          pf[0] = fmaf(wc, r0[c].x, pf[0]);
-          pf[1] = fmaf(wc, r0[c].y, pf[1]);
-          pf[2] = fmaf(wc, r0[c].z, pf[2]);
-          pf[3] = fmaf(wc, r0[c].w, pf[3]);
-          pf[4] = fmaf(wc, r1[c].x, pf[4]);
-          pf[5] = fmaf(wc, r1[c].y, pf[5]);
-          pf[6] = fmaf(wc, r1[c].z, pf[6]);
-          pf[7] = fmaf(wc, r1[c].w, pf[7]);
-          if (EIK) {
-            float dwc[3];
-            corner_dw(X, Y, Z, cb + c, dwc);
-            const float rr[8] = {r0[c].x, r0[c].y, r0[c].z, r0[c].w, r1[c].x, r1[c].y, r1[c].z, r1[c].w};
+        for (int cp = 0; cp < V3_GB; cp += 2) {  // corners (cb + cp, cb + cp + 1): the same (cx, cy), cz = 0 / 1
+          f32x2 dw[3];
+          if (EIK) corner_dw_pair(X, Y, Z, (cb + cp) >> 1, dw);
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
+          for (int h = 0; h < 2; ++h) {
+            const int c = cp + h;
+            const f32x2 rr[4] = {{r0[c].x, r0[c].y}, {r0[c].z, r0[c].w}, {r1[c].x, r1[c].y}, {r1[c].z, r1[c].w}};
+            const f32x2 wc = splat2(w[cb + c]);
 #pragma unroll
-              for (int q = 0; q < 8; ++q) Ag[q][e] = fmaf(dwc[e], rr[q], Ag[q][e]);  // (zero for a miss: dt = 0 above)
+            for (int j = 0; j < 4; ++j) pf[j] = pk_fma(wc, rr[j], pf[j]);
+            if (EIK) {
+#pragma unroll
+              for (int e = 0; e < 3; ++e) {
+                const f32x2 de = splat2(dw[e][h]);  // (zero for a miss: dt = 0 above)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ag[j][e] = pk_fma(de, rr[j], Ag[j][e]);
+              }
             }
           }
         }
@@ -302,30 +349,56 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
       }
     }
     // prefetch of tile t+1's point data, issued after every gather of this tile (vmcnt counts in order)
+    bool fhit = false;  // FAR: this lane's (point, level) of tile t+1 has a node
     {
-      const long long ni = base + V3_TP + pt, ni2 = ni + V3_TP;
+      const long long ni = base + V3_TP + pt, ni2 = ni + V3_TP, ni3 = ni2 + V3_TP;
       nvalid = ni < end;
       np = 0;
       nx0 = nx1 = nx2 = nlabel = nweight = 0.f;
       nslot = -1;
+      if (FAR) {  // the corner ids of tile t+1 (its slot came in a tile ago), then the slot of tile t+2
+        nslot = nvalid ? fslot : -1;
+        fhit = nslot >= 0;
+        const unsigned int fs = fhit ? (unsigned int)nslot : 0u;
+        fia = lv_vals[2u * fs];
+        fib = lv_vals[2u * fs + 1u];
+        fslot = -1;
+        if (lvl_on && ni2 < end)
+          fslot = __builtin_nontemporal_load(a.slots + (a.pool_mode ? (long long)np3 : ni2) * L + g);
+      }
       if (nvalid) {
         np = SL_PERM ? (long long)np2 : ni;
         const long long si = a.pool_mode ? np : ni;
-        if (lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
+        if (!FAR && lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
         nx0 = __builtin_nontemporal_load(a.coord + 3 * np);
         nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
         nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
         nlabel = __builtin_nontemporal_load(a.label + np);
         if ((EIK && !EXT) || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
       }
-      if (SL_PERM && ni2 < end) np2 = __builtin_nontemporal_load(SL_PERM + ni2);
+      if (FAR) {
+        np2 = np3;
+        np3 = 0;
+        if (SL_PERM && ni3 < end) np3 = __builtin_nontemporal_load(SL_PERM + ni3);
+      } else if (SL_PERM && ni2 < end) {
+        np2 = __builtin_nontemporal_load(SL_PERM + ni2);
+      }
+    }
+    // FAR: touch every row tile t+1 will gather from and scatter to (its ids are waited for HERE, a phase after their request)
+#define SHINE_FAR_TOUCHES                                                                  \
+    if (FAR && SHINE_FAR_TOUCH >= 1 && fhit) {                                             \
+      const int nid[8] = {fia.x, fia.y, fia.z, fia.w, fib.x, fib.y, fib.z, fib.w};         \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                      \
+        touch_line(lv_feat + (size_t)(unsigned int)nid[c] * F, sink);                      \
+        if (SHINE_FAR_TOUCH >= 2 && lv_grad) touch_line_l2(lv_grad + (size_t)(unsigned int)nid[c] * F, sink); \
+      }                                                                                    \
     }
     // reduce-scatter of the per-level sums over the point's four lanes: lane g ends with features (2g, 2g+1)
     float f2[2];
     {
       float h4[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) h4[q] = xsum32(pf[q], pf[4 + q]);  // g < 2: features q, g >= 2: features 4 + q
+      for (int q = 0; q < 4; ++q) h4[q] = xsum32(pf[q >> 1][q & 1], pf[2 + (q >> 1)][q & 1]);  // g < 2: features q, g >= 2: features 4 + q
 #pragma unroll
       for (int t = 0; t < 2; ++t) f2[t] = xsum16(h4[t], h4[2 + t]);  // even g: t, odd g: 2 + t
     }
@@ -337,7 +410,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
       for (int e = 0; e < 3; ++e) {
         float h4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h4[q] = xsum32(Ag[q][e], Ag[4 + q][e]);
+        for (int q = 0; q < 4; ++q) h4[q] = xsum32(Ag[q >> 1][e][q & 1], Ag[2 + (q >> 1)][e][q & 1]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) A2[t][e] = xsum16(h4[t], h4[2 + t]);
       }
@@ -379,6 +452,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     yp += __shfl_xor(yp, 16, 64);
     const float y = yp + __shfl_xor(yp, 32, 64) + b3;
     if (!EXT && valid && g == 0 && a.pred) __builtin_nontemporal_store(y, a.pred + po);
+    if (SHINE_FAR_POS == 0) { SHINE_FAR_TOUCHES }
     __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
     SHINE_STAMP(2)  // decoder forward
 
@@ -407,9 +481,11 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     // ================================================================ phase 4: backward through the decoder
     float d2[8], d1[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      d2[r] = h2[r] > 0.f ? delta * w3r[r] : 0.f;
-      dw3c[r] = fmaf(delta, h2[r], dw3c[r]);
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 dw = splat2(delta) * (f32x2){w3r[2 * j], w3r[2 * j + 1]};
+      d2[2 * j] = h2[2 * j] > 0.f ? dw[0] : 0.f;
+      d2[2 * j + 1] = h2[2 * j + 1] > 0.f ? dw[1] : 0.f;
+      dw3c[j] = pk_fma(splat2(delta), (f32x2){h2[2 * j], h2[2 * j + 1]}, dw3c[j]);
     }
     if (g == 0) db3 += delta;
     f32x4 e1[2] = {zero4(), zero4()}, e0 = zero4();
@@ -422,6 +498,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) e0 = mfma16(opa[V3_OPA1T + ks * 64], d1[ks], e0);
     sdf2[0] = e0[0], sdf2[1] = e0[1];  // d loss / d f for features 2g, 2g+1 of this lane's point
+    if (SHINE_FAR_POS == 1) { SHINE_FAR_TOUCHES }
     __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
     SHINE_STAMP(3)  // loss + decoder backward
 
@@ -544,24 +621,31 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
 #pragma unroll
         for (int m = 0; m < 2; ++m) t2[m] = mfma16(opa[V3_OPA2 + (8 * m + ks) * 64], a1[ks], t2[m]);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float a2 = h2[r] > 0.f ? t2[r >> 2][r & 3] : 0.f;  // (W2 a1) .* m2
-        dw3c[r] += fmaf(delta, h2[r], a2);
-        db2c[r] = fmaf(delta, v2[r], db2c[r]);
-        db1c[r] = fmaf(delta, v1[r], db1c[r]);
+      for (int j = 0; j < 4; ++j) {
+        f32x2 a2;  // (W2 a1) .* m2
+        a2[0] = h2[2 * j] > 0.f ? t2[j >> 1][2 * (j & 1)] : 0.f;
+        a2[1] = h2[2 * j + 1] > 0.f ? t2[j >> 1][2 * (j & 1) + 1] : 0.f;
+        const f32x2 dl = splat2(delta);
+        dw3c[j] += pk_fma(dl, (f32x2){h2[2 * j], h2[2 * j + 1]}, a2);
+        db2c[j] = pk_fma(dl, (f32x2){v2[2 * j], v2[2 * j + 1]}, db2c[j]);
+        db1c[j] = pk_fma(dl, (f32x2){v1[2 * j], v1[2 * j + 1]}, db1c[j]);
       }
     }
     sdf2[0] = J2[0], sdf2[1] = J2[1];
+    if (SHINE_FAR_POS == 1) { SHINE_FAR_TOUCHES }
     __builtin_amdgcn_sched_barrier(0);  // phase boundary
     SHINE_STAMP(3)  // loss + decoder backward (eikonal chain)
 
     // ================================================================ phase 5 (eikonal build): decoder weight grads
     if (a.decoder_grad_on) {
       const int i16 = lane & 15;
+      f32x2 dha[4];  // delta h1 + a1
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dha[j] = pk_fma(splat2(delta), (f32x2){h1[2 * j], h1[2 * j + 1]}, (f32x2){a1[2 * j], a1[2 * j + 1]});
 #pragma unroll
       for (int r = 0; r < 8; ++r) {  // channel 16 (r >> 2) + 4 g + (r & 3)
         t_wr[(16 * (r >> 2) + (r & 3)) * V3_TT] = v2[r];
-        t_wr[(32 + 16 * (r >> 2) + (r & 3)) * V3_TT] = fmaf(delta, h1[r], a1[r]);
+        t_wr[(32 + 16 * (r >> 2) + (r & 3)) * V3_TT] = dha[r >> 1][r & 1];
       }
       wave_lds_fence();
       {
@@ -607,17 +691,23 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     //   (delta w_c + sigma (d w_c / d x . q)) J      (BCE part delta J w_c, eikonal part sigma (dw_c/dx . q) J);
     // a miss stages 0 (its eikonal terms would all land on the trash row, where they cancel: sum_c dw_c/dx = 0)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float dwc[3];
-      corner_dw(X, Y, Z, c, dwc);
-      const float cq = a.sigma * (dwc[0] * qv[0] + dwc[1] * qv[1] + dwc[2] * qv[2]);
-      st_w[c * V3_WP] = fmaf(delta, w[c], cq);  // a miss stages 0: w = 0 and dt = 0
+    for (int cp = 0; cp < 4; ++cp) {  // corners (2 cp, 2 cp + 1), packed
+      f32x2 dw[3];
+      corner_dw_pair(X, Y, Z, cp, dw);
+      f32x2 cq = dw[0] * splat2(qv[0]);
+      cq = pk_fma(dw[1], splat2(qv[1]), cq);
+      cq = pk_fma(dw[2], splat2(qv[2]), cq);
+      const f32x2 wp = {w[2 * cp], w[2 * cp + 1]};
+      const f32x2 o = pk_fma(splat2(delta), wp, splat2(a.sigma) * cq);  // a miss stages 0: w = 0 and dt = 0
+      st_w[(2 * cp) * V3_WP] = o[0];
+      st_w[(2 * cp + 1) * V3_WP] = o[1];
     }
     if (g == 0) R2[V3_DL + o_pt] = delta;  // the trash rows need delta J (their weights sum to 1)
     __builtin_amdgcn_sched_barrier(0);  // phase boundary
     SHINE_STAMP(5)  // weight grads
     }
     // ================================================================ phase 6: feature-grad scatter (run-length)
+    if (SHINE_FAR_POS == 2) { SHINE_FAR_TOUCHES }
     f_wr[V3_DF] = sdf2[0];
     f_wr[V3_DF + V3_DFP] = sdf2[1];
     wave_lds_fence();
@@ -706,6 +796,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     SHINE_STAMP(4)  // scatter
   }
 
+  if (FAR) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink));  // every touch has landed: its register may be reused
   // ---- end of the wave's run: flush the open node runs
 #pragma unroll
   for (int s = 0; s < L; ++s) {
@@ -725,10 +816,10 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
         wvec[MLP_W2 + row * H + jc] = accW2[m][0][r];
         wvec[MLP_W2 + row * H + 16 + jc] = accW2[m][1][r];
         if (jc < F || (!EIK && jc == F)) wvec[jc < F ? MLP_W1 + row * F + jc : MLP_B1 + row] = accW1[m][r];  // BCE: column 8 of accW1 is db1
-        const float w3v = row16_sum(dw3c[4 * m + r]);  // channel 16 m + 4 g + r over the 16 points of the DPP row
+        const float w3v = row16_sum(dw3c[2 * m + (r >> 1)][r & 1]);  // channel 16 m + 4 g + r over the 16 points of the DPP row
         if (pt == 0) wvec[MLP_W3 + 16 * m + 4 * g + r] = w3v;
         if (EIK) {
-          const float b2v = row16_sum(db2c[4 * m + r]), b1v = row16_sum(db1c[4 * m + r]);
+          const float b2v = row16_sum(db2c[2 * m + (r >> 1)][r & 1]), b1v = row16_sum(db1c[2 * m + (r >> 1)][r & 1]);
           if (pt == 0) {
             wvec[MLP_B2 + 16 * m + 4 * g + r] = b2v;
             wvec[MLP_B1 + 16 * m + 4 * g + r] = b1v;
@@ -787,6 +878,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     if (tid == 64 && a.zero_f64) *a.zero_f64 = 0.0;
   }
 #undef SHINE_STAMP
+#undef SHINE_FAR_TOUCHES
 #undef SL_N
 #undef SL_PERM
 #undef SL_TOUCHED

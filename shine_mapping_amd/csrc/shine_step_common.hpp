@@ -105,6 +105,20 @@ __device__ __forceinline__ void corner_dw(const Axis& X, const Axis& Y, const Ax
   out[2] = px * py * gz;
 }
 
+// ... and for the corner PAIR (2 cp, 2 cp + 1) — the same (cx, cy), cz = 0 / 1 — as packed values: out[e] = {d w_{2cp} / d x_e,
+// d w_{2cp+1} / d x_e}, every product in corner_dw's association
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void corner_dw_pair(const Axis& X, const Axis& Y, const Axis& Z, int cp, f32x2_t out[3]) {
+  const int cx = (cp >> 1) & 1, cy = cp & 1;
+  const float px = cx ? X.t : 1.0f - X.t, py = cy ? Y.t : 1.0f - Y.t;
+  const float gx = cx ? X.dt : -X.dt, gy = cy ? Y.dt : -Y.dt;
+  const f32x2_t pz = {1.0f - Z.t, Z.t}, gz = {-Z.dt, Z.dt};
+  const float a = gx * py, b = px * gy, c = px * py;
+  out[0] = (f32x2_t){a, a} * pz;
+  out[1] = (f32x2_t){b, b} * pz;
+  out[2] = (f32x2_t){c, c} * gz;
+}
+
 __device__ __forceinline__ Axis axis_weight_rt(bool poly, float x, float res) {
   return poly ? axis_weight<true>(x, res, res * 0.5f) : axis_weight<false>(x, res, res * 0.5f);
 }

@@ -35,10 +35,10 @@
 namespace shine {
 
 // one launch = one step: every workgroup runs its share of the batch (shine_step_body.hpp)
-template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false>
+template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false, bool FAR = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_v3(V1Args a) {
   __shared__ StepShared<WAVES> sm;
-  step_body<L, WAVES, EIK, PROF, EXT, MARK>(a, sm, (int)blockIdx.x, (int)gridDim.x);
+  step_body<L, WAVES, EIK, PROF, EXT, MARK, false, FAR>(a, sm, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // x[l] + y[l ^ 32] style exchanges through v_permlane32_swap / v_permlane16_swap: pins the lane maps xsum32 / xsum16 assume
@@ -67,25 +67,43 @@ long long v3_lds_bytes(int wg_waves) {
          4 * sizeof(double);
 }
 
-// the instantiation a launch uses: {levels, workgroup shape, eikonal term, profiling stamps, external delta, touched-row marks}
+// the instantiation a launch uses: {levels, workgroup shape, eikonal term, profiling stamps, external delta, touched-row marks,
+// FAR = the build for tables beyond the Infinity Cache (full-chip launches of 3- and 4-level trees)}
 template <int L, bool EIK, bool EXT, bool MARK>
-static const void* step_fn_l(int wg_waves, bool prof) {
+static const void* step_fn_l(int wg_waves, bool prof, bool far) {
 #if SHINE_V3_PROFBUILD  // measurement builds only (tools/mk_variant.py -DSHINE_V3_PROFBUILD=1): the per-wave phase counters
-  if (prof && !EXT && !MARK)
+  if (prof && !EXT && !MARK) {
+    if constexpr (L >= 3)
+      if (far && wg_waves == V3_BIG) return (const void*)k_step_v3<L, V3_BIG, EIK, true, false, false, true>;
     return wg_waves == V3_BIG ? (const void*)k_step_v3<L, V3_BIG, EIK, true> : (const void*)k_step_v3<L, 4, EIK, true>;
+  }
 #endif
   (void)prof;
+  if constexpr (L >= 3 && !EXT)
+    if (far && wg_waves == V3_BIG) return (const void*)k_step_v3<L, V3_BIG, EIK, false, false, MARK, true>;
   return wg_waves == V3_BIG ? (const void*)k_step_v3<L, V3_BIG, EIK, false, EXT, MARK>
                             : (const void*)k_step_v3<L, 4, EIK, false, EXT, MARK>;
 }
 template <bool EIK, bool EXT, bool MARK>
-static const void* step_fn(int levels, int wg_waves, bool prof) {
+static const void* step_fn(int levels, int wg_waves, bool prof, bool far = false) {
   switch (levels) {
-    case 1: return step_fn_l<1, EIK, EXT, MARK>(wg_waves, prof);
-    case 2: return step_fn_l<2, EIK, EXT, MARK>(wg_waves, prof);
-    case 3: return step_fn_l<3, EIK, EXT, MARK>(wg_waves, prof);
-    default: return step_fn_l<4, EIK, EXT, MARK>(wg_waves, prof);
+    case 1: return step_fn_l<1, EIK, EXT, MARK>(wg_waves, prof, far);
+    case 2: return step_fn_l<2, EIK, EXT, MARK>(wg_waves, prof, far);
+    case 3: return step_fn_l<3, EIK, EXT, MARK>(wg_waves, prof, far);
+    default: return step_fn_l<4, EIK, EXT, MARK>(wg_waves, prof, far);
   }
+}
+
+// FAR or not: by the size of the feature tables (their gradient tables are as large again, the node records as well) against the
+// 256 MiB Infinity Cache; kernel_variant's low byte overrides (5: FAR, 6: never) for A/B measurements and the parity tests
+constexpr long long FAR_TABLE_BYTES = 256ll << 20;
+static bool far_regime(const shine_step_config* cfg, const int64_t* rows) {
+  const int v = cfg->kernel_variant & 0xff;
+  if (v == 5) return true;
+  if (v == 6) return false;
+  long long bytes = 0;
+  for (int s = 0; s < cfg->n_levels; ++s) bytes += (rows[s] + 1) * (long long)(F * sizeof(float));
+  return bytes > FAR_TABLE_BYTES;
 }
 
 // Everything of a fused-step launch but the launch itself: argument block, kernel instantiation, geometry.  Used by
@@ -122,12 +140,13 @@ int prepare_step_v3(StepLaunch* out, const shine_tables* t, const shine_step_con
   for (int s = 0; s < cfg->n_levels; ++s) mark_in_kernel = mark_in_kernel && a.lv[s].grad != nullptr;
   out->mark_pass = touched && !mark_in_kernel;
   const bool prof = a.prof != nullptr;
+  const bool far = far_regime(cfg, rows);
   if (mark_in_kernel)
-    out->fn = cfg->eikonal_on ? step_fn<true, false, true>(cfg->n_levels, g.wg_waves, prof)
-                              : step_fn<false, false, true>(cfg->n_levels, g.wg_waves, prof);
+    out->fn = cfg->eikonal_on ? step_fn<true, false, true>(cfg->n_levels, g.wg_waves, prof, far)
+                              : step_fn<false, false, true>(cfg->n_levels, g.wg_waves, prof, far);
   else
-    out->fn = cfg->eikonal_on ? step_fn<true, false, false>(cfg->n_levels, g.wg_waves, prof)
-                              : step_fn<false, false, false>(cfg->n_levels, g.wg_waves, prof);
+    out->fn = cfg->eikonal_on ? step_fn<true, false, false>(cfg->n_levels, g.wg_waves, prof, far)
+                              : step_fn<false, false, false>(cfg->n_levels, g.wg_waves, prof, far);
   out->grid = dim3((unsigned)g.blocks);
   out->block = dim3((unsigned)(g.wg_waves * 64));
   out->blocks = (int)g.blocks;
@@ -142,6 +161,14 @@ extern "C" int shine_selftest_permlane(const float* x, const float* y, float* o3
   if (!x || !y || !o32 || !o16) return set_error(SHINE_E_INVALID, "shine_selftest_permlane: null argument");
   hipLaunchKernelGGL(k_selftest_permlane, dim3(1), dim3(64), 0, (hipStream_t)stream, x, y, o32, o16);
   SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
+}
+
+extern "C" int shine_train_step_regime(const shine_step_config* cfg, const int64_t* rows, int64_t n, int32_t* far_out) {
+  if (!cfg || !rows || !far_out) return set_error(SHINE_E_INVALID, "shine_train_step_regime: null argument");
+  if (cfg->n_levels < 1 || cfg->n_levels > LCAP) return set_error(SHINE_E_INVALID, "shine_train_step_regime: 1..4 featured levels");
+  // (the far build exists for full-chip launches of 3- and 4-level trees: step_fn_l)
+  *far_out = far_regime(cfg, rows) && cfg->n_levels >= 3 && v3_geometry(n > 0 ? n : 1).wg_waves == V3_BIG ? 1 : 0;
   return SHINE_OK;
 }
 

@@ -7,6 +7,12 @@
 namespace shine {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// packed fp32 (gfx950: v_pk_fma_f32 / v_pk_mul_f32 do two fp32 operations per lane; a splat operand costs nothing, op_sel
+// broadcasts one half of the source pair)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
 
 constexpr int V3_TP = 16;                      // points per tile
 constexpr int V3_WP = 16;                      // pitch of the [corner][point] staging rows

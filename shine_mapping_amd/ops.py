@@ -39,7 +39,8 @@ class StepOptions:
     zero_f64: Optional[torch.Tensor] = None     # one float64 element cleared by the step (the regulariser's accumulator)
     next_draw: Optional[object] = None          # SortedPool.next_draw(...): the first pass of the NEXT large sorted draw rides on
                                                 # the step's reduction launch; complete it with pool.draw(..., pass1_done=True)
-    kernel_variant: int = 0           # 0 the fused step; tests / tools: 1 the lane-per-point reference kernel
+    kernel_variant: int = 0           # 0 the fused step (5 / 6: its far / near build whatever the table size); tests / tools: 1 the
+                                      # lane-per-point reference kernel
                                       # (libshine_check.so)
 
 
@@ -220,7 +221,7 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         raise ValueError("slots (from dp.plan_batch, or of a batch in visiting order): CUDA int32 [N, L]")
     ws = _workspace(dev, cfg)
     if pending is not None:
-        if variant not in (0, 4) or slots is None:
+        if variant not in (0, 4, 5, 6) or slots is None:
             raise ValueError("pending= (deferred reduction) needs the product kernel on a planned / pool batch")
         cfg.defer_reduce = 1
         pending.clear()

@@ -127,7 +127,7 @@ def test_product_library_holds_the_fused_step_only_and_the_check_library_the_res
     """the product library ships ONE fused-step kernel generation.  The lane-per-point reference kernel
     (kernel_variant 1) lives in libshine_check.so, which tests / tools load explicitly; the product's dispatcher refuses that
     variant (and unplanned batches) instead of silently falling back.  Round 4 deleted the role-specialised experiment
-    (kernel_variant 5, a losing A/B of round 3) from the tree."""
+    (a losing A/B of round 3) from the tree; round 5 gave kernel_variant 5 / 6 to the far / near build of the ONE fused step."""
     from shine_mapping_amd import _lib, build
 
     build.build(verbose=False)
@@ -139,7 +139,7 @@ def test_product_library_holds_the_fused_step_only_and_the_check_library_the_res
     cfg = _lib.StepConfig()
     cfg.n_levels, cfg.max_level = 3, 12
     lib = _lib.lib()
-    for variant, word in ((1, b"check library"), (5, b"unknown kernel_variant"), (0, b"plan")):
+    for variant, word in ((1, b"check library"), (7, b"unknown kernel_variant"), (0, b"plan"), (5, b"plan"), (6, b"plan")):
         cfg.kernel_variant = variant
         rc = lib.shine_train_step(None, ctypes.byref(cfg), None, None, None, None, None, None, 16, None, None, None, None,
                                   None, None, None, None, None, None, 0, None)

@@ -26,8 +26,11 @@ def _workload(kind, levels, frames=8, seed=21, **over):
 
 # BASELINE.json config 2 (2^18 points, 4-level octree, BCE) and config 3 (2^20 points, L=3, eikonal), each with a ragged
 # tail (+37 / +1) so that the last tile is partial.  Reference: shine_batch.py:115-209.
+# variant 5: the build for tables beyond the Infinity Cache (corner ids one tile ahead, next tile's rows touched), forced onto the
+# same small maps — the same arithmetic behind another load schedule.
 @pytest.mark.parametrize("kind,levels,n,variant", [("maicity", 4, (1 << 18) + 37, 0), ("maicity", 3, (1 << 16) + 5, 0),
-                                                   ("kitti", 3, (1 << 20) + 1, 0)])
+                                                   ("kitti", 3, (1 << 20) + 1, 0), ("maicity", 4, (1 << 18) + 37, 5),
+                                                   ("kitti", 3, (1 << 17) + 1, 5)])
 def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n, variant):
     from oracle import shine_oracle as so
     from shine_mapping_amd import StepOptions, fused_train_step

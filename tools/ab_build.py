@@ -14,18 +14,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from shine_mapping_amd import StepOptions, fused_train_step, synth, _lib
 from shine_mapping_amd.sampler import SortedPool
 
-paths = sys.argv[1:]
-# AB_VARIANTS="0,3": every library is timed once per kernel_variant (low byte; 0 = the library's own choice)
+# AB_VARIANTS="0,3": every library is timed once per kernel_variant (low byte; 0 = the library's own choice);
+# "lib.so@5,6" gives one library its own list (e.g. the far / near build of the fused step, whatever the table size)
 variants = [int(v, 0) for v in os.environ.get("AB_VARIANTS", "0").split(",")]
-lib_paths = list(paths)
-paths = ["%s:%d" % (p, v) for p in lib_paths for v in variants]
-handles = []
-for pth in lib_paths:
+lib_paths, paths, handles = [], [], []
+for arg in sys.argv[1:]:
+    pth, _, own = arg.partition("@")
+    lib_paths.append(pth)
     h = C.CDLL(os.path.abspath(pth))
     for name, (res, args) in _lib._SIGNATURES.items():
-        fn = getattr(h, name)
-        fn.restype, fn.argtypes = res, args
-    for v in variants:
+        fn = getattr(h, name, None)  # (an older build may lack the newest entry points)
+        if fn is not None:
+            fn.restype, fn.argtypes = res, args
+    for v in ([int(x, 0) for x in own.split(",")] if own else variants):
+        paths.append("%s:%d" % (pth, v))
         handles.append(h)
 _lib._lib = handles[0]
 kvar = {name: int(name.rsplit(":", 1)[1]) for name in paths}
