@@ -115,6 +115,12 @@ int shine_tables_destroy(shine_tables* t);
 int shine_tables_insert(shine_tables* t, int32_t slot, const int64_t* keys, const int32_t* corner_ids,
                         int64_t n, void* stream);
 int shine_tables_stats(const shine_tables* t, int32_t slot, int64_t* capacity, int64_t* count);
+/* Device arrays a growth replaced (a rehashed table, an outgrown scratch buffer) are not freed on the spot — launches bound to
+ * them may be in flight, and hipFree waits for the whole device — but retired.  shine_tables_retired_bytes reports how much the
+ * handle holds that way; shine_tables_trim frees it.  Call trim only when no launch that was given the OLD arrays can still be
+ * pending (after a device synchronisation, with every iteration graph re-bound since the growth). */
+int shine_tables_retired_bytes(const shine_tables* t, int64_t* bytes);
+int shine_tables_trim(shine_tables* t, int64_t* freed_bytes);
 
 /* ---- octree growth on the device: FeatureOctree.update (model/feature_octree.py:114-166), SURVEY.md §8 f-2.
  *      points[n,3] f32 (device, scaled to [-1,1]) = the frame's surface points.  Inserts every node the frame
@@ -162,7 +168,8 @@ int shine_forward(const shine_tables* t, const shine_step_config* cfg, const flo
  *      sigmoid(sdf_label / sigma)) and its derivative in ONE launch: *loss_out (device float) = the mean (reduction_sum = 0)
  *      or the sum of the per-sample terms, each multiplied by weight[i] when weight != NULL (loss_weight_on);
  *      dpred_out [n] (or NULL) = d loss / d pred — what autograd's backward of the torch composite produces in three more
- *      launches.  One workgroup (the reference's batch sizes are a few thousand points). */
+ *      launches.  One workgroup up to 16384 points (the reference's batch sizes are a few thousand), a grid of them beyond
+ *      (their partial sums meet in fp32 atomics: the last bit of the loss may differ from run to run there). */
 int shine_bce_loss(const float* pred, const float* sdf_label, const float* weight, int64_t n, float sigma,
                    int32_t reduction_sum, float* loss_out, float* dpred_out, void* stream);
 

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "shine_tables_destroy": (C.c_int, [_P]),
     "shine_tables_insert": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, _P]),
     "shine_tables_stats": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "shine_tables_retired_bytes": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "shine_tables_trim": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "shine_query_indices": (C.c_int, [_P, C.POINTER(StepConfig), _P, C.c_int64, C.POINTER(_P), _P]),
     "shine_forward": (
         C.c_int,

@@ -251,8 +251,9 @@ class FusedMLPBackward(torch.autograd.Function):
 # The fused node may take a batch whose `coord` asks for a gradient (the eikonal configurations: coord.requires_grad_(True),
 # shine_batch.py:119-120) only if g = d pred / d coord is then obtained through losses.get_gradient — the fused counterpart of
 # utils/tools.py:175-185 that dropin installs under the reference's name.  torch.autograd.grad(create_graph=True) straight
-# through the fused node is refused (its backward is one non-differentiable launch), so without that function the eikonal
-# configurations keep the split, twice-differentiable nodes.
+# through the fused node still works — its backward then recomputes through the split, twice-differentiable nodes
+# (_fused_split_backward) — but costs what the split nodes cost, so without that function the eikonal configurations keep the
+# split nodes from the start.
 FUSE_WITH_COORD_GRAD = False
 
 
@@ -322,10 +323,10 @@ class FusedInterpSdf(torch.autograd.Function):
         from .ops import _workspace
 
         if torch.is_grad_enabled():
-            raise RuntimeError("FusedInterpSdf: a differentiable backward (torch.autograd.grad(..., create_graph=True)) through "
-                               "the fused query_feature -> sdf node: use shine_mapping_amd.losses.get_gradient (installed as "
-                               "utils.tools.get_gradient by shine_mapping_amd.dropin), or set "
-                               "autograd_ops.FUSE_WITH_COORD_GRAD = False to keep the split nodes")
+            # a DIFFERENTIABLE backward was asked for — torch.autograd.grad(..., create_graph=True) straight through this node,
+            # e.g. the reference's own get_gradient (utils/tools.py:175-185) in a driver that bound it before dropin re-bound
+            # the name.  The one fused launch below is not differentiable; the split nodes are: recompute through them.
+            return FusedInterpSdf._split_backward(ctx, g)
         coord, *params = ctx.saved_tensors
         octree, src = ctx.octree, ctx.src
         q, src.q = src.q, None
@@ -364,6 +365,30 @@ class FusedInterpSdf(torch.autograd.Function):
             "shine_interp_sdf_backward",
         )
         return (None, None, None, None, None) + tuple(views)
+
+
+def _fused_split_backward(ctx, g):
+    """backward of FusedInterpSdf through OctreeInterp -> FusedMLP (twice differentiable, one kernel per derivative): the
+    gradients come back attached to the split nodes' graph, so whatever the caller builds on them differentiates as it would
+    have without the fusion"""
+    coord, *params = ctx.saved_tensors
+    octree = ctx.octree
+    L = octree.featured_level_num
+    if g is None:
+        return (None,) * (5 + len(params))
+    need = [bool(ctx.needs_input_grad[1])] + [bool(x) for x in ctx.needs_input_grad[5:]]
+    cand = [coord] + list(params)
+    with torch.enable_grad():
+        feat = OctreeInterp.apply(coord, octree, *params[:L])
+        octree.__dict__.pop("_spec_result", None)  # (OctreeInterp's speculated decoder output belongs to no FeatureSource here)
+        pred = FusedMLP.apply(feat, *params[L:])
+        wanted = [t for t, n in zip(cand, need) if n and t.requires_grad]
+        got = iter(torch.autograd.grad(pred, wanted, g, create_graph=True, allow_unused=True)) if wanted else iter(())
+    grads = [next(got) if (n and t.requires_grad) else None for t, n in zip(cand, need)]
+    return (None, grads[0], None, None, None) + tuple(grads[1:])
+
+
+FusedInterpSdf._split_backward = staticmethod(_fused_split_backward)
 
 
 class InterpSdfGradCoord(torch.autograd.Function):

@@ -208,13 +208,16 @@ __global__ __launch_bounds__(256) void k_query_indices(FwdArgs a) {
 }
 
 // sdf_bce_loss (utils/loss.py:17-24): BCEWithLogits(pred, sigmoid(label / sigma)) [x weight], mean or sum, AND its derivative
-// d loss / d pred in the same launch (what autograd would compute in three more).  One workgroup: the reference's batch sizes are
-// a few thousand points, a grid-wide sum would cost a second launch or same-address atomics.
+// d loss / d pred in the same launch (what autograd would compute in three more).  One workgroup at the reference's batch sizes
+// (a few thousand points: a grid-wide sum would cost a second launch); large Tier-A batches (2^16 .. 2^20 points) run MULTI
+// workgroups, whose fp64 partial sums meet in one fp32 atomic each on the pre-zeroed result (<= 256 terms).
+template <bool MULTI>
 __global__ __launch_bounds__(1024) void k_bce_loss(const float* pred, const float* label, const float* weight, long long n,
                                                    float sigma, float scale, float* loss_out, float* dpred_out) {
   __shared__ double s_red[16];
   double acc = 0.0;
-  for (long long i = threadIdx.x; i < n; i += 1024) {
+  const long long stride = MULTI ? (long long)gridDim.x * 1024 : 1024;
+  for (long long i = (MULTI ? (long long)blockIdx.x * 1024 : 0) + threadIdx.x; i < n; i += stride) {
     const float y = pred[i];
     const float z = 1.0f / (1.0f + expf(-(label[i] / sigma)));  // torch.sigmoid(label / sigma), utils/loss.py:23
     const float w = weight ? weight[i] : 1.0f;
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(1024) void k_bce_loss(const float* pred, const floa
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int k = 0; k < 16; ++k) tot += s_red[k];
-    *loss_out = (float)(tot * (double)scale);
+    if (MULTI) atomicAdd(loss_out, (float)(tot * (double)scale));
+    else *loss_out = (float)(tot * (double)scale);
   }
 }
 
@@ -295,8 +299,17 @@ extern "C" int shine_bce_loss(const float* pred, const float* sdf_label, const f
                               int32_t reduction_sum, float* loss_out, float* dpred_out, void* stream) {
   if (n < 1 || !pred || !sdf_label || !loss_out || !(sigma > 0.f))
     return set_error(SHINE_E_INVALID, "shine_bce_loss: bad argument");
-  hipLaunchKernelGGL(k_bce_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, sdf_label, weight, (long long)n,
-                     sigma, reduction_sum ? 1.0f : 1.0f / (float)n, loss_out, dpred_out);
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = reduction_sum ? 1.0f : 1.0f / (float)n;
+  if (n <= 16384) {
+    hipLaunchKernelGGL(k_bce_loss<false>, dim3(1), dim3(1024), 0, st, pred, sdf_label, weight, (long long)n, sigma, scale, loss_out,
+                       dpred_out);
+  } else {  // (2^18 .. 2^20 points on ONE compute unit otherwise)
+    SHINE_HIP_CHECK(hipMemsetAsync(loss_out, 0, sizeof(float), st));
+    const long long blocks = (n + 4095) / 4096;
+    hipLaunchKernelGGL(k_bce_loss<true>, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(1024), 0, st, pred, sdf_label, weight,
+                       (long long)n, sigma, scale, loss_out, dpred_out);
+  }
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }

@@ -203,11 +203,13 @@ static int ensure(shine_tables* t, void** ptr, size_t* have, size_t need, hipStr
   (void)st;
   if (need <= *have) return SHINE_OK;
   if (*ptr) {
-    t->retired.push_back(*ptr);  // (launches that read it may still be in flight: no free, no sync — shine_internal.hpp)
+    t->retire(*ptr, *have);  // (launches that read it may still be in flight: no free, no sync — shine_internal.hpp)
     *ptr = nullptr;
     *have = 0;
   }
-  const size_t want = 2 * need;
+  // headroom so that the next frames do not outgrow it again: the need again, but at most 64 MiB (a 10^7-row map's
+  // scratch is hundreds of MB, and doubling it held that much idle)
+  const size_t want = need + (need < ((size_t)64 << 20) ? need : ((size_t)64 << 20));
   if (hipMalloc(ptr, want) != hipSuccess) return set_error(SHINE_E_NOMEM, "shine_tables_grow: scratch allocation failed");
   *have = want;
   return SHINE_OK;
@@ -233,8 +235,8 @@ static int corner_reserve(shine_tables* t, CornerLevel& Cn, long long need, hipS
     hipLaunchKernelGGL(k_rehash_corners, dim3((unsigned)((Cn.cap + 255) / 256)), dim3(256), 0, st, Cn.keys, Cn.vals,
                        Cn.cap, keys, vals, shift, mask);
     SHINE_HIP_CHECK(hipGetLastError());
-    t->retired.push_back(Cn.keys);
-    t->retired.push_back(Cn.vals);
+    t->retire(Cn.keys, (size_t)Cn.cap * 8);
+    t->retire(Cn.vals, (size_t)Cn.cap * 4);
   }
   Cn.keys = keys;
   Cn.vals = vals;

@@ -74,13 +74,20 @@ int set_hip_error(hipError_t e, const char* what);
 struct shine_tables {
   // Device arrays a growth replaced (a rehashed table, an outgrown scratch buffer): kept until the handle is destroyed instead
   // of being freed on the spot.  hipFree waits for the whole device and was measured at 40-68 ms inside an incremental run whose
-  // frames take 3.4 ms; the arrays double, so what is retired never exceeds what is live.
+  // frames take 3.4 ms; the arrays double, so what is retired never exceeds what is live.  shine_tables_trim frees them once
+  // the caller knows that no launch bound to them is pending.
   std::vector<void*> retired;
   int n_levels = 0;
   long long n_buckets = 0;  // nodes of all featured levels + 1 ("misses everywhere"); 0: ranks not set
   shine::TableLevel lv[SHINE_MAX_LEVELS];
   shine::CornerLevel cl[SHINE_MAX_LEVELS];
   shine::GrowScratch grow;
+  long long retired_bytes = 0;
+  void retire(void* p, size_t bytes) {
+    if (!p) return;
+    retired.push_back(p);
+    retired_bytes += (long long)bytes;
+  }
 };
 
 #define SHINE_HIP_CHECK(expr)                                      \

@@ -129,6 +129,21 @@ extern "C" int shine_tables_destroy(shine_tables* t) {
   return SHINE_OK;
 }
 
+extern "C" int shine_tables_retired_bytes(const shine_tables* t, int64_t* bytes) {
+  if (!t || !bytes) return set_error(SHINE_E_INVALID, "shine_tables_retired_bytes: null argument");
+  *bytes = t->retired_bytes;
+  return SHINE_OK;
+}
+
+extern "C" int shine_tables_trim(shine_tables* t, int64_t* freed_bytes) {
+  if (!t) return set_error(SHINE_E_INVALID, "shine_tables_trim: null handle");
+  for (void* p : t->retired) (void)hipFree(p);
+  if (freed_bytes) *freed_bytes = t->retired_bytes;
+  t->retired.clear();
+  t->retired_bytes = 0;
+  return SHINE_OK;
+}
+
 extern "C" int shine_tables_stats(const shine_tables* t, int32_t slot, int64_t* capacity, int64_t* count) {
   if (!t || slot < 0 || slot >= t->n_levels) return set_error(SHINE_E_INVALID, "bad table/slot");
   if (capacity) *capacity = t->lv[slot].cap;
@@ -155,9 +170,9 @@ extern "C" int shine_tables_insert(shine_tables* t, int32_t slot, const int64_t*
       hipLaunchKernelGGL(k_rehash, dim3((unsigned)((L.cap + 255) / 256)), dim3(256), 0, st, L.keys, L.vals,
                          (long long)L.cap, fresh.keys, fresh.vals, fresh.shift, fresh.mask);
       SHINE_HIP_CHECK(hipGetLastError());
-      t->retired.push_back(L.keys);  // (no free on the spot: shine_internal.hpp)
-      t->retired.push_back(L.vals);
-      t->retired.push_back(L.ranks);
+      t->retire(L.keys, (size_t)L.cap * sizeof(unsigned long long));  // (no free on the spot: shine_internal.hpp)
+      t->retire(L.vals, (size_t)L.cap * 8 * sizeof(int));
+      t->retire(L.ranks, (size_t)L.cap * sizeof(int));
     }
     fresh.count = L.count;
     L = fresh;

@@ -194,6 +194,11 @@ class FeatureOctree(nn.Module):
         coordinates of the last query — cal_regularization (:246-255) and the mesher (utils/mesher.py:82,102) read them."""
         d = self.__dict__
         if d.get("_hidx") is None and d.get("_hidx_coord") is not None:
+            if d.get("_hidx_epoch") != self._tables_epoch:
+                # the reference's list is computed AT query time and holds -1 for nodes that did not exist then (:199-218);
+                # a lazy evaluation against the grown tables would silently differ
+                raise RuntimeError("hierarchical_indices of a query made before update() grew the octree: they are computed on "
+                                   "first access — read them before update(), or call get_indices(coord) again")
             coord, d["_hidx_coord"] = d["_hidx_coord"], None
             self.get_indices(coord)
         return d.get("_hidx") if d.get("_hidx") is not None else []
@@ -206,6 +211,7 @@ class FeatureOctree(nn.Module):
     def _defer_indices(self, coord):
         self.__dict__["_hidx"] = None
         self.__dict__["_hidx_coord"] = coord.detach()
+        self.__dict__["_hidx_epoch"] = self._tables_epoch
 
     # ------------------------------------------------------------------ :78-81
     def set_zero(self):
@@ -371,6 +377,7 @@ class FeatureOctree(nn.Module):
         if side is not main:
             self._ev_grown.record(side)
             main.wait_event(self._ev_grown)  # the appends, plans and steps queued from here on see the grown tables
+            flat.record_stream(main)  # (allocated in the side stream's pool, read on the caller's: _drain_dev_frames / _sync_host)
         stream = main.cuda_stream
         self._dev_frames.append((flat, nf, na))
         self._sort_box_cache = None
@@ -386,6 +393,31 @@ class FeatureOctree(nn.Module):
         if side is main:
             self._ranks_uploaded = False
         self._tables_epoch += 1
+        if self.retired_table_bytes() > self.trim_retired_above:
+            self.trim_tables()
+
+    # Device arrays a growth replaced are retired inside the handle, not freed (launches bound to them may be queued, and hipFree
+    # waits for the whole device).  They never exceed the live tables (capacities double), but on a 10^7-row map that is still
+    # hundreds of MB: above this many bytes update() synchronises the device once and frees them.
+    trim_retired_above = 1 << 30
+
+    def retired_table_bytes(self) -> int:
+        if self._tables is None:
+            return 0
+        b = C.c_int64()
+        _lib.check(_lib.lib().shine_tables_retired_bytes(self._tables.handle, C.byref(b)), "shine_tables_retired_bytes")
+        return int(b.value)
+
+    def trim_tables(self) -> int:
+        """Free the arrays earlier growths replaced.  Synchronises the device first: every launch that was handed the old arrays
+        — also those of an iteration graph bound before the growth — has then finished (graphs are re-bound to the handle's
+        live arrays when the next frame's iterations are set up)."""
+        if self._tables is None:
+            return 0
+        torch.cuda.synchronize(self.hier_features[0].device if len(self.hier_features) else None)
+        b = C.c_int64()
+        _lib.check(_lib.lib().shine_tables_trim(self._tables.handle, C.byref(b)), "shine_tables_trim")
+        return int(b.value)
 
     def enable_async_growth(self, stream=None):
         """Let update() grow the tree on a stream of its own (`growth_stream`), so that a loop which keeps the host ahead of the

@@ -16,16 +16,42 @@ from .dp import plan_batch
 from .ops import StepOptions, _dense_grad
 
 # scratch of the sweep (the chunks' private gradient tables and row flags): zero on entry, left zero by the call, so ONE buffer per
-# device is kept and re-used by every frame, whatever the octree's size was when it was allocated
+# device is kept and re-used from frame to frame.  It is sized for the map at hand (+ 1/8 so that a growing map does not
+# re-allocate every frame), dropped when the map needs less than half of it, capped by SCRATCH_BUDGET_BYTES and by a quarter of
+# the device memory that is free when it is (re)allocated — fewer chunks per launch then, not more memory — and
+# release_scratch() hands it back.
 _SCRATCH = {}
+_BUDGET = {}
 SCRATCH_BUDGET_BYTES = 2 << 30
+
+
+def _scratch_budget(dev) -> int:
+    b = _BUDGET.get(dev)
+    if b is None:  # (asked of the driver once per (re)allocation, not once per frame)
+        held = _SCRATCH.get(dev)
+        free = torch.cuda.mem_get_info(dev)[0] + (held.numel() if held is not None else 0)
+        b = _BUDGET[dev] = int(max(64 << 20, min(SCRATCH_BUDGET_BYTES, free // 4)))
+    return b
 
 
 def _zero_scratch(dev, nbytes):
     buf = _SCRATCH.get(dev)
-    if buf is None or buf.numel() < nbytes:
-        buf = _SCRATCH[dev] = torch.zeros(nbytes + nbytes // 2, dtype=torch.uint8, device=dev)
+    if buf is None or buf.numel() < nbytes or buf.numel() > 2 * nbytes + (16 << 20):
+        _SCRATCH.pop(dev, None)
+        buf = None  # (the old buffer goes back to the allocator before the new one is asked for)
+        buf = _SCRATCH[dev] = torch.zeros(nbytes + nbytes // 8, dtype=torch.uint8, device=dev)
+        _BUDGET.pop(dev, None)
     return buf
+
+
+def release_scratch(dev=None):
+    """Give the sweep's scratch buffer(s) back to torch's allocator (kept otherwise for the life of the process)."""
+    if dev is None:
+        _SCRATCH.clear()
+        _BUDGET.clear()
+    else:
+        _SCRATCH.pop(torch.device(dev), None)
+        _BUDGET.pop(torch.device(dev), None)
 
 
 def chunk_partition(perm, sample_count, batch_interval, down_rate):
@@ -94,7 +120,7 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
     torch._foreach_zero_([_dense_grad(f) for f in octree.hier_features])
     rows = octree.row_counts()
     group, scratch_bytes, ws_bytes = C.c_int32(), C.c_size_t(), C.c_size_t()
-    _lib.check(lib.shine_importance_sweep_sizes(len(octree.hier_features), rows, iter_n, max_chunk, SCRATCH_BUDGET_BYTES,
+    _lib.check(lib.shine_importance_sweep_sizes(len(octree.hier_features), rows, iter_n, max_chunk, _scratch_budget(dev),
                                                 C.byref(group), C.byref(scratch_bytes), C.byref(ws_bytes)),
                "shine_importance_sweep_sizes")
     scratch = _zero_scratch(dev, scratch_bytes.value)

@@ -31,6 +31,71 @@ class FusedAdam:
         self._dev = None  # (step_state int64[8], lr float[n]) for graph-replayable steps
         self._dev_params = []  # the tensors those steps update (the set the device-side counter counts for)
 
+    # ------------------------------------------------------------------ torch.optim.Optimizer's checkpoint interface
+    # (utils/tools.py:200-213: save_checkpoint stores optimizer.state_dict(); shine_batch.py:232, shine_incre.py)
+    _DEFAULTS = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     decoupled_weight_decay=False)
+
+    def state_dict(self):
+        """torch.optim.Adam's layout: {"state": {index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} with the
+        parameters numbered across the groups in order — torch.optim.Adam(groups).load_state_dict() accepts it.  Steps a graph
+        took on the device are counted in (read from the device-side counter; the graph-replayable state stays live)."""
+        extra = {}
+        if self._dev is not None:
+            more = self.steps_taken() - self.step_count
+            extra = {id(p): more for p in self._dev_params}
+        state, groups, k = {}, [], 0
+        for g in self.param_groups:
+            idx = []
+            for p in g["params"]:
+                st = self.state.get(p)
+                age = self._age.get(p, 0) + extra.get(id(p), 0)
+                if st is not None and age > 0:  # (torch creates a parameter's state at its first step)
+                    state[k] = {"step": torch.tensor(float(age)), "exp_avg": st[0], "exp_avg_sq": st[1]}
+                idx.append(k)
+                k += 1
+            d = {key: val for key, val in g.items() if key != "params"}
+            d.setdefault("betas", tuple(self.betas))
+            d.setdefault("eps", self.eps)
+            for key, val in self._DEFAULTS.items():
+                d.setdefault(key, val)
+            d["params"] = idx
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        """The inverse (also of a torch.optim.Adam state_dict over the same groups): moments are copied to the parameters'
+        devices, the groups' hyper-parameters (lr, weight_decay) are taken over."""
+        saved = sd["param_groups"]
+        if len(saved) != len(self.param_groups) or any(len(a["params"]) != len(b["params"])
+                                                       for a, b in zip(saved, self.param_groups)):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+        if self._dev is not None:
+            self._fold_device_steps()
+        params = {}
+        for sg, g in zip(saved, self.param_groups):
+            for i, p in zip(sg["params"], g["params"]):
+                params[i] = p
+            for key, val in sg.items():
+                if key == "params":
+                    continue
+                if key == "betas":
+                    self.betas = tuple(val)
+                elif key == "eps":
+                    self.eps = float(val)
+                elif key in ("lr", "weight_decay") or key not in self._DEFAULTS:
+                    g[key] = val
+        self.state, self._age = {}, {}
+        for i, st in sd["state"].items():
+            p = params[int(i)]
+            m = st["exp_avg"].detach().to(device=p.device, dtype=p.dtype).contiguous().clone()
+            v = st["exp_avg_sq"].detach().to(device=p.device, dtype=p.dtype).contiguous().clone()
+            if m.shape != p.shape or v.shape != p.shape:
+                raise ValueError("optimiser state of parameter %d has another shape" % int(i))
+            self.state[p] = (m, v)
+            self._age[p] = int(float(st["step"]))
+        self.step_count = max(self._age.values(), default=0)
+
     def _tensors(self):
         out = []
         for g in self.param_groups:
