@@ -255,6 +255,9 @@ class FusedMLPBackward(torch.autograd.Function):
 # (_fused_split_backward) — but costs what the split nodes cost, so without that function the eikonal configurations keep the
 # split nodes from the start.
 FUSE_WITH_COORD_GRAD = False
+# tests: the fused node's backward as ONE wave walking the batch, so that every feature-grad atomic is applied in stream order and
+# an Adam trajectory through Tier A is reproducible to the bit (StepOptions.deterministic is Tier B's switch for the same launch)
+DETERMINISTIC_BACKWARD = False
 
 
 class FeatureSource:
@@ -350,7 +353,8 @@ class FusedInterpSdf(torch.autograd.Function):
             off += sz
         mlp_c = [_f32c(p) for p in mlp]
         feats_c = [_f32c(p) for p in feats]
-        cfg = octree.step_config(sorted_input=1, decoder_grad_on=1 if need_m else 0)
+        cfg = octree.step_config(sorted_input=1, decoder_grad_on=1 if need_m else 0,
+                                 kernel_variant=0x4000 if DETERMINISTIC_BACKWARD else 0)
         ws = _workspace(dev, cfg)
         _lib.check(
             _lib.lib().shine_interp_sdf_backward(
@@ -424,6 +428,102 @@ class InterpSdfGradCoord(torch.autograd.Function):
             q = _f32c(gq)
             ctx.src.q = q if ctx.src.q is None else ctx.src.q + q
         return (None,) * ctx.n_in
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Tier A: FeatureOctree.cal_regularization as a node (the incremental configuration through the unchanged shine_incre.py)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class OctreeRegularizer(torch.autograd.Function):
+    """reg = sum_levels sum_{u in unique(hierarchical_indices)} importance[u] (F[u] - F_last[u])^2  — cal_regularization,
+    model/feature_octree.py:246-255, called once per iteration by shine_incre.py:152-158 — for the coordinates of the octree's
+    last query_feature.  The reference finds the rows with a sort-based unique() of 8 N int64 per level and runs three gathers;
+    here one launch marks the rows the query's nodes address (shine_mark_touched: byte flags) and one row-parallel launch
+    evaluates the sum on the flagged rows and clears the flags again (shine_regularize).
+    Gradient: only the levels whose features_last_frame is still a DETACHED copy receive one (from the second frame on the
+    reference stores an attached clone of the Parameter, :160, and d reg / d F cancels) — 2 importance (F - F_last) on the
+    flagged rows, evaluated by the same kernel in backward.  The tensors themselves say which (levels_with_gradient)."""
+
+    @staticmethod
+    def levels_with_gradient(octree):
+        """per level: True (features_last_frame is detached: the gradient is live), False (an attached clone of this level's
+        Parameter: it cancels) — or None for a state this node does not cover (the copy requires grad through something else)"""
+        on = []
+        for last, p in zip(octree.features_last_frame, octree.hier_features):
+            if not last.requires_grad:
+                on.append(True)
+                continue
+            fn = last.grad_fn
+            nf = fn.next_functions if fn is not None else ()
+            if fn is None or not type(fn).__name__.startswith("CloneBackward") or len(nf) != 1 \
+                    or getattr(nf[0][0], "variable", None) is not p:
+                return None
+            on.append(False)
+        return on
+
+    @staticmethod
+    def forward(ctx, octree, coord, *feats):
+        from .ops import touched_flags
+
+        L = octree.featured_level_num
+        t = octree._require_tables()
+        c = octree._check_coord(coord.detach())
+        dev = c.device
+        rows = octree.row_counts()
+        flags = octree.__dict__.get("_reg_flags")
+        if flags is None or any(f.shape[0] != p.shape[0] or f.device != dev for f, p in zip(flags, feats)):
+            flags = octree.__dict__["_reg_flags"] = touched_flags(octree)
+            octree.__dict__["_reg_flags_dirty"] = False
+        if octree.__dict__.get("_reg_flags_dirty"):  # a forward whose backward never came left its rows flagged
+            for f in flags:
+                f.zero_()
+            octree.__dict__["_reg_flags_dirty"] = False
+        lib = _lib.lib()
+        cfg = octree.step_config()
+        _lib.check(lib.shine_mark_touched(t.handle, C.byref(cfg), c.data_ptr(), None, None, c.shape[0], rows,
+                                          _lib.ptr_array([f.data_ptr() for f in flags]), _stream()), "shine_mark_touched")
+        live = OctreeRegularizer.levels_with_gradient(octree)
+        need_grad = any(bool(n) and bool(on) for n, on in zip(ctx.needs_input_grad[2:], live))
+        feats_c = [_f32c(p) for p in feats]
+        last = [_f32c(x.detach()) for x in octree.features_last_frame]
+        imp = [_f32c(x) for x in octree.importance_weight]
+        out = torch.empty(1, dtype=torch.float64, device=dev)
+        off = (C.c_int32 * L)(*([0] * L))
+        _lib.check(
+            lib.shine_regularize(L, _lib.ptr_array([x.data_ptr() for x in feats_c]), _lib.ptr_array([x.data_ptr() for x in last]),
+                                 _lib.ptr_array([x.data_ptr() for x in imp]), _null_ptrs(L),
+                                 _lib.ptr_array([f.data_ptr() for f in flags]), rows, off, 0.0, out.data_ptr(), 0,
+                                 1 if need_grad else 0, _stream()),
+            "shine_regularize")
+        if need_grad:  # the flagged rows are needed again: backward clears them
+            octree.__dict__["_reg_flags_dirty"] = True
+            ctx.octree, ctx.flags, ctx.keep, ctx.live = octree, flags, (feats_c, last, imp), live
+        ctx.need_grad = need_grad
+        return out[0].to(torch.float32)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        n_in = 2 + len(ctx.needs_input_grad[2:])
+        if not ctx.need_grad or g is None:
+            return (None,) * n_in
+        octree, flags = ctx.octree, ctx.flags
+        feats_c, last, imp = ctx.keep
+        L = octree.featured_level_num
+        on = [bool(n) and bool(o) for n, o in zip(ctx.needs_input_grad[2:], ctx.live)]
+        grads = [torch.zeros_like(p) if o else None for p, o in zip(feats_c, on)]
+        scratch = torch.empty(1, dtype=torch.float64, device=feats_c[0].device)
+        _lib.check(
+            _lib.lib().shine_regularize(
+                L, _lib.ptr_array([x.data_ptr() for x in feats_c]), _lib.ptr_array([x.data_ptr() for x in last]),
+                _lib.ptr_array([x.data_ptr() for x in imp]), _lib.ptr_array([x.data_ptr() if x is not None else None for x in grads]),
+                _lib.ptr_array([f.data_ptr() for f in flags]), octree.row_counts(), (C.c_int32 * L)(*[1 if o else 0 for o in on]),
+                1.0, scratch.data_ptr(), 0, 0, _stream()),
+            "shine_regularize")
+        octree.__dict__["_reg_flags_dirty"] = False
+        gf = g.to(torch.float32)
+        return (None, None) + tuple(x * gf if x is not None else None for x in grads)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -37,7 +37,10 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 // and — once they are back — every feature row and every gradient row of tile t + 1 is TOUCHED (one dword load per row into a
 // register nobody reads), so that the gather and the atomics of tile t + 1 find their lines in the L2.
 #ifndef SHINE_FAR_TOUCH
-#define SHINE_FAR_TOUCH 2  // 0: ids ahead only, 1: + touch the feature rows, 2: + touch the gradient rows
+#define SHINE_FAR_TOUCH 0  // 0: ids ahead only, 1: + touch the feature rows, 2: + touch the gradient rows
+#endif
+#ifndef SHINE_FAR_NT
+#define SHINE_FAR_NT 0  // 1: the far build's row gathers carry the nontemporal hint
 #endif
 #ifndef SHINE_FAR_POS
 #define SHINE_FAR_POS 0  // where the touches are issued: 0 after the decoder's forward, 1 after its backward, 2 in front of the scatter
@@ -321,8 +324,15 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
 #pragma unroll
         for (int c = 0; c < V3_GB; ++c) {  // a miss reads row 0 with weight 0 (no branches)
           const float* row = lv_feat + (size_t)(hit ? (unsigned int)ids[cb + c] : 0u) * F;
-          r0[c] = *reinterpret_cast<const float4*>(row);
-          r1[c] = *reinterpret_cast<const float4*>(row + 4);
+          if (FAR && SHINE_FAR_NT) {
+            const f32x4 a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row));
+            const f32x4 a1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + 4));
+            r0[c] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+            r1[c] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+          } else {
+            r0[c] = *reinterpret_cast<const float4*>(row);
+            r1[c] = *reinterpret_cast<const float4*>(row + 4);
+          }
         }
 #pragma unroll
         for (int cp = 0; cp < V3_GB; cp += 2) {  // corners (cb + cp, cb + cp + 1): the same (cx, cy), cz = 0 / 1

@@ -232,7 +232,12 @@ extern "C" int shine_interp_sdf_backward(const shine_tables* t, const shine_step
   a.ext_delta = grad_pred;
   a.ext_q = grad_g;
   a.inv_n = 1.0f;
-  const V2Geometry g = v3_geometry(n);
+  V2Geometry g = v3_geometry(n);
+  if (a.ablate & 64) {  // kernel_variant bit 0x4000: the deterministic (single-wave) launch of the test suite, as in prepare_step_v3
+    g.blocks = 1;
+    g.wg_waves = 4;
+    g.waves = 4;
+  }
   a.tiles = g.tiles;
   a.waves_total = g.waves;
   const size_t need = (size_t)g.blocks * PART_STRIDE * sizeof(float);

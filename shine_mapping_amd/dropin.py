@@ -12,7 +12,7 @@ Only these two modules are replaced — `dataset.*` and the rest of `model.*` ke
 side effect worth having: the reference's `model/feature_octree.py` (and with it the kaolin import at `:6`) is never executed
 on the training path.
 
-Three FUNCTIONS of the reference's own `utils` modules are additionally re-bound (the drivers pick them up through
+Four FUNCTIONS of the reference's own `utils` modules are additionally re-bound (the drivers pick them up through
 `from utils.tools import *` / `from utils.loss import *`, shine_batch.py:14-15), each falling back to the reference's original
 for anything it does not cover, each with an opt-out environment variable (= "0"):
 
@@ -22,6 +22,13 @@ for anything it does not cover, each with an opt-out environment variable (= "0"
     utils.tools.get_gradient     ->  losses.get_gradient: for the fused query_feature -> sdf node ONE forward-kernel launch,
                                      linked to that node so that the eikonal term's backward joins its single fused launch
                                      (lets the eikonal configurations use the fused node)            SHINE_DROPIN_FUSED_GRADIENT
+
+    utils.incre_learning.cal_feature_importance -> incre_learning.cal_feature_importance: the chunk loop of
+                                     utils/incre_learning.py:8-40 as two launches per 64 chunks (shine_incre.py:185-188 imports
+                                     it after this module, so the driver's name binds to it)   SHINE_DROPIN_FUSED_IMPORTANCE
+
+`FeatureOctree.cal_regularization` (shine_incre.py:156) needs no re-binding: it is a method of the replaced class, and runs as one
+autograd node over two launches whenever it follows a `query_feature` (autograd_ops.OctreeRegularizer).
 
 The re-binding needs `utils.tools` / `utils.loss` to be importable when this module is imported (the drivers import it from the
 reference's root directory, first line); `patch_utils()` can be called again later, `status()` says what is in place.
@@ -119,6 +126,31 @@ def patch_utils():
             ut.get_gradient = ut._shine_reference["get_gradient"]
             autograd_ops.FUSE_WITH_COORD_GRAD = False
             _STATUS["get_gradient"] = "off (SHINE_DROPIN_FUSED_GRADIENT=0)"
+    try:  # (imports dataset.lidar_dataset, i.e. open3d: present wherever the drivers themselves run)
+        ui = importlib.import_module("utils.incre_learning")
+    except Exception as e:
+        ui = None
+        _STATUS["utils.incre_learning"] = "not importable: %r" % (e,)
+    if ui is not None:
+        if not hasattr(ui, "_shine_reference"):
+            ui._shine_reference = {"cal_feature_importance": ui.cal_feature_importance}
+        ref_sweep = ui._shine_reference["cal_feature_importance"]
+        if _on("SHINE_DROPIN_FUSED_IMPORTANCE"):
+            from . import incre_learning
+
+            def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduction='mean', loss_weight_on=False):
+                if (isinstance(octree, FeatureOctree) and isinstance(mlp, Decoder) and mlp.fusable and len(octree.hier_features)
+                        and octree.hier_features[0].is_cuda and octree.featured_level_num <= 4):
+                    return incre_learning.cal_feature_importance(data, octree, mlp, sigma, bs, down_rate, loss_reduction,
+                                                                 loss_weight_on)
+                return ref_sweep(data, octree, mlp, sigma, bs, down_rate, loss_reduction, loss_weight_on)
+
+            cal_feature_importance.__doc__ = "shine_mapping_amd drop-in for utils.incre_learning.cal_feature_importance (:8-40)"
+            ui.cal_feature_importance = cal_feature_importance
+            _STATUS["cal_feature_importance"] = True
+        else:
+            ui.cal_feature_importance = ref_sweep
+            _STATUS["cal_feature_importance"] = "off (SHINE_DROPIN_FUSED_IMPORTANCE=0)"
     if ul is not None:
         if _on("SHINE_DROPIN_FUSED_LOSS"):
             ul.sdf_bce_loss = losses.sdf_bce_loss
@@ -139,7 +171,7 @@ def uninstall():
     for attr in ("feature_octree", "decoder"):
         if pkg is not None and (getattr(getattr(pkg, attr, None), "__doc__", "") or "").startswith("shine_mapping_amd"):
             delattr(pkg, attr)
-    for name in ("utils.tools", "utils.loss"):  # the reference's own functions back in place
+    for name in ("utils.tools", "utils.loss", "utils.incre_learning"):  # the reference's own functions back in place
         mod = sys.modules.get(name)
         for attr, fn in getattr(mod, "_shine_reference", {}).items():
             setattr(mod, attr, fn)

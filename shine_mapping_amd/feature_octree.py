@@ -679,6 +679,24 @@ class FeatureOctree(nn.Module):
 
     # ------------------------------------------------------------------ :246-255
     def cal_regularization(self):
+        """shine_incre.py:152-158 calls this right after `feature = octree.query_feature(coord)`: the rows of THAT query are what
+        the reference's unique(hierarchical_indices) selects.  When the indices have not been materialised (a training loop:
+        nothing read them) the regulariser is one autograd node over two HIP launches (autograd_ops.OctreeRegularizer);
+        otherwise — indices set from outside, CPU tensors, more than 4 levels — the reference's composite below."""
+        d = self.__dict__
+        coord = d.get("_hidx_coord")
+        if (coord is not None and d.get("_hidx") is None and d.get("_hidx_epoch") == self._tables_epoch and coord.is_cuda
+                and self.featured_level_num <= 4 and len(self.importance_weight) == self.featured_level_num
+                and len(self.features_last_frame) == self.featured_level_num
+                and all(a.shape == p.shape and b.shape == p.shape and a.is_cuda and b.is_cuda
+                        for a, b, p in zip(self.importance_weight, self.features_last_frame, self.hier_features))):
+            from .autograd_ops import OctreeRegularizer
+
+            if OctreeRegularizer.levels_with_gradient(self) is not None:
+                return OctreeRegularizer.apply(self, coord, *self.feature_list())
+        return self._cal_regularization_composite()
+
+    def _cal_regularization_composite(self):
         regularization = 0.0
         for i in range(self.featured_level_num):
             feature_level = self.featured_level_num - i - 1

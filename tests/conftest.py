@@ -85,6 +85,40 @@ def oracle_from_product(octree, dec, cfg):
     return ocfg, oct_, mlp
 
 
+def oracle_from_product_restricted(octree, dec, cfg, coord):
+    """oracle_from_product for a map too large for a python dict of ALL its nodes (10^7): the oracle's node tables hold only the
+    nodes the batch `coord` addresses — found on the oracle's side (its own quantise + Morton arithmetic, oracle/kaolin_shim.py)
+    in the product's host copies of the (node key, corner ids) arrays (the tables the reference's update() would have built:
+    test_device_octree_build_matches_reference_tables)."""
+    import numpy as np
+
+    from oracle import kaolin_shim as kal
+    from oracle import shine_oracle as so
+
+    ocfg = so.make_config(tree_level_world=cfg.tree_level_world, tree_level_feat=cfg.tree_level_feat,
+                          leaf_vox_size=cfg.leaf_vox_size, sigma_sigmoid_m=cfg.sigma_sigmoid_m,
+                          ekional_loss_on=cfg.ekional_loss_on, weight_e=cfg.weight_e, poly_int_on=cfg.poly_int_on,
+                          loss_reduction=cfg.loss_reduction, lambda_forget=getattr(cfg, "lambda_forget", 0.0))
+    oct_ = so.OracleOctree(ocfg)
+    octree._sync_host()
+    L = octree.featured_level_num
+    c = coord.detach().cpu()
+    for s in range(L):
+        lvl = octree.free_level_num + s
+        want = np.unique(kal.points_to_morton(kal.quantize_points(c, lvl)).cpu().numpy().astype(np.int64))
+        keys, ids = octree._node_keys[s], octree._node_ids[s]
+        order = np.argsort(keys, kind="stable")
+        pos = np.searchsorted(keys[order], want)
+        pos[pos >= keys.size] = keys.size - 1
+        at = order[pos]
+        hit = keys[at] == want
+        oct_.node_table[lvl] = dict(zip(want[hit].tolist(), ids[at[hit]].tolist()))
+    oct_.hier_features = [p.detach().cpu().clone().requires_grad_(True) for p in octree.hier_features]
+    mlp = so.OracleDecoder(ocfg)
+    mlp.load_state_dict({k: v.detach().cpu() for k, v in dec.state_dict().items()})
+    return ocfg, oct_, mlp
+
+
 def feat_grads_of_the_fused_terms(fx):
     """Feature grads of a fixture WITHOUT the regulariser term, from the CPU oracle (fp32, the reference's op sequence).
 

@@ -63,6 +63,12 @@ class OracleIncremental:
         self.opt = so.adam_param_groups(oct_, self.mlp, lr=self.lr, weight_decay=self.wd)  # shine_incre.py:107-109
         return grew
 
+    def freeze_decoder(self):
+        """freeze_model(geo_mlp), utils/tools.py:188-191 (shine_incre.py:93-97): the decoder's tensors stop requiring grad; the
+        per-frame optimiser still lists them (shine_incre.py:107-109) and Adam skips parameters without a gradient"""
+        for p in self.mlp.params():
+            p.requires_grad_(False)
+
     def iterate(self, coord, label, weight):
         oct_, mlp, cfg = self.octree, self.mlp, self.cfg
         if self.literal:

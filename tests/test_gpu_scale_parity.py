@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import (feat_grads_of_the_fused_terms, load_golden, oracle_from_golden, oracle_from_product,
-                      product_from_golden)
+                      oracle_from_product_restricted, product_from_golden)
 from test_gpu_parity import TOL, abs_err, rel_err, step_options
 
 pytestmark = pytest.mark.gpu
@@ -92,6 +92,139 @@ def test_pool_mode_step_at_baseline_size_matches_oracle(kind, levels, n, variant
     assert abs_err(pred, wide["pred"]) <= TOL
     # set_zero (model/feature_octree.py:78-81): the trash rows are zero after the step
     assert all(float(p[-1].abs().max()) == 0.0 for p in octree.hier_features)
+
+
+def test_far_build_on_a_map_beyond_the_infinity_cache():
+    """the fused step on a map whose feature tables (> 256 MiB) do not fit the Infinity Cache — the
+    `kitti-large` workload of bench.py, 2^20 + 1 points, L = 3, BCE + eikonal.  The launch picks the FAR build by table size
+    (shine_train_step_regime); it is held (i) to the near build on the same batch (same arithmetic behind another load schedule:
+    only the atomics' order differs) and (ii) to the CPU oracle, whose node tables are restricted to the nodes the batch
+    addresses (a python dict of all 10^7 nodes would take minutes): pred, loss, every gradient tensor."""
+    import ctypes as C
+
+    from oracle import shine_oracle as so
+    from shine_mapping_amd import StepOptions, _lib, fused_train_step, synth
+    from shine_mapping_amd.sampler import SortedPool
+
+    n = (1 << 20) + 1
+    wl = synth.build_workload("kitti_large", frames=2800, device="cuda", seed=42, tree_level_feat=3, azimuths=300)
+    octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
+    with torch.no_grad():
+        for p in octree.hier_features:
+            p.mul_(5.0)
+    assert sum(p.numel() * 4 for p in octree.hier_features) > (256 << 20)
+    far = C.c_int32(-1)
+    _lib.check(_lib.lib().shine_train_step_regime(C.byref(octree.step_config(eikonal_on=1)), octree.row_counts(), n, C.byref(far)),
+               "shine_train_step_regime")
+    assert far.value == 1
+    octree._require_tables(with_ranks=True)
+    sp = SortedPool(octree, wl.pool.coord, wl.pool.sdf_label, wl.pool.weight, seed=2)
+    idx = sp.draw(n)
+    params = list(octree.hier_features) + dec.fused_params()
+    outs = {}
+    for variant in (0, 6):  # the library's choice (far) / the near build forced
+        for p in params:
+            p.grad = None
+        opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=True, weight_e=cfg.weight_e, kernel_variant=variant)
+        loss, pred, g = fused_train_step(octree, dec, None, None, None, opts, want_grad_x=True, pool=sp, idx=idx)
+        torch.cuda.synchronize()
+        outs[variant] = (float(loss), pred.clone(), g.clone(), [p.grad.clone() for p in params])
+    a, b = outs[0], outs[6]
+    assert abs(a[0] - b[0]) <= 1e-6 * max(1.0, abs(b[0])) and abs_err(a[1], b[1]) <= 1e-6 and rel_err(a[2], b[2]) <= 1e-6
+    for x, y in zip(a[3], b[3]):
+        assert rel_err(x, y) <= 1e-5
+    c, l, w = (t.cpu() for t in sp.get_batch(idx))
+    del wl.pool, sp
+    ocfg, oct_, mlp = oracle_from_product_restricted(octree, dec, cfg, c)
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    ref = so.train_step(oct_, mlp, c, l, w, ocfg)
+    assert abs_err(a[1], ref["pred"]) <= TOL
+    assert abs(a[0] - float(ref["loss"])) <= TOL * max(1.0, abs(float(ref["loss"])))
+    gr = ref["g"].double()
+    err = (a[2].double().cpu() - gr).abs().max(dim=1).values / float(gr.abs().max())
+    assert int((err > TOL).sum()) <= max(4, n // 20000)  # (ReLU-kink points: test_pool_mode_step_at_baseline_size_matches_oracle)
+    so.to_wide(oct_, mlp)
+    wide = so.train_step(oct_, mlp, c, l, w, ocfg)
+    for k, (r, r64) in enumerate(zip(ref["feat_grads"], wide["feat_grads"])):
+        ours = a[3][k].double().cpu()
+        scale = float(r64.abs().max())
+        assert float((ours[:-1] - r[:-1].double()).abs().max()) <= TOL * scale, "feature grad level %d (fp32 oracle)" % k
+        assert float((ours - r64).abs().max()) <= TOL * scale, "feature grad level %d incl. trash row (wide oracle)" % k
+    for k, (p, r, r64) in enumerate(zip(a[3][3:], ref["mlp_grads"], wide["mlp_grads"])):
+        assert rel_err(p, r64) <= TOL, "decoder grad %d (wide oracle)" % k
+        assert rel_err(p, r) <= TOL + rel_err(r, r64), "decoder grad %d (fp32 oracle)" % k
+
+
+def test_fused_adam_state_dict_round_trips_through_torch_adam(tmp_path):
+    """the reference checkpoints optimizer.state_dict() (utils/tools.py:200-213, shine_batch.py:232) and the
+    drop-in binds utils.tools.setup_optimizer to FusedAdam.  Its state_dict has torch.optim.Adam's layout: after three fused
+    steps torch.optim.Adam loads it and both continue identically; a FusedAdam that loads torch's state continues like torch;
+    the dict survives torch.save / torch.load — the reference's save_checkpoint body, verbatim."""
+    from shine_mapping_amd.optim import FusedAdam
+
+    g = torch.Generator().manual_seed(11)
+    shapes = [(32, 8), (32,), (32, 32), (32,), (1, 32), (1,), (1001, 8), (4003, 8)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    groups = lambda t: [{"params": t[:6], "lr": 0.01, "weight_decay": 1e-7}, {"params": [t[7]], "lr": 0.01},
+                        {"params": [t[6]], "lr": 0.005}]
+    fused = FusedAdam(groups(ps), betas=(0.9, 0.99), eps=1e-15)
+    ref = torch.optim.Adam(groups(qs), betas=(0.9, 0.99), eps=1e-15)
+
+    def grads(*sets):
+        for k in range(len(shapes)):
+            gr = torch.randn(shapes[k], generator=g).cuda()
+            for t in sets:
+                t[k].grad = gr.clone()
+
+    for _ in range(3):
+        grads(ps, qs)
+        fused.step()
+        ref.step()
+    sd = fused.state_dict()
+    assert set(sd) == {"state", "param_groups"} and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert sorted(sd["param_groups"][0]) == sorted(ref.state_dict()["param_groups"][0])
+    assert float(sd["state"][7]["step"]) == 3.0
+    # utils/tools.py:200-213, save_checkpoint's call
+    torch.save({"iters": 3, "optimizer": fused.state_dict()}, tmp_path / "ckpt.pth")
+    loaded = torch.load(tmp_path / "ckpt.pth", weights_only=False)["optimizer"]
+    other = torch.optim.Adam(groups(rs), betas=(0.9, 0.99), eps=1e-15)
+    other.load_state_dict(loaded)
+    with torch.no_grad():
+        for r, p in zip(rs, ps):
+            r.copy_(p)
+    back = FusedAdam(groups(qs), betas=(0.5, 0.5), eps=1.0)
+    back.load_state_dict(ref.state_dict())
+    assert back.betas == (0.9, 0.99) and back.eps == 1e-15 and back.step_count == 3
+    for _ in range(2):
+        grads(ps, qs, rs)
+        fused.step()
+        other.step()
+        back.step()
+    for p, q, r in zip(ps, qs, rs):
+        assert rel_err(p, r) <= 2e-6  # fused continues == torch continues from the fused state
+        assert rel_err(q, r) <= 4e-6  # a FusedAdam on torch's state (torch took q's first three steps)
+
+
+def test_the_two_decoder_forward_paths_agree_bit_for_bit(golden):
+    """Tier A evaluates the decoder in two places — shine_mlp_forward (Decoder.sdf's own launch, the first
+    iteration) and the decoder rider of shine_forward (query_feature's launch speculating the decoder that consumed its features
+    last: every later iteration).  Both walk the 8 -> 32 -> 32 -> 1 layers in the same order with the same fmaf chains, so a loop's
+    loss does not change its rounding between iteration 1 and iteration 2."""
+    cfg, octree, dec = product_from_golden(golden)
+    coord = golden["coord"].cuda()
+    with torch.no_grad():
+        first = dec.sdf(octree.query_feature(coord.clone().requires_grad_(False)))  # plain tensors: FusedMLP path
+    c1 = coord.clone()
+    pred1 = dec.sdf(octree.query_feature(c1))       # fused node, decoder's own launch; registers the decoder for speculation
+    src_feat = octree.query_feature(c1)             # this launch speculates the decoder
+    src = src_feat._shine_src
+    spec = src.speculated(dec)
+    assert spec is not None
+    pred2 = dec.sdf(src_feat)
+    assert torch.equal(pred2.detach(), spec)
+    assert torch.equal(pred1.detach(), first) and torch.equal(pred2.detach(), pred1.detach())
 
 
 @pytest.mark.parametrize("bs,down_rate", [(4096, 2), (1500, 1), (40000, 1)])  # (the last: several tiles per wave, radix partition)

@@ -470,16 +470,20 @@ def test_dropin_rebinds_the_reference_utils_functions():
         "import os, sys, torch\n"
         "from oracle import ref_import\n"
         "ref = ref_import.install()\n"
-        "import utils.tools as ut, utils.loss as ul\n"
+        "import utils.tools as ut, utils.loss as ul, utils.incre_learning as ui\n"
         "orig = (ut.setup_optimizer, ut.get_gradient, ul.sdf_bce_loss)\n"
+        "orig_sweep = ui.cal_feature_importance\n"
         "import shine_mapping_amd.dropin as d\n"
         "from shine_mapping_amd import losses, optim, autograd_ops\n"
         "st = d.status()\n"
         "assert st['setup_optimizer'] is True and st['get_gradient'] is True and st['sdf_bce_loss'] is True, st\n"
         "assert ut.get_gradient is losses.get_gradient and ul.sdf_bce_loss is losses.sdf_bce_loss\n"
         "assert ut.setup_optimizer is not orig[0] and autograd_ops.FUSE_WITH_COORD_GRAD\n"
+        "# round 5: the importance sweep of the incremental driver (shine_incre.py:17, :185-188)\n"
+        "assert st['cal_feature_importance'] is True and ui.cal_feature_importance is not orig_sweep, st\n"
         "ns = {}\n"
-        "exec('from utils.tools import *\\nfrom utils.loss import *', ns)\n"  # what the drivers do
+        "exec('from utils.tools import *\\nfrom utils.loss import *\\nfrom utils.incre_learning import cal_feature_importance', ns)\n"  # what the drivers do
+        "assert ns['cal_feature_importance'] is ui.cal_feature_importance\n"
         "assert ns['get_gradient'] is losses.get_gradient and ns['sdf_bce_loss'] is losses.sdf_bce_loss\n"
         "# CPU parameters: the wrapper hands over to the reference's own setup_optimizer (torch.optim.Adam)\n"
         "cfg = ref.SHINEConfig(); cfg.device = 'cpu'\n"
@@ -496,6 +500,7 @@ def test_dropin_rebinds_the_reference_utils_functions():
         "assert torch.equal(ns['get_gradient'](c, (c ** 2).sum(1)), orig[1](c, (c ** 2).sum(1)))\n"
         "d.uninstall()\n"
         "assert (ut.setup_optimizer, ut.get_gradient, ul.sdf_bce_loss) == orig and not autograd_ops.FUSE_WITH_COORD_GRAD\n"
+        "assert ui.cal_feature_importance is orig_sweep\n"
         "os.environ['SHINE_DROPIN_FUSED_LOSS'] = '0'\n"
         "d.install()\n"
         "assert ul.sdf_bce_loss is orig[2] and ut.get_gradient is losses.get_gradient, d.status()\n"
