@@ -30,31 +30,45 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 // configuration's 4096 points, where the extra launch is half the step (ncd-incre 172 -> 179 frames/s).
 // SLICED: the launch holds many independent steps (shine_sweep.hip); `sl` names this workgroup's one — sample indices, size,
 // normaliser, private gradient tables and flags — and bid / nbid count inside the slice.
-// FAR: the build for feature tables that do not fit the Infinity Cache (the launch picks it by table size, shine_step_v3.hip).
-// There a tile's dependent chain  hash slot -> 8 corner ids -> 8 rows  and the scatter's atomics each cost an HBM round trip that
-// two waves per SIMD cannot cover (profiles/r04_pmc_kitti-large_*: waves parked 0.40, issue-stalled 0.38).  The FAR build runs the
-// chain one tile ahead: the slot arrives two tiles ahead, the corner ids of tile t + 1 are loaded under the decoder of tile t,
-// and — once they are back — every feature row and every gradient row of tile t + 1 is TOUCHED (one dword load per row into a
-// register nobody reads), so that the gather and the atomics of tile t + 1 find their lines in the L2.
-#ifndef SHINE_FAR_TOUCH
-#define SHINE_FAR_TOUCH 0  // 0: ids ahead only, 1: + touch the feature rows, 2: + touch the gradient rows
-#endif
-#ifndef SHINE_FAR_NT
-#define SHINE_FAR_NT 0  // 1: the far build's row gathers carry the nontemporal hint
-#endif
-#ifndef SHINE_FAR_POS
-#define SHINE_FAR_POS 0  // where the touches are issued: 0 after the decoder's forward, 1 after its backward, 2 in front of the scatter
-#endif
-__device__ __forceinline__ void touch_line(const float* p, int& sink) {
-  // (not a compiler-visible load: nothing waits for it; `sink` stays allocated because every touch reads and writes it)
-  asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p));
-}
-__device__ __forceinline__ void touch_line_l2(const float* p, int& sink) {  // agent scope: allocates in the L2 only
-  asm volatile("global_load_dword %0, %1, off sc1" : "+v"(sink) : "v"(p));
+// AHEAD (every full-chip build, WAVES == V3_BIG): a tile's dependent chain  hash slot -> 8 corner ids -> 8 rows  is run one
+// tile ahead — the slot arrives two tiles ahead and the corner ids of tile t + 1 are requested under the work of tile t, so the
+// row gathers of a tile start from registers.  Round 5, same-box A/B: 71.4 -> 69.6 us (2^18 x L4 BCE), 232 -> 224 us (2^20 x L3
+// eikonal), 502 -> 499 us on the 324 MB map (profiles/r05_ab_experiments.txt block 2; round 3 had measured the opposite sign
+// on its kernel).  TOUCHING the rows of tile t + 1 into the L2 on top of that — one dword load per row into a register nobody
+// reads — makes the big map SLOWER (540 us with the feature rows, 632 us with the gradient rows too: block 1): that regime is
+// not waiting for memory, it is short of atomic throughput (below); tools/experiments/r05_far_touch.patch keeps the code.
+//
+// FAR: the build for feature tables beyond the Infinity Cache (the launch picks it by table size, shine_step_v3.hip).  What
+// bounds the step there is the L2's fp32 atomic rate: the run-merged scatter of a 2^20-point batch on the 324 MB map is 1.28 M
+// node runs = 82 M lane atomics, which the memory system retires in 408 us with NOTHING else running
+// (tools/ubench/random_rows.py: ~200 per ns, the same rate as on a cache-resident map) inside a 500 us kernel — the gathers
+// of the same batch take 106 us.  Node runs merge little on such a map (about one sample per leaf node), but neighbouring nodes
+// share corner rows: the FAR build keeps, per wave and level, a 4 x 4 x 4 lattice of corner rows in LDS (slot = the corner's
+// voxel coordinates mod 4, tag = its row id), adds a closed run's eight row sums there, and issues the global atomic only when
+// a slot is taken over by another row or the wave is done: 2.0-2.2 x fewer atomics on the synthetic maps
+// (profiles/r05_corner_merge_sim.txt).  The eight corners of one node always fall into eight different slots, so the eight
+// lane groups of the scatter never meet in one.
+// FAR: a closed node run's sum for ONE corner row goes into the wave's lattice of that level.  Called by all 64 lanes of the
+// scatter role at once, lane = (corner, feature): `packed` = the corner's row id | its lattice slot << 25.  The slot holds the
+// row already: add; it holds another row (or nothing): that row's sum leaves as one atomic per feature and the slot is taken
+// over.  The eight corners of a node sit in eight different slots, so no two lane groups touch the same slot here.
+__device__ __forceinline__ void lattice_add(float* lat, float* gbase, int packed, int sq, float v) {
+  const int row = packed & ((1 << V3_ROW_BITS) - 1), slot = (packed >> V3_ROW_BITS) & (V3_CSLOTS - 1);
+  int* const tag = reinterpret_cast<int*>(lat) + slot;
+  float* const val = lat + V3_CSLOTS + slot * F + sq;
+  const int T = *tag;
+  if (T == row) {
+    *val += v;
+  } else {
+    const float old = *val;
+    *val = v;
+    if (sq == 0) *tag = row;
+    if (T >= 0) atomic_add_f32(gbase + ((unsigned int)T << 3) + sq, old);
+  }
 }
 
 template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false, bool SLICED = false, bool FAR = false>
-__device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm, const int bid, const int nbid,
+__device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES, FAR>& sm, const int bid, const int nbid,
                                           const StepSlice* sl = nullptr) {
 // (spelled as expressions at every use, not as locals: the unsliced builds must stay the instruction streams the committed
 // counter files were measured on — tools/kernel_hash.py)
@@ -131,8 +145,9 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
   int np2 = 0, np1 = 0;
   if (SL_PERM && second + pt < end) np2 = SL_PERM[second + pt];
   if (SL_PERM && nvalid) np1 = SL_PERM[begin + pt];
-  int np3 = 0;  // FAR: the sample index of the tile after that (its slot is loaded two tiles ahead)
-  if (FAR && SL_PERM && second + V3_TP + pt < end) np3 = SL_PERM[second + V3_TP + pt];
+  constexpr bool AHEAD = WAVES == V3_BIG && !SLICED;
+  int np3 = 0;  // AHEAD: the sample index of the tile after that (its slot is loaded two tiles ahead)
+  if (AHEAD && SL_PERM && second + V3_TP + pt < end) np3 = SL_PERM[second + V3_TP + pt];
 
   // ---- per-workgroup setup: A operands in 16x16x4 lane order (lane l: row i = l & 15, k = l >> 4), biases.
   // Branch-free source select and a fully unrolled loop: the (up to 11) loads of a thread are all in flight together.
@@ -168,8 +183,8 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     nlabel = a.label[np];
     if ((EIK && !EXT) || a.weighted) nweight = a.weight[np];
   }
-  int fslot = -1;  // FAR: the hash slot of the tile after the one n* describes
-  if (FAR && lvl_on_i && second + pt < end)
+  int fslot = -1;  // AHEAD: the hash slot of the tile after the one n* describes
+  if (AHEAD && lvl_on_i && second + pt < end)
     fslot = __builtin_nontemporal_load(a.slots + (a.pool_mode ? (long long)np2 : second + pt) * L + g);
 
   if (WAVES == 4 && use_img) {  // (opA and bias are adjacent in StepShared: the image is their concatenation)
@@ -182,6 +197,12 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
   if (tid == 0) s_loss[0] = s_loss[1] = s_loss[2] = s_loss[3] = 0.0;
   __syncthreads();
 
+  // FAR: this wave's corner lattice (tags -1 = empty); only this wave touches it
+  float* const cbase = sm.cache[FAR ? wv : 0];
+  if (FAR) {
+#pragma unroll
+    for (int s = 0; s < L; ++s) reinterpret_cast<int*>(cbase)[s * V3_CLEVEL + lane] = -1;
+  }
   float* U = sm.wave[wv];
   int* U_ids = reinterpret_cast<int*>(U);  // [LCAP][8][16]
   float* U_w = U + V3_IDS;                 // [LCAP][8][16]
@@ -210,16 +231,8 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
       lv_res = a.lv[s].res;
     }
 
-  const float* lv_grad = nullptr;  // FAR: this lane's level's gradient table (touched one tile ahead)
-  if (FAR && SHINE_FAR_TOUCH >= 2) {
-    lv_grad = SLICED ? sl->grad[0] : a.lv[0].grad;
-#pragma unroll
-    for (int s = 1; s < L; ++s)
-      if (gs == s) lv_grad = SLICED ? sl->grad[s] : a.lv[s].grad;
-  }
-  int4 fia = make_int4(0, 0, 0, 0), fib = fia;  // FAR: the corner ids of the tile n* describes, loaded one tile ahead
-  int sink = 0;
-  if (FAR) {
+  int4 fia = make_int4(0, 0, 0, 0), fib = fia;  // AHEAD: the corner ids of the tile n* describes, loaded one tile ahead
+  if (AHEAD) {
     const unsigned int s0 = nvalid && nslot >= 0 ? (unsigned int)nslot : 0u;
     fia = lv_vals[2u * s0];
     fib = lv_vals[2u * s0 + 1u];
@@ -306,8 +319,8 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     for (int q = 0; q < (EIK ? 4 : 1); ++q) Ag[q][0] = Ag[q][1] = Ag[q][2] = splat2(0.f);
     {  // every lane gathers the 8 ids and the 8 x 32-B rows of its own (point, level)
       const unsigned int sl = hit ? (unsigned int)slot : 0u;
-      int4 ia, ib;  // the eight corner ids: two 16-B loads (FAR: requested one tile ago)
-      if (FAR) {
+      int4 ia, ib;  // the eight corner ids: two 16-B loads (AHEAD: requested one tile ago)
+      if (AHEAD) {
         ia = fia, ib = fib;
       } else {
         ia = lv_vals[2u * sl], ib = lv_vals[2u * sl + 1u];
@@ -315,8 +328,19 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
       const int ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
       // staging for the scatter: a miss stages -1 (trash row), never the speculative ids
       const int mneg = hit ? 0 : -1;
+      if (FAR) {  // each id carries the lattice slot of its corner: the node's voxel coordinates + the corner's offset, mod 4
+        const int vx = (int)__fmul_rn(lv_res, __fadd_rn(__fmul_rn(x0, 0.5f), 0.5f));
+        const int vy = (int)__fmul_rn(lv_res, __fadd_rn(__fmul_rn(x1, 0.5f), 0.5f));
+        const int vz = (int)__fmul_rn(lv_res, __fadd_rn(__fmul_rn(x2, 0.5f), 0.5f));
+        const int sx[2] = {(vx & 3) << (V3_ROW_BITS + 4), ((vx + 1) & 3) << (V3_ROW_BITS + 4)};
+        const int sy[2] = {(vy & 3) << (V3_ROW_BITS + 2), ((vy + 1) & 3) << (V3_ROW_BITS + 2)};
+        const int sz[2] = {(vz & 3) << V3_ROW_BITS, ((vz + 1) & 3) << V3_ROW_BITS};
 #pragma unroll
-      for (int c = 0; c < 8; ++c) st_ids[c * V3_WP] = ids[c] | mneg;
+        for (int c = 0; c < 8; ++c) st_ids[c * V3_WP] = (ids[c] | sx[(c >> 2) & 1] | sy[(c >> 1) & 1] | sz[c & 1]) | mneg;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) st_ids[c * V3_WP] = ids[c] | mneg;
+      }
       // V3_GB corners (2 V3_GB 16-B loads) in flight at a time
 #pragma unroll
       for (int cb = 0; cb < 8; cb += V3_GB) {
@@ -324,15 +348,8 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
 #pragma unroll
         for (int c = 0; c < V3_GB; ++c) {  // a miss reads row 0 with weight 0 (no branches)
           const float* row = lv_feat + (size_t)(hit ? (unsigned int)ids[cb + c] : 0u) * F;
-          if (FAR && SHINE_FAR_NT) {
-            const f32x4 a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row));
-            const f32x4 a1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + 4));
-            r0[c] = make_float4(a0[0], a0[1], a0[2], a0[3]);
-            r1[c] = make_float4(a1[0], a1[1], a1[2], a1[3]);
-          } else {
-            r0[c] = *reinterpret_cast<const float4*>(row);
-            r1[c] = *reinterpret_cast<const float4*>(row + 4);
-          }
+          r0[c] = *reinterpret_cast<const float4*>(row);
+          r1[c] = *reinterpret_cast<const float4*>(row + 4);
         }
 #pragma unroll
         for (int cp = 0; cp < V3_GB; cp += 2) {  // corners (cb + cp, cb + cp + 1): the same (cx, cy), cz = 0 / 1
@@ -359,17 +376,15 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
       }
     }
     // prefetch of tile t+1's point data, issued after every gather of this tile (vmcnt counts in order)
-    bool fhit = false;  // FAR: this lane's (point, level) of tile t+1 has a node
     {
       const long long ni = base + V3_TP + pt, ni2 = ni + V3_TP, ni3 = ni2 + V3_TP;
       nvalid = ni < end;
       np = 0;
       nx0 = nx1 = nx2 = nlabel = nweight = 0.f;
       nslot = -1;
-      if (FAR) {  // the corner ids of tile t+1 (its slot came in a tile ago), then the slot of tile t+2
+      if (AHEAD) {  // the corner ids of tile t+1 (its slot came in a tile ago), then the slot of tile t+2
         nslot = nvalid ? fslot : -1;
-        fhit = nslot >= 0;
-        const unsigned int fs = fhit ? (unsigned int)nslot : 0u;
+        const unsigned int fs = nslot >= 0 ? (unsigned int)nslot : 0u;
         fia = lv_vals[2u * fs];
         fib = lv_vals[2u * fs + 1u];
         fslot = -1;
@@ -379,29 +394,20 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
       if (nvalid) {
         np = SL_PERM ? (long long)np2 : ni;
         const long long si = a.pool_mode ? np : ni;
-        if (!FAR && lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
+        if (!AHEAD && lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
         nx0 = __builtin_nontemporal_load(a.coord + 3 * np);
         nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
         nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
         nlabel = __builtin_nontemporal_load(a.label + np);
         if ((EIK && !EXT) || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
       }
-      if (FAR) {
+      if (AHEAD) {
         np2 = np3;
         np3 = 0;
         if (SL_PERM && ni3 < end) np3 = __builtin_nontemporal_load(SL_PERM + ni3);
       } else if (SL_PERM && ni2 < end) {
         np2 = __builtin_nontemporal_load(SL_PERM + ni2);
       }
-    }
-    // FAR: touch every row tile t+1 will gather from and scatter to (its ids are waited for HERE, a phase after their request)
-#define SHINE_FAR_TOUCHES                                                                  \
-    if (FAR && SHINE_FAR_TOUCH >= 1 && fhit) {                                             \
-      const int nid[8] = {fia.x, fia.y, fia.z, fia.w, fib.x, fib.y, fib.z, fib.w};         \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                      \
-        touch_line(lv_feat + (size_t)(unsigned int)nid[c] * F, sink);                      \
-        if (SHINE_FAR_TOUCH >= 2 && lv_grad) touch_line_l2(lv_grad + (size_t)(unsigned int)nid[c] * F, sink); \
-      }                                                                                    \
     }
     // reduce-scatter of the per-level sums over the point's four lanes: lane g ends with features (2g, 2g+1)
     float f2[2];
@@ -462,7 +468,6 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     yp += __shfl_xor(yp, 16, 64);
     const float y = yp + __shfl_xor(yp, 32, 64) + b3;
     if (!EXT && valid && g == 0 && a.pred) __builtin_nontemporal_store(y, a.pred + po);
-    if (SHINE_FAR_POS == 0) { SHINE_FAR_TOUCHES }
     __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
     SHINE_STAMP(2)  // decoder forward
 
@@ -508,7 +513,6 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) e0 = mfma16(opa[V3_OPA1T + ks * 64], d1[ks], e0);
     sdf2[0] = e0[0], sdf2[1] = e0[1];  // d loss / d f for features 2g, 2g+1 of this lane's point
-    if (SHINE_FAR_POS == 1) { SHINE_FAR_TOUCHES }
     __builtin_amdgcn_sched_barrier(0);  // phase boundary: no operand of the next phase is fetched early
     SHINE_STAMP(3)  // loss + decoder backward
 
@@ -642,7 +646,6 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
       }
     }
     sdf2[0] = J2[0], sdf2[1] = J2[1];
-    if (SHINE_FAR_POS == 1) { SHINE_FAR_TOUCHES }
     __builtin_amdgcn_sched_barrier(0);  // phase boundary
     SHINE_STAMP(3)  // loss + decoder backward (eikonal chain)
 
@@ -717,7 +720,6 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     SHINE_STAMP(5)  // weight grads
     }
     // ================================================================ phase 6: feature-grad scatter (run-length)
-    if (SHINE_FAR_POS == 2) { SHINE_FAR_TOUCHES }
     f_wr[V3_DF] = sdf2[0];
     f_wr[V3_DF + V3_DFP] = sdf2[1];
     wave_lds_fence();
@@ -786,13 +788,18 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
 #pragma unroll
           for (int p2 = 0; p2 < V3_TP; ++p2) {
             if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
-              if (rhit) atomic_add_f32(gbase + (unsigned int)rid, racc);  // scalar branch
+              if (rhit) {  // scalar branch
+                if (FAR) lattice_add(cbase + s * V3_CLEVEL, gbase, rid, sq, racc);
+                else atomic_add_f32(gbase + (unsigned int)rid, racc);
+              }
               racc = 0.f;
-              rid = (idr[p2] << 3) | sq;  // float offset of this lane's (corner row, feature)
+              // float offset of this lane's (corner row, feature); FAR: the staged id itself (row | lattice slot << 25)
+              rid = FAR ? idr[p2] : (idr[p2] << 3) | sq;
               rhit = (int)((hm >> p2) & 1u);
               // the touched-row flags (unique(hierarchical_indices) without -1, for shine_regularize) are set here, at the run
               // start of every hit node, by one lane per corner
-              if (MARK && rhit && SL_TOUCHED(s) && sq == 0) SL_TOUCHED(s)[idr[p2]] = 1;
+              if (MARK && rhit && SL_TOUCHED(s) && sq == 0)
+                SL_TOUCHED(s)[FAR ? idr[p2] & ((1 << V3_ROW_BITS) - 1) : idr[p2]] = 1;
             }
             racc = fmaf(wr[p2], dfr[p2], racc);  // misses and padding lanes staged w = 0
           }
@@ -806,12 +813,24 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     SHINE_STAMP(4)  // scatter
   }
 
-  if (FAR) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink));  // every touch has landed: its register may be reused
   // ---- end of the wave's run: flush the open node runs
 #pragma unroll
   for (int s = 0; s < L; ++s) {
     float* gbase = SLICED ? sl->grad[s] : a.lv[s].grad;
-    if (gbase && run_hit[s]) atomic_add_f32(gbase + (unsigned int)run_id[s], run_acc[s]);
+    if (!gbase) continue;
+    if (FAR) {
+      float* const lat = cbase + s * V3_CLEVEL;
+      if (run_hit[s]) lattice_add(lat, gbase, run_id[s], sq, run_acc[s]);
+      // what the lattice still holds goes to memory: lane group sc flushes slots 8 sc .. 8 sc + 7
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int slot = 8 * sc + j;
+        const int T = reinterpret_cast<const int*>(lat)[slot];
+        if (T >= 0) atomic_add_f32(gbase + ((unsigned int)T << 3) + sq, lat[V3_CSLOTS + slot * F + sq]);
+      }
+    } else if (run_hit[s]) {
+      atomic_add_f32(gbase + (unsigned int)run_id[s], run_acc[s]);
+    }
   }
   __syncthreads();  // every wave is done with its staging region: it now holds the wave's partial vector
   float* wvec = sm.wave[wv];
@@ -888,7 +907,6 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES>& sm
     if (tid == 64 && a.zero_f64) *a.zero_f64 = 0.0;
   }
 #undef SHINE_STAMP
-#undef SHINE_FAR_TOUCHES
 #undef SL_N
 #undef SL_PERM
 #undef SL_TOUCHED

@@ -37,7 +37,7 @@ namespace shine {
 // one launch = one step: every workgroup runs its share of the batch (shine_step_body.hpp)
 template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false, bool FAR = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == V3_BIG ? V3_BIG / 4 : 2) void k_step_v3(V1Args a) {
-  __shared__ StepShared<WAVES> sm;
+  __shared__ StepShared<WAVES, FAR> sm;
   step_body<L, WAVES, EIK, PROF, EXT, MARK, false, FAR>(a, sm, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -99,11 +99,13 @@ static const void* step_fn(int levels, int wg_waves, bool prof, bool far = false
 constexpr long long FAR_TABLE_BYTES = 256ll << 20;
 static bool far_regime(const shine_step_config* cfg, const int64_t* rows) {
   const int v = cfg->kernel_variant & 0xff;
-  if (v == 5) return true;
   if (v == 6) return false;
   long long bytes = 0;
-  for (int s = 0; s < cfg->n_levels; ++s) bytes += (rows[s] + 1) * (long long)(F * sizeof(float));
-  return bytes > FAR_TABLE_BYTES;
+  for (int s = 0; s < cfg->n_levels; ++s) {
+    if (rows[s] + 1 >= (1ll << V3_ROW_BITS)) return false;  // (a staged corner id of the far build carries 6 lattice bits)
+    bytes += (rows[s] + 1) * (long long)(F * sizeof(float));
+  }
+  return v == 5 || bytes > FAR_TABLE_BYTES;
 }
 
 // Everything of a fused-step launch but the launch itself: argument block, kernel instantiation, geometry.  Used by

@@ -59,12 +59,19 @@ __device__ __forceinline__ int row_prev(int v, int first) { return __builtin_amd
 
 // LDS of one workgroup of the fused step: the decoder operand image, biases / w3 / b3, the loss accumulators and one staging
 // region per wave (which ends its life as the wave's partial vector).
-template <int WAVES>
+// CACHE (the FAR build, shine_step_body.hpp): per wave and level a 4 x 4 x 4 lattice of corner rows — 64 tags (row ids, -1 =
+// empty) and 64 x 8 partial gradient sums — in which closed node runs are merged before they go to memory as atomics.
+constexpr int V3_CSLOTS = 64;                              // slot = (cx & 3) << 4 | (cy & 3) << 2 | (cz & 3)
+constexpr int V3_CLEVEL = V3_CSLOTS + V3_CSLOTS * F;       // floats per level: tags, then values [slot][feature]
+constexpr int V3_CACHE_FLOATS = LCAP * V3_CLEVEL;          // 2304 floats = 9216 B per wave
+constexpr int V3_ROW_BITS = 25;                            // FAR: a staged corner id carries its lattice slot above bit 25
+template <int WAVES, bool CACHE = false>
 struct StepShared {
   alignas(16) float opA[V3_OPTOTAL];
   float bias[100];  // (directly behind opA: the operand image is copied over both)
   double loss[4];
   float wave[WAVES][V3_WAVE_FLOATS];
+  float cache[CACHE ? WAVES : 1][CACHE ? V3_CACHE_FLOATS : 4];
 };
 
 // Per-workgroup setup: the decoder's A operands pre-permuted into 16x16x4 lane order (lane l: row i = l & 15, k-group

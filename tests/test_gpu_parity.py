@@ -25,6 +25,16 @@ def abs_err(a, b):
     return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
 
 
+def decoder_grad_errs(grads, refs):
+    """rel_err per decoder tensor (W1, b1, W2, b2, w3, b3), each against its own max-abs — except the ONE-element b3, whose
+    gradient sum_p delta_p can cancel to 1e-2 of its own summands' size (then fp32 summation order alone moves it by 1e-3 of
+    itself, in the reference's sum as in ours): it is scaled by the output layer's gradients (w3, b3) taken together."""
+    out = [rel_err(g, r) for g, r in zip(grads[:5], refs[:5])]
+    scale = max(float(refs[4].abs().max()), float(refs[5].abs().max()), 1e-30)
+    out.append(abs_err(grads[5], refs[5]) / scale)
+    return out
+
+
 def g_close(g, ref, tol):
     """g = sigma * d pred / d coord compared between two KERNELS (different fp32 summation orders of the same sums).
     g is discontinuous where a ReLU pre-activation crosses zero: a point whose pre-activation sits within fp32 rounding of
@@ -872,7 +882,7 @@ def test_pipelined_incremental_frames_equal_the_sequential_loop():
     assert abs(a["loss"] - b["loss"]) <= 1e-5 * abs(a["loss"])
 
 
-def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=None, tier="B"):
+def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=None, tier="B", noise_probe=False):
     """Config 4 across frames (shine_incre.py:100-195), product vs CPU oracle on the SAME drawn batches and the SAME fresh
     feature rows: per frame  [freeze_model(geo_mlp) at frame `freeze_after`, :93-97] -> update(incremental_on=True) -> a new Adam
     (:107-109) -> K iterations of {BCE(sum) + lambda_forget * cal_regularization, backward, Adam} -> cal_feature_importance.
@@ -893,6 +903,10 @@ def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=No
         max-abs on ~1 % of the elements — literal vs clean, both on the CPU, tests/test_oracle.py pins that.  No implementation
         with another rounding can follow THOSE elements; the product is held to the literal oracle in the first frame (where
         the importance is still zero) at 2e-4, and afterwards at the literal oracle's own distance from the clean one.
+    noise_probe: a THIRD oracle — the clean one fed the same batches with their points permuted, i.e. the same arithmetic in
+    another fp32 summation order — measures how many elements the oracle ITSELF moves beyond 2e-4 under a change that no
+    implementation can avoid; the allowance of a tensor is then max(16, 5e-4 of it, 3 x that count).  (At K = 10 the two clean
+    runs stay within 5e-5; at config 4's 50 iterations per frame Adam has five times as many steps to amplify a sign flip.)
     -> the allowance actually used: the largest count of elements beyond 2e-4 of max-abs (and the largest deviation) seen."""
     from incre_trajectory import OracleIncremental, deviation
     from oracle import shine_oracle as so
@@ -911,6 +925,10 @@ def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=No
     dec_state = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
     oracles = {"clean": OracleIncremental(ocfg, lr=cfg.lr, weight_decay=cfg.weight_decay, literal=False, decoder_state=dec_state),
                "literal": OracleIncremental(ocfg, lr=cfg.lr, weight_decay=cfg.weight_decay, literal=True, decoder_state=dec_state)}
+    if noise_probe:
+        oracles["shuffled"] = OracleIncremental(ocfg, lr=cfg.lr, weight_decay=cfg.weight_decay, literal=False,
+                                                decoder_state=dec_state)
+    shuffle = torch.randperm(N, generator=torch.Generator().manual_seed(9))
     opts = StepOptions(sigma=cfg.sigma_sigmoid, loss_reduction="sum", deterministic=True)
     frames = list(synth.make_frames(cfg, frames=n_frames, beams=beams, azimuths=azimuths, seed=4, device="cuda"))
     seen_quirk = False
@@ -932,10 +950,13 @@ def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=No
         pool.draws, pool._stream_state = 0, None
         rows = [p.detach().cpu() for p in octree.hier_features]
         grew = None
-        for o in oracles.values():
+        for name, o in oracles.items():
             grew = o.begin_frame(coord[weight > 0].cpu(), new_rows=rows)
             for c, l, w in batches:
-                o.iterate(c.cpu(), l.cpu(), w.cpu())
+                c, l, w = c.cpu(), l.cpu(), w.cpu()
+                if name == "shuffled":
+                    c, l, w = c[shuffle], l[shuffle], w[shuffle]
+                o.iterate(c, l, w)
             o.end_frame(coord.cpu(), label.cpu(), BS, 2)
         seen_quirk = seen_quirk or (fi > 0 and not all(grew))
         data = type("Pool", (), {"coord_pool": coord, "sdf_label_pool": label})()
@@ -970,6 +991,7 @@ def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=No
         mine = dict(features=list(octree.hier_features), decoder=dec.fused_params(), importance=octree.importance_weight,
                     features_last=octree.features_last_frame)
         clean, literal = oracles["clean"].state(), oracles["literal"].state()
+        noise = oracles["shuffled"].state() if noise_probe else None
         report, bad = [], []
         for key, tensors in mine.items():
             for k, t in enumerate(tensors):
@@ -986,6 +1008,10 @@ def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=No
                 # max-abs, none by more than 1.5 lr per frame (one whole sign flip); a systematic error — a wrong batch, a
                 # stale flag, a missing regulariser gradient, a wrong bias correction — moves hundreds of elements by lr.
                 allowed = max(16, int(5e-4 * t.numel()))
+                if noise is not None:
+                    d_noise, n_noise = deviation(noise[key][k], clean[key][k], 2e-4)
+                    allowed = max(allowed, 3 * n_noise)
+                    report[-1] = report[-1] + ("oracle vs itself reordered: %.2e" % d_noise, n_noise)
                 scale = max(float(clean[key][k].abs().max()), 1e-30)
                 if n_clean > allowed or (key != "importance" and d_clean * scale > 1.5 * cfg.lr * (fi + 1)):
                     bad.append(("clean", key, k))
@@ -996,6 +1022,8 @@ def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=No
                 used["deviation"] = max(used["deviation"], d_clean)
         assert not bad, "\n".join(str(r) for r in [bad] + report)
         for name, o in oracles.items():
+            if name == "shuffled":
+                continue
             ref = o.losses[-1]
             tol = 2e-4 if (name == "clean" or fi == 0) else 1e-2
             assert abs(total - ref) <= tol * max(1.0, abs(ref)), (fi, name, total, ref)
@@ -1017,7 +1045,7 @@ def test_incremental_trajectory_at_config_4_shape_with_the_decoder_frozen_mid_ru
     on, shine_incre.py:93-97): the frozen launches (decoder_grad_on = 0), the optimiser re-created without the decoder's
     gradients, the graph rebuilt for another kernel instantiation.  Same clean / literal oracle pair, same allowance rule; the
     allowance actually used is printed (pytest -s) so that a regression shows before it fails."""
-    used = _incremental_trajectory(K=50, N=4096, BS=4096, n_frames=4, beams=32, azimuths=240, freeze_after=2)
+    used = _incremental_trajectory(K=50, N=4096, BS=4096, n_frames=4, beams=32, azimuths=240, freeze_after=2, noise_probe=True)
     assert used["deviation"] < 0.5  # (of max-abs: one sign flip of one element is ~lr / max-abs)
 
 
