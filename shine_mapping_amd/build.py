@@ -5,6 +5,8 @@
   lib/libshine_hip.so    the PRODUCT: csrc/*.hip — the fused step (shine_step_v3.hip) and everything around it
   lib/libshine_check.so  the product's objects + shine_step_v0.hip (the lane-per-point reference step): the on-device
                          cross-check of the GPU tests.  Only tests / tools load it (StepOptions.kernel_variant 1).
+  lib/_shine_ext.so      csrc/shine_torch_ext.cpp: Tier A's autograd nodes as a torch C++ extension over the C ABI (host code
+                         only; links libshine_hip.so through rpath $ORIGIN)
 
 Both land in shine_mapping_amd/lib/ (git-ignored, but they travel with the gpurun snapshot).
 """
@@ -20,6 +22,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libshine_hip.so")
 CHECK_LIB = os.path.join(LIBDIR, "libshine_check.so")
+EXT_LIB = os.path.join(LIBDIR, "_shine_ext.so")  # Tier A's autograd nodes in C++ (csrc/shine_torch_ext.cpp): host code, g++
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(os.path.dirname(HERE), "include")]
@@ -49,7 +52,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "libshine_hip.stamp")
     dig = _digest()
-    if not force and os.path.isfile(LIB) and os.path.isfile(CHECK_LIB) and os.path.isfile(stamp) and open(stamp).read() == dig:
+    if (not force and os.path.isfile(LIB) and os.path.isfile(CHECK_LIB) and os.path.isfile(EXT_LIB) and os.path.isfile(stamp)
+            and open(stamp).read() == dig):
         return LIB
     if not os.path.isfile(HIPCC):
         raise RuntimeError("hipcc not found at %s; cannot build libshine_hip.so" % HIPCC)
@@ -84,8 +88,34 @@ def build(force: bool = False, verbose: bool = True) -> str:
     link(LIB, product_objs)
     # the check library: the product's objects + the lane-per-point reference step
     link(CHECK_LIB, product_objs + check_objs)
+    build_extension(verbose)
     open(stamp, "w").write(dig)
     return LIB
+
+
+def build_extension(verbose: bool = True) -> str:
+    """lib/_shine_ext.so: csrc/shine_torch_ext.cpp against this interpreter's torch (host code only: plain g++)."""
+    import sysconfig
+
+    import pybind11
+    import torch
+
+    ti = os.path.dirname(os.path.abspath(torch.__file__))
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_shine_ext", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           "-I" + os.path.join(ti, "include"), "-I" + os.path.join(ti, "include", "torch", "csrc", "api", "include"),
+           "-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include(),
+           os.path.join(CSRC, "shine_torch_ext.cpp"), "-o", EXT_LIB,
+           "-L" + os.path.join(ti, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
+           "-L" + LIBDIR, "-lshine_hip", "-Wl,-rpath," + os.path.join(ti, "lib"), "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building _shine_ext.so failed:\n%s\n%s" % (r.stdout, r.stderr[-4000:]))
+    return EXT_LIB
 
 
 if __name__ == "__main__":

@@ -48,23 +48,25 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 // a slot is taken over by another row or the wave is done: 2.0-2.2 x fewer atomics on the synthetic maps
 // (profiles/r05_corner_merge_sim.txt).  The eight corners of one node always fall into eight different slots, so the eight
 // lane groups of the scatter never meet in one.
-// FAR: a closed node run's sum for ONE corner row goes into the wave's lattice of that level.  Called by all 64 lanes of the
-// scatter role at once, lane = (corner, feature): `packed` = the corner's row id | its lattice slot << 25.  The slot holds the
-// row already: add; it holds another row (or nothing): that row's sum leaves as one atomic per feature and the slot is taken
-// over.  The eight corners of a node sit in eight different slots, so no two lane groups touch the same slot here.
-__device__ __forceinline__ void lattice_add(float* lat, float* gbase, int packed, int sq, float v) {
+// FAR: a node run's sum for ONE corner row goes into the wave's lattice of that level.  Called by all 64 lanes of the scatter
+// role at once, lane = (corner, feature); `packed` = the corner's row id | its lattice slot << 25.  lattice_peek — when the run
+// STARTS (or is carried into a tile) — reads the slot's tag and value; lattice_close — when the run ends — only writes: the slot
+// held the row already: value + sum; it held another row (or nothing): that row's value leaves as one atomic per feature and the
+// slot is taken over.  So the serial walk never waits for an LDS round trip at a run's end (the first version — peek and close in
+// one — cost the cache-resident kitti map 298 us against 225: profiles/r05_ab_experiments.txt block 4).  The eight corners of a
+// node sit in eight different slots, so no two lane groups meet in one; nothing else writes the lattice between a run's peek
+// and its close (closes are the only writes, and a wave closes one run per level at a time).
+__device__ __forceinline__ void lattice_peek(const float* lat, int packed, int sq, int& T, float& V) {
+  const int slot = (packed >> V3_ROW_BITS) & (V3_CSLOTS - 1);
+  T = reinterpret_cast<const int*>(lat)[slot];
+  V = lat[V3_CSLOTS + slot * F + sq];
+}
+__device__ __forceinline__ void lattice_close(float* lat, float* gbase, int packed, int sq, float v, int T, float V) {
   const int row = packed & ((1 << V3_ROW_BITS) - 1), slot = (packed >> V3_ROW_BITS) & (V3_CSLOTS - 1);
-  int* const tag = reinterpret_cast<int*>(lat) + slot;
-  float* const val = lat + V3_CSLOTS + slot * F + sq;
-  const int T = *tag;
-  if (T == row) {
-    *val += v;
-  } else {
-    const float old = *val;
-    *val = v;
-    if (sq == 0) *tag = row;
-    if (T >= 0) atomic_add_f32(gbase + ((unsigned int)T << 3) + sq, old);
-  }
+  const bool same = T == row;
+  lat[V3_CSLOTS + slot * F + sq] = same ? V + v : v;
+  reinterpret_cast<int*>(lat)[slot] = row;  // (the group's eight lanes write the same word)
+  if (!same && T >= 0) atomic_add_f32(gbase + ((unsigned int)T << 3) + sq, V);
 }
 
 template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false, bool SLICED = false, bool FAR = false>
@@ -783,19 +785,24 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES, FAR
           }
           int rid = run_id[s], rhit = run_hit[s];
           float racc = run_acc[s];
+          int lt = -1;     // FAR: the lattice entry of the open run, read when the run starts / is carried into this tile
+          float lv = 0.f;
+          float* const lat = cbase + s * V3_CLEVEL;
+          if (FAR && rhit) lattice_peek(lat, rid, sq, lt, lv);
           const unsigned int cm = (unsigned int)(chg64 >> (16 * s)) & 0xFFFFu;
           const unsigned int hm = (unsigned int)(hit64 >> (16 * s)) & 0xFFFFu;
 #pragma unroll
           for (int p2 = 0; p2 < V3_TP; ++p2) {
             if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
               if (rhit) {  // scalar branch
-                if (FAR) lattice_add(cbase + s * V3_CLEVEL, gbase, rid, sq, racc);
+                if (FAR) lattice_close(lat, gbase, rid, sq, racc, lt, lv);
                 else atomic_add_f32(gbase + (unsigned int)rid, racc);
               }
               racc = 0.f;
               // float offset of this lane's (corner row, feature); FAR: the staged id itself (row | lattice slot << 25)
               rid = FAR ? idr[p2] : (idr[p2] << 3) | sq;
               rhit = (int)((hm >> p2) & 1u);
+              if (FAR && rhit) lattice_peek(lat, rid, sq, lt, lv);
               // the touched-row flags (unique(hierarchical_indices) without -1, for shine_regularize) are set here, at the run
               // start of every hit node, by one lane per corner
               if (MARK && rhit && SL_TOUCHED(s) && sq == 0)
@@ -820,7 +827,12 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES, FAR
     if (!gbase) continue;
     if (FAR) {
       float* const lat = cbase + s * V3_CLEVEL;
-      if (run_hit[s]) lattice_add(lat, gbase, run_id[s], sq, run_acc[s]);
+      if (run_hit[s]) {
+        int lt;
+        float lv;
+        lattice_peek(lat, run_id[s], sq, lt, lv);
+        lattice_close(lat, gbase, run_id[s], sq, run_acc[s], lt, lv);
+      }
       // what the lattice still holds goes to memory: lane group sc flushes slots 8 sc .. 8 sc + 7
 #pragma unroll
       for (int j = 0; j < 8; ++j) {

@@ -77,9 +77,10 @@ struct Link {
   Tensor q;
 };
 
-py::object g_interp_backward;  // (octree id, g, coord, need_coord, feats) -> (grad_coord, *grad_feats): autograd_ops.OctreeInterpBackward
-py::object g_fused_split;      // (octree id, g, coord, feats, mlp, needs) -> grads of (coord, *feats, *mlp): the split nodes
-py::object g_read_done;        // (octree id): FeatureOctree._tables_read_done (asynchronous growth only)
+// (never destroyed: the interpreter may be gone when static destructors run)
+py::object* g_interp_backward = nullptr;  // (octree id, g, coord, need_coord, feats) -> (grad_coord, *grad_feats): OctreeInterpBackward
+py::object* g_fused_split = nullptr;      // (octree id, g, coord, feats, mlp, needs) -> grads of (coord, *feats, *mlp): the split nodes
+py::object* g_read_done = nullptr;        // (octree id): FeatureOctree._tables_read_done (asynchronous growth only)
 
 std::vector<const float*> ptrs(const std::vector<Tensor>& ts) {
   std::vector<const float*> p;
@@ -110,6 +111,7 @@ Tensor step_workspace(const Tensor& like, const shine_step_config& cfg, void* st
 // feat = query_feature(coord): the backward (a driver that consumed the features itself instead of handing them to Decoder.sdf)
 // is the Python node's — differentiable twice, as the eikonal configurations need it
 struct InterpNode : public Node {
+  std::string name() const override { return "OctreeInterp[ext]"; }
   SavedVariable coord;
   std::vector<SavedVariable> feats;
   int64_t py_id = 0;
@@ -119,7 +121,7 @@ struct InterpNode : public Node {
     if (!grads[0].defined()) return variable_list(1 + feats.size());
     py::list fl;
     for (auto& f : feats) fl.append(f.unpack());
-    py::tuple out = g_interp_backward(py_id, grads[0], coord.unpack(), need_coord, fl);
+    py::tuple out = (*g_interp_backward)(py_id, grads[0], coord.unpack(), need_coord, fl);
     variable_list res;
     for (size_t i = 0; i < out.size(); ++i) res.push_back(out[i].is_none() ? Tensor() : out[i].cast<Tensor>());
     return res;
@@ -131,6 +133,7 @@ struct InterpNode : public Node {
 };
 
 struct FusedSdfNode : public Node {
+  std::string name() const override { return "FusedInterpSdf[ext]"; }
   SavedVariable coord;
   std::vector<SavedVariable> feats, mlp;
   std::shared_ptr<TierAState> st;
@@ -155,7 +158,7 @@ struct FusedSdfNode : public Node {
       for (auto& f : F) fl.append(f);
       for (auto& m : M) ml.append(m);
       for (bool b : need) nl.append(b);
-      py::tuple res = g_fused_split(st->py_id, g, c, fl, ml, nl);
+      py::tuple res = (*g_fused_split)(st->py_id, g, c, fl, ml, nl);
       for (size_t i = 0; i < res.size() && i < out.size(); ++i) out[i] = res[i].is_none() ? Tensor() : res[i].cast<Tensor>();
       return out;
     }
@@ -195,7 +198,7 @@ struct FusedSdfNode : public Node {
             "shine_plan_batch");
       if (st->async_growth) {
         py::gil_scoped_acquire gil;
-        g_read_done(st->py_id);
+        (*g_read_done)(st->py_id);
       }
     }
     std::vector<Tensor> views;
@@ -232,6 +235,7 @@ struct FusedSdfNode : public Node {
 };
 
 struct GradCoordNode : public Node {
+  std::string name() const override { return "InterpSdfGradCoord[ext]"; }
   std::shared_ptr<Link> link;
   size_t n_in = 0;
   variable_list apply(variable_list&& grads) override {
@@ -246,6 +250,7 @@ struct GradCoordNode : public Node {
 };
 
 struct BceNode : public Node {
+  std::string name() const override { return "SdfBce[ext]"; }
   Tensor dpred;
   variable_list apply(variable_list&& grads) override {
     variable_list out(1);
@@ -375,22 +380,22 @@ Tensor grad_coord(const std::shared_ptr<TierAState>& st, const Tensor& pred, con
 }
 
 Tensor bce_loss(const Tensor& pred, const Tensor& label, const c10::optional<Tensor>& weight, double sigma, bool reduction_sum) {
-  Tensor out;
+  Tensor loss, dpred;
   {
     at::AutoDispatchBelowADInplaceOrView guard;
     Tensor p = f32c(pred.detach()), l = f32c(label.detach());
     Tensor w = weight.has_value() ? f32c(weight->detach()) : Tensor();
     const int64_t n = p.size(0);
-    out = at::empty({n + 1}, p.options());  // [d loss / d pred (n) | loss]
+    Tensor out = at::empty({n + 1}, p.options());  // [d loss / d pred (n) | loss]
     check(shine_bce_loss(p.data_ptr<float>(), l.data_ptr<float>(), w.defined() ? w.data_ptr<float>() : nullptr, n, (float)sigma,
                          reduction_sum ? 1 : 0, out.data_ptr<float>() + n, out.data_ptr<float>(), cur_stream(p)),
           "shine_bce_loss");
+    loss = out.select(0, n);
+    dpred = out.narrow(0, 0, n);
   }
-  const int64_t n = pred.size(0);
-  Tensor loss = out.select(0, n);
   if (at::GradMode::is_enabled() && pred.requires_grad()) {
     auto node = make_node<BceNode>({pred});
-    node->dpred = out.narrow(0, 0, n);
+    node->dpred = dpred;
     torch::autograd::create_gradient_edge(loss, node);
   }
   return loss;
@@ -440,9 +445,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       });
   py::class_<Link, std::shared_ptr<Link>>(m, "Link").def("pending", [](Link& l) { return l.q.defined(); });
   m.def("set_callbacks", [](py::object interp_backward, py::object fused_split, py::object read_done) {
-    g_interp_backward = std::move(interp_backward);
-    g_fused_split = std::move(fused_split);
-    g_read_done = std::move(read_done);
+    g_interp_backward = new py::object(std::move(interp_backward));
+    g_fused_split = new py::object(std::move(fused_split));
+    g_read_done = new py::object(std::move(read_done));
   });
   m.def("query_feature", &query_feature);
   m.def("fused_sdf", &fused_sdf);

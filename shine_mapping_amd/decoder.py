@@ -51,9 +51,17 @@ class Decoder(nn.Module):
                 import weakref
 
                 src.octree.__dict__["_spec_decoder"] = weakref.ref(self)  # (the next query_feature evaluates this decoder too)
-                pred = FusedInterpSdf.apply(sum_features.detach(), src.coord, src.octree, src, src.speculated(self),
-                                            *src.octree.feature_list(), *self.fused_params())
-                pred._shine_link = (src, tuple(src.octree.feature_list()) + tuple(self.fused_params()))
+                from . import _ext, autograd_ops
+
+                ext = _ext.module()
+                feats, mlp = src.octree.feature_list(), self.fused_params()
+                if ext is not None and src.coord.is_cuda:  # the C++ node (csrc/shine_torch_ext.cpp)
+                    pred, link = ext.fused_sdf(src.octree._ext_state(ext), sum_features, src.coord, src.speculated(self), feats,
+                                               mlp, autograd_ops.DETERMINISTIC_BACKWARD)
+                    pred._shine_link = (src, tuple(feats) + tuple(mlp), link)
+                    return pred
+                pred = FusedInterpSdf.apply(sum_features.detach(), src.coord, src.octree, src, src.speculated(self), *feats, *mlp)
+                pred._shine_link = (src, tuple(feats) + tuple(mlp), None)
                 return pred
             return FusedMLP.apply(sum_features, *self.fused_params())
         h = sum_features  # other shapes / devices: the reference's composite

@@ -589,6 +589,22 @@ class FeatureOctree(nn.Module):
             off += n
         return out
 
+    def _ext_state(self, ext):
+        """The C++ extension's view of this octree (csrc/shine_torch_ext.cpp TierAState): table handle, scalar configuration,
+        row counts — refreshed when the tables grew or were rebuilt (both bump _tables_epoch)."""
+        d = self.__dict__
+        key = (self._tables_epoch, self._tables.handle.value if self._tables is not None else 0, len(self.hier_features))
+        st = d.get("_ext_st")
+        if st is None or d.get("_ext_key") != key:
+            from . import _ext
+
+            if st is None:
+                st = d["_ext_st"] = ext.TierAState()
+            st.set(int(self._tables.handle.value), bytes(self.step_config()), [int(r) for r in self.row_counts()],
+                   _ext.register(self), self._growth_stream is not None)
+            d["_ext_key"] = key
+        return st
+
     def step_config(self, with_sort_box=False, **kw) -> _lib.StepConfig:
         cfg = _lib.StepConfig()
         cfg.n_levels = self.featured_level_num
@@ -728,6 +744,9 @@ class FeatureOctree(nn.Module):
         state["_hidx_coord"] = None
         state.pop("_spec_decoder", None)
         state.pop("_spec_result", None)
+        state.pop("_ext_st", None)
+        state.pop("_ext_key", None)
+        state.pop("_reg_flags", None)
         state["_dict_cache"] = None
         state["_pending"] = None
         state["_dev_log"] = None

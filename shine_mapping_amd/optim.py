@@ -245,6 +245,19 @@ class FusedAdam:
         for p, m, v, _, _ in ts:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
                 raise ValueError("FusedAdam needs contiguous CUDA float32 parameters and grads")
+        from . import _ext
+
+        ext = _ext.module()
+        if ext is not None:  # (one call with tensor lists instead of five ctypes pointer arrays)
+            flags = []
+            if row_flags:
+                self._flag_array(ts, row_flags)  # (validates)
+                by_id = {id(p): f for p, f in row_flags.items()}
+                flags = [by_id.get(id(t[0])) for t in ts]
+            ext.adam_step([t[0] for t in ts], [t[0].grad for t in ts], [t[1] for t in ts], [t[2] for t in ts], [t[3] for t in ts],
+                          [t[4] for t in ts], float(self.betas[0]), float(self.betas[1]), float(self.eps), int(step),
+                          bool(zero_grad), flags)
+            return
         lr = (C.c_float * n)(*[t[3] for t in ts])
         wd = (C.c_float * n)(*[t[4] for t in ts])
         _lib.check(

@@ -903,10 +903,14 @@ def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=No
         max-abs on ~1 % of the elements — literal vs clean, both on the CPU, tests/test_oracle.py pins that.  No implementation
         with another rounding can follow THOSE elements; the product is held to the literal oracle in the first frame (where
         the importance is still zero) at 2e-4, and afterwards at the literal oracle's own distance from the clean one.
-    noise_probe: a THIRD oracle — the clean one fed the same batches with their points permuted, i.e. the same arithmetic in
-    another fp32 summation order — measures how many elements the oracle ITSELF moves beyond 2e-4 under a change that no
-    implementation can avoid; the allowance of a tensor is then max(16, 5e-4 of it, 3 x that count).  (At K = 10 the two clean
-    runs stay within 5e-5; at config 4's 50 iterations per frame Adam has five times as many steps to amplify a sign flip.)
+    noise_probe: a THIRD oracle — the clean one fed the same batches with their points permuted AND every coordinate moved to
+    the next representable float (one ulp: ~1e-7 relative on every interpolation weight, the size of the differences any
+    implementation with its own exp / log / reciprocal and its own summation order has per sample) — measures how many elements
+    the oracle ITSELF moves beyond 2e-4 under a perturbation of that size; the allowance of a tensor is then max(16, 5e-4 of
+    it, 3 x that count).  (Permuting alone moves the oracle by 1e-6: measured, profiles/r05_ab_experiments.txt block 5.  At
+    K = 10 two such runs stay within 5e-5; at config 4's 50 iterations per frame Adam — eps 1e-15, a normalised step — has five
+    times as many steps to turn the relative error of a nearly cancelling coarse-level gradient into a move of that fraction
+    of lr per step.)
     -> the allowance actually used: the largest count of elements beyond 2e-4 of max-abs (and the largest deviation) seen."""
     from incre_trajectory import OracleIncremental, deviation
     from oracle import shine_oracle as so
@@ -955,7 +959,7 @@ def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=No
             for c, l, w in batches:
                 c, l, w = c.cpu(), l.cpu(), w.cpu()
                 if name == "shuffled":
-                    c, l, w = c[shuffle], l[shuffle], w[shuffle]
+                    c, l, w = torch.nextafter(c[shuffle], torch.full_like(c, float("inf"))), l[shuffle], w[shuffle]
                 o.iterate(c, l, w)
             o.end_frame(coord.cpu(), label.cpu(), BS, 2)
         seen_quirk = seen_quirk or (fi > 0 and not all(grew))

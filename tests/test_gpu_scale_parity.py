@@ -14,6 +14,11 @@ from test_gpu_parity import TOL, abs_err, decoder_grad_errs, rel_err, step_optio
 pytestmark = pytest.mark.gpu
 
 
+def node_name(fn):
+    """the autograd node's name: the Python Function's class name, or what a C++ node (csrc/shine_torch_ext.cpp) reports"""
+    return type(fn).__name__ + "/" + fn.name()
+
+
 def _workload(kind, levels, frames=8, seed=21, **over):
     from shine_mapping_amd import synth
 
@@ -435,7 +440,7 @@ def test_fused_mlp_matches_the_torch_composite_through_double_backward(n):
     pred, gf, gfeat, gw = run(dec, feat, lambda d, f: d.sdf(f))
     pred_t, gf_t, gfeat_t, gw_t = run(dec_t, feat_t, _torch_sdf)
     torch.cuda.synchronize()
-    assert "FusedMLP" in type(dec.sdf(feat).grad_fn).__name__
+    assert "FusedMLP" in node_name(dec.sdf(feat).grad_fn)
     assert abs_err(pred, pred_t) <= 1e-5
     assert rel_err(gf, gf_t) <= 1e-5
     assert rel_err(gfeat, gfeat_t) <= 1e-5
@@ -456,7 +461,7 @@ def test_train_step_is_an_autograd_node(golden):
     coord, label, weight = golden["coord"].cuda(), golden["sdf_label"].cuda(), golden["weight"].cuda()
     opts = step_options(golden)
     loss, pred, g = train_step(octree, dec, coord, label, weight, opts, want_grad_x=True)
-    assert loss.requires_grad and loss.dtype == torch.float32 and "ShineTrainStep" in type(loss.grad_fn).__name__
+    assert loss.requires_grad and loss.dtype == torch.float32 and "ShineTrainStep" in node_name(loss.grad_fn)
     assert not pred.requires_grad
     loss.backward()
     torch.cuda.synchronize()
@@ -511,7 +516,7 @@ def test_tier_a_fuses_query_feature_and_sdf_into_one_node(name):
         elif mode == "replaced":
             feature = feature * 1.0
         pred = dec.sdf(feature)
-        node = type(pred.grad_fn).__name__
+        node = node_name(pred.grad_fn)
         assert ("FusedInterpSdf" in node) == (mode == "fused"), (mode, node)
         loss = sdf_bce_loss(pred, label, fx["sigma"], None, False, red)
         loss.backward()
@@ -531,7 +536,7 @@ def test_tier_a_fuses_query_feature_and_sdf_into_one_node(name):
     cfg, octree, dec = product_from_golden(fx)
     c2 = coord.clone().requires_grad_(True)
     pred = dec.sdf(octree.query_feature(c2))
-    assert "FusedInterpSdf" not in type(pred.grad_fn).__name__
+    assert "FusedInterpSdf" not in node_name(pred.grad_fn)
     g = torch.autograd.grad(pred.sum(), c2, create_graph=True)[0]
     assert g.requires_grad
 
@@ -560,9 +565,9 @@ def test_tier_a_eikonal_loop_on_the_fused_node(name):
             if touch:
                 feature = feature * 1.0
             pred = dec.sdf(feature)
-            assert ("FusedInterpSdf" in type(pred.grad_fn).__name__) == (fuse and not touch)
+            assert ("FusedInterpSdf" in node_name(pred.grad_fn)) == (fuse and not touch)
             g = get_gradient(coord, pred) * sigma
-            assert ("InterpSdfGradCoord" in type(g.grad_fn.next_functions[0][0]).__name__) == (fuse and not touch)
+            assert ("InterpSdfGradCoord" in node_name(g.grad_fn.next_functions[0][0])) == (fuse and not touch)
             loss = sdf_bce_loss(pred, label, sigma, torch.abs(weight), False, c.get("loss_reduction", "mean"))
             loss = loss + w_e * ((1.0 - g[weight > 0].norm(2, dim=-1)) ** 2).mean()
             loss.backward()
@@ -598,7 +603,7 @@ def test_tier_a_eikonal_loop_on_the_fused_node(name):
         cfg, octree, dec = product_from_golden(fx)
         coord = fx["coord"].cuda().requires_grad_(True)
         pred = dec.sdf(octree.query_feature(coord))
-        assert "FusedInterpSdf" in type(pred.grad_fn).__name__
+        assert "FusedInterpSdf" in node_name(pred.grad_fn)
         g = reference_get_gradient(coord, pred) * sigma
         assert g.requires_grad
         loss = sdf_bce_loss(pred, label, sigma, torch.abs(weight), False, c.get("loss_reduction", "mean"))
@@ -635,7 +640,7 @@ def test_query_feature_speculates_the_decoder_and_notices_changed_weights():
     f2 = octree.query_feature(coord)
     assert f2._shine_src.speculated(dec) is not None
     p2 = dec.sdf(f2)
-    assert p2.data_ptr() == f2._shine_src.spec[0].data_ptr() and "FusedInterpSdf" in type(p2.grad_fn).__name__
+    assert p2.data_ptr() == f2._shine_src.spec[0].data_ptr() and "FusedInterpSdf" in node_name(p2.grad_fn)
     assert abs_err(p2, p1) <= 1e-5 and abs_err(p2, sdf_of(f2)) <= 1e-5
     p2.sum().backward()  # (and the node still backpropagates)
     assert all(p.grad is not None for p in list(octree.hier_features) + dec.fused_params())
@@ -669,14 +674,14 @@ def test_one_launch_bce_loss_matches_the_torch_composite(reduction, weighted):
         w = (torch.rand(n, generator=g) + 0.25).cuda()
         sigma = 6.7e-5
         a = losses.sdf_bce_loss(pred, label, sigma, w, weighted, reduction)
-        assert "SdfBce" in type(a.grad_fn).__name__
+        assert "SdfBce" in node_name(a.grad_fn)
         b = losses._bce_composite(ref_pred, label, sigma, w, weighted, reduction)
         (a * 1.7).backward()
         (b * 1.7).backward()
         assert abs(float(a) - float(b)) <= 2e-6 * max(1.0, abs(float(b)))
         assert rel_err(pred.grad, ref_pred.grad) <= 2e-6
     cpu = losses.sdf_bce_loss(torch.randn(8, requires_grad=True), torch.zeros(8), 1.0, None)  # CPU tensors: the composite
-    assert "SdfBce" not in type(cpu.grad_fn).__name__
+    assert "SdfBce" not in node_name(cpu.grad_fn)
 
 
 def test_tier_a_loop_runs_no_torch_gemm():

@@ -7,7 +7,8 @@ classes — query_feature -> sdf -> [get_gradient] -> sdf_bce_loss [+ eikonal] -
                      torch.optim.Adam);
   "dropin"           what `import shine_mapping_amd.dropin` gives it now: utils.tools.setup_optimizer / get_gradient and
                      utils.loss.sdf_bce_loss re-bound to the fused forms (one-launch Adam, one-launch loss, the eikonal loop
-                     on the fused node);
+                     on the fused node) — with the autograd nodes in Python (round 4) and in the C++ extension
+                     (csrc/shine_torch_ext.cpp, round 5: SHINE_TIER_A_EXT);
   "tier B"           the fused step on the same unordered batch + the fused Adam, for scale.
 Same process, same box, interleaved repetitions; ms per iteration = median of 5 x 30 iterations."""
 import os, statistics, sys, time, torch
@@ -36,7 +37,7 @@ for case_i, (kind, lv, n) in enumerate((CASES[0],) + tuple(CASES)):
     g = torch.Generator(device="cuda").manual_seed(1)
     sigma = cfg.sigma_sigmoid
 
-    def make_loop(patched):
+    def make_loop(patched, ext="1"):
         feats, mlp = list(octree.parameters()), list(dec.parameters())
         if patched:
             opt = optim.setup_optimizer(cfg, feats, mlp)
@@ -48,6 +49,7 @@ for case_i, (kind, lv, n) in enumerate((CASES[0],) + tuple(CASES)):
             bce, grad_fn = losses._bce_composite, ref_get_gradient
 
         def loop():
+            os.environ["SHINE_TIER_A_EXT"] = ext  # (read per call: _ext.module())
             autograd_ops.FUSE_WITH_COORD_GRAD = patched
             coord, sdf_label, weight = synth.draw_batch(wl.pool, n, g)
             if eik:
@@ -76,7 +78,8 @@ for case_i, (kind, lv, n) in enumerate((CASES[0],) + tuple(CASES)):
         fused_train_step(octree, dec, coord, label, weight, o)
         adam_b.step(zero_grad=True)
 
-    loops = {"utils unpatched (r03)": make_loop(False), "dropin (r04)": make_loop(True), "tier B (fused step + fused Adam)": tier_b}
+    loops = {"utils unpatched, Python nodes (r03)": make_loop(False, "0"), "dropin, Python nodes (r04)": make_loop(True, "0"),
+             "dropin, C++ nodes (r05)": make_loop(True, "1"), "tier B (fused step + fused Adam)": tier_b}
     times = {k: [] for k in loops}
     for fn in loops.values():
         for _ in range(5):
