@@ -23,7 +23,9 @@ ranks on 127.0.0.1 (so `python bench.py --gpus 8` and the driver's explicit torc
 than N visible devices is an error, never a silent fall-back to one rank.
 
 The default invocation (no --workload, one GPU) also runs abbreviated legs of BASELINE configs 3 (`kitti`) and 4
-(`ncd-incre`) and embeds their lines under `configs`, so one driver-timed record covers configs 2, 3 and 4.
+(`ncd-incre`, Tier B and Tier A), of the map beyond the Infinity Cache (`kitti-large`) and of rank 0's share of config 5
+(`kitti-dp8-rank`, with a MODELLED scaling block) and embeds their lines under `configs`, so one driver-timed record covers
+configs 2-5.
 
 One JSON line on rank 0: the driver's contract + `roofline` + `cpu_baseline` (DESIGN.md §5 explains every field).
 """
@@ -311,7 +313,7 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
                 surf = coord[weight > 0]
         else:
             surf = coord[weight > 0]
-        octree.update(surf, incremental_on=True)
+        octree.update(surf, incremental_on=True, ready=False if pipelined else None)  # (selected on the growth's own stream)
         octree._require_tables(with_ranks=True, probe=False)
         ev[1].record()
         t1 = time.perf_counter()
@@ -384,6 +386,16 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
     }
     # roofline of the dominant kernel at this batch size (HIP events around back-to-back launches of the fused kernel)
     out["roofline"] = kernel_roofline("ncd-incre", octree, dec, cfg, pool, bs, None)
+    # the same configuration through the UNCHANGED driver's names (Tier A: shine_incre.py's loop body verbatim on the drop-in's
+    # classes, every launch issued by Python; tools/tier_a_bench.py) next to the fused loop above (Tier B)
+    try:
+        from tier_a_bench import tier_a_incremental
+
+        n_a = min(len(frames), 8)
+        out["tier_a"] = tier_a_incremental(dev, frames[:n_a], bs=bs, iters=iters, warmup=2, levels=cfg.tree_level_feat)
+        out["tier_a"]["vs_tier_b_frames_per_s"] = out["tier_a"]["frames_per_s"] / out["frames_per_s"]
+    except Exception as e:
+        out["tier_a"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if with_cpu_baseline:
         cb = cpu_baseline(wl, n=bs, seconds=cpu_seconds, regularize=True)
         out["cpu_baseline"] = cb
@@ -994,6 +1006,98 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
     return out
 
 
+XGMI_LINK_GBS = 153.0  # per direction and link, 7 links per GPU (/opt/skills/guides: xGMI point-to-point)
+
+
+def run_dp_rank_model(args, dev, steps=60, warmup=10):
+    """VERDICT r04 item 6 — BASELINE config 5 (KITTI-like, 2^22 points per iteration over 8 GPUs) as far as ONE GPU can measure
+    it: rank 0's whole share of a step — its 2^19-point slice of the ONE global sorted draw of 2^22 (only the slice is
+    generated), the global normalisers, the fused step marking its rows, then the own-rows exchange with 8 SYNTHETIC peers (pack,
+    8 device copies of the message standing in for what the all-gather delivers, 8 unpack-adds) — against the same slice without
+    any exchange and against the dense bucket's local costs.  Everything except the wire is measured; `scale_model` adds the wire
+    from the xGMI link model and is labelled MODELLED.  -> dict"""
+    from shine_mapping_amd import StepOptions, fused_train_step, synth
+    from shine_mapping_amd import dp as shine_dp
+    from shine_mapping_amd.sampler import SortedPool
+
+    world, spec = 8, WORKLOADS["kitti"]
+    points = (1 << 22) // world
+    n_global = points * world
+    wl = synth.build_workload(spec["preset"], frames=spec["frames"], device=dev, seed=42, tree_level_feat=spec["levels"],
+                              azimuths=spec["azimuths"])
+    cfg, octree, decoder, pool = wl.cfg, wl.octree, wl.decoder, wl.pool
+    params = list(octree.hier_features) + decoder.fused_params()
+    octree._require_tables(with_ranks=True)
+    spool = SortedPool(octree, pool.coord, pool.sdf_label, pool.weight, seed=1000, canonical=True)
+    feats, dec_params = list(octree.hier_features), decoder.fused_params()
+    idx_buf = torch.empty(points, dtype=torch.int32, device=dev)
+    surf_parts = spool.surf_parts_buffer(points)
+    opts = StepOptions(sigma=cfg.sigma_sigmoid, loss_reduction=cfg.loss_reduction, ekional_loss_on=cfg.ekional_loss_on,
+                       weight_e=cfg.weight_e, n_global=n_global)
+
+    def timed(body):
+        for _ in range(warmup):
+            body()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            body()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    res = {}
+    for kind in ("none", "gather"):
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        reducer = shine_dp.RowGatherReducer(feats, dec_params, None, synthetic_world=world if kind == "gather" else 0)
+
+        def body():
+            idx = spool.draw(points, out=idx_buf, zero=reducer.flat, graph_safe=True, n_global=n_global, slice_begin=0,
+                             surf_parts=surf_parts)
+            n_surf = surf_parts.sum() * world  # (stands in for the 8-byte all-reduce of the ranks' counts)
+            fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx,
+                             touched=reducer.flags if kind == "gather" else None)
+            if kind == "gather":
+                reducer.exchange()
+
+        res[kind] = timed(body)
+        if kind == "gather":
+            msg_bytes, cap, dense = reducer.last_bytes, reducer.capacity, reducer.dense_bytes()
+            overflow = reducer.overflowed()
+    # the dense alternative's local part: nothing beyond the step itself (the bucket is cleared by the draw; the reduction is the
+    # collective's own kernels), so its measured share is res["none"]
+    t_none, t_gather = res["none"] * 1e-3, res["gather"] * 1e-3
+    link = XGMI_LINK_GBS * 1e9
+    wire = {
+        "gather_direct_s": msg_bytes / link,                      # every peer's message over its own link, in parallel
+        "gather_ring_s": (world - 1) * msg_bytes / link,          # one ring: 7 hops of one message each
+        "dense_direct_s": 2.0 * (dense / world) / link,           # reduce-scatter + all-gather over all 7 links at once
+        "dense_ring_s": 2.0 * (world - 1) / world * dense / link, # single ring
+    }
+    model = {}
+    for name, local, w in (("gather, direct all-gather", t_gather, wire["gather_direct_s"]),
+                           ("gather, ring", t_gather, wire["gather_ring_s"]),
+                           ("dense, direct reduce-scatter + all-gather", t_none, wire["dense_direct_s"]),
+                           ("dense, single ring", t_none, wire["dense_ring_s"])):
+        t = local + w  # (no overlap assumed: the exchange follows the step)
+        model[name] = {"ms_per_step": t * 1e3, "samples_per_s_8_gpus": n_global / t, "weak_scaling_efficiency_vs_1_gpu": t_none / t}
+    return {
+        "what": "rank 0's share of BASELINE config 5 on one GPU: slice of 2^19 of ONE global sorted draw of 2^22 points, KITTI-like "
+                "map, BCE + eikonal with global normalisers; 'gather' adds the own-rows exchange with 8 synthetic peers (pack, 8 "
+                "device copies of the message, 8 unpack-adds) — everything except the wire",
+        "points_per_rank": points, "n_global": n_global, "world": world,
+        "ms_per_step_measured": {"no exchange": res["none"], "own-rows exchange, 8 synthetic peers": res["gather"]},
+        "exchange_local_cost_ms": res["gather"] - res["none"],
+        "message_bytes_per_rank": int(msg_bytes), "message_capacity_rows": int(cap), "dense_bucket_bytes": int(dense),
+        "message_overflow": bool(overflow),
+        "scale_model": {"MODELLED": True, "link_GBps": XGMI_LINK_GBS, "wire_s": wire, "by_exchange": model,
+                        "note": "measured local time + message bytes / link bandwidth, no overlap, no collective launch latency; "
+                                "no multi-GPU node was available to any round: these are not measurements"},
+    }
+
+
 def _release(dev):
     import gc
 
@@ -1088,6 +1192,18 @@ def main():
                                                  cpu_seconds=6.0)
         except Exception as e:
             extra["ncd-incre"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        _release(dev)
+        try:  # the regime real KITTI-00 lives in: feature tables beyond the Infinity Cache (the far build of the fused step).  No
+            # CPU baseline here: its python dict of 10^7 nodes takes minutes (profiles/r04_bench_kitti-large.json.log has one)
+            extra["kitti-large"] = run_batch(args, "kitti-large", None, 1, 0, dev, 40, 10, with_cpu_baseline=False,
+                                             with_like_for_like=False, with_iteration=False)
+        except Exception as e:
+            extra["kitti-large"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        _release(dev)
+        try:  # config 5 as far as one GPU can measure it + a MODELLED scaling block
+            extra["kitti-dp8-rank"] = run_dp_rank_model(args, dev)
+        except Exception as e:
+            extra["kitti-dp8-rank"] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["configs"] = extra
     if rank == 0:
         print(json.dumps(out))

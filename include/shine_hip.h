@@ -72,8 +72,9 @@ typedef struct shine_step_config {
                               2: POOL mode — coord/label/weight/slots are a node-ordered sample pool, perm[] holds the
                               batch's sorted sample indices (shine_sample_sorted), outputs are written at batch position */
   int32_t kernel_variant;  /* low byte — 0 (or 4): the fused step (shine_step_v3.hip: planned / pool batches, <= 4 featured
-                              levels).  The CHECK library (libshine_check.so, tests / tools only) adds 1: the lane-per-point
-                              reference kernel (any batch, <= 8 levels) and 5: the role-specialised experimental kernel */
+                              levels; 5 / 6 force / forbid its build for tables beyond the Infinity Cache, which 0 picks by
+                              table size).  The CHECK library (libshine_check.so, tests / tools only) adds 1: the lane-per-point
+                              reference kernel (any batch, <= 8 levels) */
   float sigma;             /* sigma_sigmoid = ratio*sigma_m*scale      (shine_batch.py:87) */
   float weight_e;          /* eikonal weight                           (config weight_e) */
   double inv_n;            /* 1/N_global for "mean", 1 for "sum"       */
@@ -485,13 +486,17 @@ int shine_finish_iteration(const shine_step_config* cfg, int64_t n, const void* 
  *      shine_incre.py:107-109) costs no stream capture and no instantiation.  launch replays it `replays` times on the
  *      stream (= replays * unroll iterations; the per-iteration scalars — sampler stream id, Adam step count — live in device
  *      memory and are advanced by the kernels).  The argument arrays are read inside set_*; the DEVICE buffers they name
- *      must stay alive while the graph is launched.  For small batches (< 32768 points) the graph also owns the decoder's MFMA
- *      operand image: launch rebuilds it first from the decoder tensors as they are then, the tail nodes keep it current, the step
- *      nodes copy it instead of building it per workgroup.  commit waits (on the host) for the graph's own last replay before it touches
+ *      must stay alive while the graph is launched.  For small batches (< 32768 points) the graph can keep the decoder's MFMA
+ *      operand image in a buffer the CALLER hands it (set_operand_image: shine_iter_graph_operand_image_floats() floats, 16-byte
+ *      aligned, alive as long as the graph; call it before set_step; NULL or never: no image, the step builds its operands per
+ *      workgroup — the library allocates no device memory for a graph): launch rebuilds it first from the decoder tensors as they
+ *      are then, the tail nodes keep it current, the step nodes copy it instead of building it per workgroup.  commit waits (on the host) for the graph's own last replay before it touches
  *      the instantiated graph, not for other work queued since.  stats: commits so far, and how many of them built the graph. */
 typedef struct shine_iter_graph shine_iter_graph;
 int shine_iter_graph_create(int32_t unroll, shine_iter_graph** out);
 int shine_iter_graph_destroy(shine_iter_graph* g);
+int shine_iter_graph_operand_image_floats(void);
+int shine_iter_graph_set_operand_image(shine_iter_graph* g, float* image);
 int shine_iter_graph_set_step(shine_iter_graph* g, const shine_tables* t, const shine_step_config* cfg, const float* coord,
                               const float* sdf_label, const float* weight, const int32_t* perm, const int32_t* slots,
                               const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,

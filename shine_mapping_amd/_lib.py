@@ -195,6 +195,8 @@ def lib():
     return h
 
 
+_SIGNATURES["shine_iter_graph_operand_image_floats"] = (C.c_int, [])
+_SIGNATURES["shine_iter_graph_set_operand_image"] = (C.c_int, [_P, _P])
 _SIGNATURES["shine_iter_graph_set_step"] = (C.c_int, [_P] + _SIGNATURES["shine_train_step"][1][:-1])
 _SIGNATURES["shine_iter_graph_set_finish"] = (C.c_int, [_P] + _SIGNATURES["shine_finish_iteration"][1][:-1])
 

@@ -33,7 +33,9 @@ struct shine_iter_graph {
   hipEvent_t last_replay = nullptr;
   bool replayed = false;
   // the decoder's MFMA operand image for the small-batch builds of the step (V1Args::op_image): built at the head of every
-  // launch() from the decoder as it is then, kept current by the graph's own tail nodes
+  // launch() from the decoder as it is then, kept current by the graph's own tail nodes.  The CALLER's buffer
+  // (shine_iter_graph_set_operand_image: the library allocates no device memory for a graph); null: the step builds its operands
+  // per workgroup
   float* image = nullptr;
 };
 
@@ -113,7 +115,6 @@ extern "C" int shine_iter_graph_destroy(shine_iter_graph* g) {
   if (!g) return SHINE_OK;
   graph_drop(g);
   if (g->last_replay) (void)hipEventDestroy(g->last_replay);
-  if (g->image) (void)hipFree(g->image);
   delete g;
   return SHINE_OK;
 }
@@ -137,13 +138,21 @@ extern "C" int shine_iter_graph_set_step(shine_iter_graph* g, const shine_tables
                                       "marking pass in front of the step is not part of the graph); no profiling build");
   // (SHINE_NO_OPERAND_IMAGE=1 in the environment switches it off: same-box A/B, profiles/r04_ab_experiments.txt block 14)
   static const bool image_off = std::getenv("SHINE_NO_OPERAND_IMAGE") != nullptr;
-  if (sl.block.x == 256 && !image_off) {  // a small batch (4-wave workgroups): the step copies the operand image instead of building it
-    if (!g->image) SHINE_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->image), V3_IMAGE_FLOATS * sizeof(float)));
+  if (sl.block.x == 256 && !image_off && g->image)  // a small batch (4-wave workgroups): the step copies the operand image
     sl.a.op_image = g->image;
-  }
   g->step = sl;
   g->have_step = true;
   g->dirty = true;
+  return SHINE_OK;
+}
+
+extern "C" int shine_iter_graph_operand_image_floats(void) { return V3_IMAGE_FLOATS; }
+
+extern "C" int shine_iter_graph_set_operand_image(shine_iter_graph* g, float* image) {
+  if (!g) return set_error(SHINE_E_INVALID, "shine_iter_graph_set_operand_image: null graph");
+  if (image && ((size_t)image & 15)) return set_error(SHINE_E_INVALID, "shine_iter_graph_set_operand_image: 16-byte aligned buffer");
+  g->image = image;
+  g->dirty = g->have_step;  // (a bound step names the old buffer: set_step again)
   return SHINE_OK;
 }
 

@@ -1,7 +1,7 @@
 // shine_step_body.hpp — the body of the fused SHINE training step (one workgroup's share of a batch) as a device function,
-// so that two kernels can run it: k_step_v3 (shine_step_v3.hip: one launch = one step) and k_iterate (shine_iterate.hip: a
-// persistent launch that runs whole iterations — step, grid barrier, optimiser, grid barrier — without returning to the host).
-// The design notes are in shine_step_v3.hip's header.
+// so that two kernels can run it: k_step_v3 (shine_step_v3.hip: one launch = one step) and k_step_sweep (shine_sweep.hip: the
+// SLICED build — up to 64 independent chunk steps of the importance sweep in one launch).  The design notes are in
+// shine_step_v3.hip's header.
 #pragma once
 #include "shine_tile16.hpp"
 

@@ -56,6 +56,7 @@ class Decoder(nn.Module):
                 ext = _ext.module()
                 feats, mlp = src.octree.feature_list(), self.fused_params()
                 if ext is not None and src.coord.is_cuda:  # the C++ node (csrc/shine_torch_ext.cpp)
+                    src.octree._require_tables(with_ranks=True, probe=False)  # (its backward plans the batch: node ranks)
                     pred, link = ext.fused_sdf(src.octree._ext_state(ext), sum_features, src.coord, src.speculated(self), feats,
                                                mlp, autograd_ops.DETERMINISTIC_BACKWARD)
                     pred._shine_link = (src, tuple(feats) + tuple(mlp), link)

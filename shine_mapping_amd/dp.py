@@ -302,8 +302,13 @@ class RowGatherReducer(GradReducer):
     which `overflowed()` reads (one host sync — call it outside the hot loop; the result of such a step is incomplete).
     CPU tensors (gloo tests) run the same algorithm in torch index ops."""
 
-    def __init__(self, feature_params, other_params, dist=None, group=None, capacity_rows=None, async_op=False):
+    def __init__(self, feature_params, other_params, dist=None, group=None, capacity_rows=None, async_op=False,
+                 synthetic_world=0):
         super().__init__(list(feature_params) + list(other_params), dist, group)
+        # measurement aid (bench.py's kitti-dp8-rank leg): without a process group, stand in for `synthetic_world` ranks — the
+        # all-gather becomes that many device copies of this rank's own message, and every copy is unpacked and added: the
+        # pack, the receive-side writes and the unpack of an N-rank exchange are all there, only the wire is not
+        self.synthetic_world = int(synthetic_world) if dist is None else 0
         self.async_op = bool(async_op)  # issue the all-gather asynchronously (it then runs on the backend's own stream, under
         #                                 whatever the caller launches next — the next micro-batch); finish() waits for it
         self.n_feat = len(list(feature_params))
@@ -335,6 +340,8 @@ class RowGatherReducer(GradReducer):
         return sum(p.numel() for p in self.params) * 4
 
     def world(self):
+        if self.synthetic_world > 1:
+            return self.synthetic_world
         return self.dist.get_world_size(self.group) if self.dist is not None else 1
 
     def _measure_capacity(self):
@@ -380,6 +387,8 @@ class RowGatherReducer(GradReducer):
                 work = self.dist.all_gather_into_tensor(gathered, msg, group=self.group, async_op=True)
             else:
                 self.dist.all_gather_into_tensor(gathered, msg, group=self.group)
+        elif self.synthetic_world > 1:
+            gathered = msg.repeat(self.synthetic_world)
         else:
             gathered = msg
         self._pending.append((gathered, work, msg))  # (msg is kept alive until the collective has read it)

@@ -76,6 +76,13 @@ class IterationGraph:
         self.handle = C.c_void_p()
         self.owner = None  # the GraphedIteration whose buffers the nodes currently name
         _lib.check(_lib.lib().shine_iter_graph_create(self.unroll, C.byref(self.handle)), "shine_iter_graph_create")
+        self.image = None  # the decoder's operand image for small-batch steps: torch's allocation, handed to the graph
+
+    def ensure_image(self, dev):
+        if self.image is None or self.image.device != torch.device(dev):
+            lib = _lib.lib()
+            self.image = torch.empty(int(lib.shine_iter_graph_operand_image_floats()), dtype=torch.float32, device=dev)
+            _lib.check(lib.shine_iter_graph_set_operand_image(self.handle, self.image.data_ptr()), "shine_iter_graph_set_operand_image")
 
     @classmethod
     def shared(cls, device, unroll, slot=0):
@@ -195,6 +202,7 @@ class GraphedIteration:
         ent = self._native.get(unroll)
         g = ent[0] if ent is not None else IterationGraph.shared(self.pool.coord.device, unroll, self.graph_slot)
         if ent is None or g.owner is not self:
+            g.ensure_image(self.pool.coord.device)
             keep = {}
             out = self._body(graph=g, keep=keep)
             g.commit()

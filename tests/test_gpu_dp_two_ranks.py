@@ -48,11 +48,21 @@ class HostStaged:
         return dist.get_world_size(group)
 
     @staticmethod
-    def all_gather_into_tensor(out, inp, group=None):
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
         c = inp.detach().cpu()
         parts = [torch.empty_like(c) for _ in range(dist.get_world_size(group))]
-        dist.all_gather(parts, c, group=group)
-        out.copy_(torch.cat(parts))
+        if not async_op:
+            dist.all_gather(parts, c, group=group)
+            out.copy_(torch.cat(parts))
+            return None
+        work = dist.all_gather(parts, c, group=group, async_op=True)  # in flight under whatever the caller launches next
+
+        class Pending:
+            def wait(self):
+                work.wait()
+                out.copy_(torch.cat(parts))
+
+        return Pending()
 
 
 torch.cuda.set_device(0)
@@ -64,8 +74,12 @@ opts = StepOptions(sigma=cfg.sigma_sigmoid, loss_reduction=cfg.loss_reduction, e
 params = list(octree.hier_features) + decoder.fused_params()
 for p in params:
     p.grad = torch.zeros_like(p)
+micro = 2 if exchange == "gather-micro2" else 1
+if micro > 1:  # bench.py --micro-batches 2: the (asynchronous) all-gather of micro-batch k under the fused kernel of k + 1
+    exchange = "gather"
 Reducer = shine_dp.RowGatherReducer if exchange == "gather" else shine_dp.TouchedRowReducer
-reducer = Reducer(list(octree.hier_features), decoder.fused_params(), None if single else HostStaged)
+reducer = Reducer(list(octree.hier_features), decoder.fused_params(), None if single else HostStaged,
+                  **({"async_op": True} if micro > 1 else {}))
 octree._require_tables(with_ranks=True)
 spool = SortedPool(octree, pool.coord, pool.sdf_label, pool.weight, seed=1000, canonical=True)
 flags = None
@@ -82,10 +96,24 @@ for it in range(3):
     if opts.ekional_loss_on:
         n_surf = (spool.weight[idx.long()] > 0).sum()
         reducer.all_reduce_scalar(n_surf)
-    loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx,
-                                     touched=reducer.flags if exchange == "gather" else None)
-    loss = loss.detach().clone()
-    if exchange == "gather":  # own rows (flagged by the step itself) -> message -> all-gather -> added back
+    if micro > 1:  # bench.py run_micro: contiguous sub-slices, exchange after each, everything added back after the last
+        loss, preds = None, []
+        for k in range(micro):
+            a_, b_ = k * points // micro, (k + 1) * points // micro
+            l_, p_, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx[a_:b_],
+                                         touched=reducer.flags)
+            loss = l_.detach().clone() if loss is None else loss + l_.detach()
+            preds.append(p_.detach().clone())
+            reducer.exchange(finish=k == micro - 1)
+        pred = torch.cat(preds)
+        assert not reducer.overflowed()
+    else:
+        loss, pred, _ = fused_train_step(octree, decoder, None, None, None, opts, n_surf=n_surf, pool=spool, idx=idx,
+                                         touched=reducer.flags if exchange == "gather" else None)
+        loss = loss.detach().clone()
+    if micro > 1:
+        pass
+    elif exchange == "gather":  # own rows (flagged by the step itself) -> message -> all-gather -> added back
         reducer.exchange()
         assert not reducer.overflowed()
     elif exchange == "touched":
@@ -139,7 +167,8 @@ def _run(tmp_path, kind, exchange, points, world, tag):
 
 
 @pytest.mark.parametrize("kind,exchange", [("maicity", "dense"), ("maicity", "touched"), ("kitti", "dense"),
-                                           ("kitti", "touched"), ("maicity", "gather"), ("kitti", "gather")])
+                                           ("kitti", "touched"), ("maicity", "gather"), ("kitti", "gather"),
+                                           ("kitti", "gather-micro2")])
 def test_two_ranks_match_one_process(kind, exchange, tmp_path):
     points = 8192 + 40  # per rank; ragged against the 16-point tiles and the sampler's 1024-draw blocks
     two = _run(tmp_path, kind, exchange, points, 2, "two")

@@ -850,7 +850,12 @@ def test_pipelined_incremental_frames_equal_the_sequential_loop():
                     surf = coord[weight > 0]
             else:
                 surf = coord[weight > 0]
-            octree.update(surf, incremental_on=True)
+            # ready: the points were selected on the growth's own stream (frames 0, 2, ...: stated; frame 1: an event says so)
+            ev = None
+            if pipelined and fi % 2 == 1:
+                ev = torch.cuda.Event()
+                ev.record(octree.growth_stream)
+            octree.update(surf, incremental_on=True, ready=(ev if ev is not None else False) if pipelined else None)
             opt = setup_optimizer(cfg, list(octree.parameters()), dec.fused_params())
             pool = SortedPool(octree, coord, label, weight, seed=fi, canonical=True)
             it = GraphedIteration(octree, dec, pool, opt, opts, N, lambda_forget=cfg.lambda_forget, unroll=2, eager_first=False,
@@ -1025,12 +1030,12 @@ def _incremental_trajectory(K, N, BS, n_frames, beams, azimuths, freeze_after=No
                     used.update(elements=n_clean, of=t.numel(), tensor=(fi, key, k))
                 used["deviation"] = max(used["deviation"], d_clean)
         assert not bad, "\n".join(str(r) for r in [bad] + report)
-        for name, o in oracles.items():
-            if name == "shuffled":
-                continue
-            ref = o.losses[-1]
-            tol = 2e-4 if (name == "clean" or fi == 0) else 1e-2
-            assert abs(total - ref) <= tol * max(1.0, abs(ref)), (fi, name, total, ref)
+        ref_clean, ref_lit = oracles["clean"].losses[-1], oracles["literal"].losses[-1]
+        assert abs(total - ref_clean) <= 2e-4 * max(1.0, abs(ref_clean)), (fi, "clean", total, ref_clean)
+        # the literal oracle: at its own distance from the clean one (its noise-amplified features enter lambda_forget = 1e4 times
+        # the regulariser: 1 % of the loss after 10 iterations per frame, 5 % after 50), exactly in the first frame
+        lit_own = 0.0 if fi == 0 else 1.5 * abs(ref_lit - ref_clean)
+        assert abs(total - ref_lit) <= 2e-4 * max(1.0, abs(ref_lit)) + lit_own, (fi, "literal", total, ref_lit, ref_clean)
     assert all(not g for g in octree._reg_grad_on) or seen_quirk  # every level grew again: the attached-clone quirk is live
     if freeze_after is not None:
         assert all(not p.requires_grad for p in dec.parameters()) and n_frames > freeze_after

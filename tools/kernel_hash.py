@@ -14,12 +14,13 @@ import sys
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 DEFAULT_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shine_mapping_amd", "lib",
                            "libshine_hip.so")
-# mangled-name fragments of the kernels bench.py quotes counters for: k_step_v3<L, WAVES, EIK, PROF, EXT, MARK>
+# mangled-name fragments of the kernels bench.py quotes counters for: k_step_v3<L, WAVES, EIK, PROF, EXT, MARK, FAR>
+# (kitti-large: the far build — tables beyond the Infinity Cache, picked by table size)
 STEP_KERNELS = {
-    ("maicity", 4): "k_step_v3ILi4ELi8ELb0ELb0ELb0ELb0EE",
-    ("maicity", 3): "k_step_v3ILi3ELi8ELb0ELb0ELb0ELb0EE",
-    ("kitti", 3): "k_step_v3ILi3ELi8ELb1ELb0ELb0ELb0EE",
-    ("kitti-large", 3): "k_step_v3ILi3ELi8ELb1ELb0ELb0ELb0EE",
+    ("maicity", 4): "k_step_v3ILi4ELi8ELb0ELb0ELb0ELb0ELb0EE",
+    ("maicity", 3): "k_step_v3ILi3ELi8ELb0ELb0ELb0ELb0ELb0EE",
+    ("kitti", 3): "k_step_v3ILi3ELi8ELb1ELb0ELb0ELb0ELb0EE",
+    ("kitti-large", 3): "k_step_v3ILi3ELi8ELb1ELb0ELb0ELb0ELb1EE",
 }
 
 

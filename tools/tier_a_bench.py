@@ -22,6 +22,63 @@ def ref_get_gradient(inputs, outputs):  # utils/tools.py:175-185
                                only_inputs=True)[0]
 
 
+def tier_a_incremental(dev, frames, bs=4096, iters=50, warmup=2, levels=3, ext="1"):
+    """BASELINE config 4 through the UNCHANGED driver's names: the loop body of shine_incre.py:100-195 verbatim
+    on what `import shine_mapping_amd.dropin` binds them to — per frame  octree.update(incremental_on=True)  ->  setup_optimizer
+    (a new Adam, :107-109)  ->  `iters` x {get_batch, query_feature, sdf, sdf_bce_loss(sum), lambda_forget * cal_regularization(),
+    zero_grad / backward / step}  ->  cal_feature_importance — every launch issued eagerly by Python, one frame after the other
+    (the driver synchronises for its timers between the phases, T0..T3).  `frames`: list of (coord, label, weight) per scan.
+    -> dict(frames_per_s, ms_per_frame, ms_per_iteration, split)"""
+    from shine_mapping_amd import Decoder, FeatureOctree, incre_learning
+
+    os.environ["SHINE_TIER_A_EXT"] = ext
+    cfg = synth.make_config("ncd", device=dev, lr=0.01, opt_adam=True, adam_eps=1e-15, lr_level_reduce_ratio=1.0, tree_level_feat=levels)
+    torch.manual_seed(0)
+    octree, geo_mlp = FeatureOctree(cfg), Decoder(cfg)
+    sigma_sigmoid = cfg.sigma_sigmoid
+    gen = torch.Generator(device=dev).manual_seed(1)
+    t_frames, t_iter, t_update, t_sweep = [], [], [], []
+    for fi, (coord, label, weight) in enumerate(frames):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        octree.update(coord[weight > 0], incremental_on=True)                       # dataset.process_frame, lidar_dataset.py:215
+        octree_feat = list(octree.parameters())
+        opt = optim.setup_optimizer(cfg, octree_feat, list(geo_mlp.parameters()))   # shine_incre.py:107-109
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pool = type("P", (), {"coord": coord, "sdf_label": label, "weight": weight})()
+        for _ in range(iters):                                                      # shine_incre.py:114-181
+            c, sdf_label, w = synth.draw_batch(pool, bs, gen)
+            feature = octree.query_feature(c)
+            sdf_pred = geo_mlp.sdf(feature)
+            cur_loss = 0.
+            w = torch.abs(w)
+            sdf_loss = losses.sdf_bce_loss(sdf_pred, sdf_label, sigma_sigmoid, w, False, "sum")
+            cur_loss += sdf_loss
+            reg_loss = octree.cal_regularization()
+            cur_loss += cfg.lambda_forget * reg_loss
+            opt.zero_grad(set_to_none=True)
+            cur_loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)                                             # shine_incre.py:185-188
+        data = type("D", (), {"coord_pool": coord, "sdf_label_pool": label})()
+        incre_learning.cal_feature_importance(data, octree, geo_mlp, sigma_sigmoid, bs, 2, "sum")
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        if fi >= warmup:
+            t_frames.append(t3 - t0), t_update.append(t1 - t0), t_iter.append((t2 - t1) / iters), t_sweep.append(t3 - t2)
+    med = statistics.median
+    return {"frames_per_s": 1.0 / med(t_frames), "ms_per_frame": med(t_frames) * 1e3, "ms_per_iteration": med(t_iter) * 1e3,
+            "split_ms": {"update + new optimiser": med(t_update) * 1e3, "%d iterations" % iters: med(t_iter) * iters * 1e3,
+                         "importance sweep": med(t_sweep) * 1e3},
+            "frames_timed": len(t_frames), "final_loss": float(cur_loss),
+            "autograd_nodes": "C++ extension (lib/_shine_ext.so)" if ext == "1" else "Python (SHINE_TIER_A_EXT=0)",
+            "what": "the loop body of shine_incre.py:100-195 verbatim on the drop-in's classes and re-bound functions; eager launches, "
+                    "one host synchronisation per phase (the driver's T0..T3)"}
+
+
 if os.environ.get("TIER_A_SINGLE_THREAD_AUTOGRAD"):  # experiment: backward on the calling thread (no hand-over to the device thread)
     torch.autograd.set_multithreading_enabled(False)
 CASES = (("maicity", 3, 4096), ("kitti", 3, 4096), ("maicity", 3, 1 << 16), ("kitti", 3, 1 << 16))
@@ -29,7 +86,9 @@ if os.environ.get("TIER_A_SMALL"):
     CASES = CASES[:2]
 # the first case of a process reads the host's own warm-up (allocator, clocks: 0.53 against 0.31 ms for the same loop run second):
 # one discarded pass of the first case in front
-for case_i, (kind, lv, n) in enumerate((CASES[0],) + tuple(CASES)):
+if __name__ != "__main__":
+    CASES = ()
+for case_i, (kind, lv, n) in enumerate(((CASES[0],) + tuple(CASES)) if CASES else ()):
     wl = synth.build_workload(kind, frames=30, device="cuda", seed=42, tree_level_feat=lv)
     octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
     cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio = True, 1e-15, 1.0
@@ -97,3 +156,12 @@ for case_i, (kind, lv, n) in enumerate((CASES[0],) + tuple(CASES)):
         continue
     print(kind, "L%d" % lv, "N=%d" % n, "BCE+eikonal" if eik else "BCE",
           {k: "%.3f ms (min %.3f)" % (statistics.median(v), min(v)) for k, v in times.items()}, flush=True)
+
+if __name__ == "__main__":  # config 4, Tier A: the incremental driver's frame, Python nodes then C++ nodes
+    cfg_i = synth.make_config("ncd", device="cuda", tree_level_feat=3)
+    fr = list(synth.make_frames(cfg_i, frames=10, beams=64, azimuths=900, seed=42, device="cuda"))
+    for ext in ("0", "1"):
+        r = tier_a_incremental("cuda", fr, ext=ext)
+        print("ncd-incre tier A (%s): %.1f frames/s, %.2f ms/frame, %.3f ms/iteration, split %s" % (
+            r["autograd_nodes"], r["frames_per_s"], r["ms_per_frame"], r["ms_per_iteration"],
+            {k: round(v, 3) for k, v in r["split_ms"].items()}), flush=True)
