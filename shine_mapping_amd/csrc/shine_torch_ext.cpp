@@ -201,11 +201,12 @@ struct FusedSdfNode : public Node {
         (*g_read_done)(st->py_id);
       }
     }
-    std::vector<Tensor> views;
+    // (each view goes straight into `out` and is referenced from nowhere else: AccumulateGrad then adopts it as .grad instead
+    // of cloning it — one small copy launch per parameter otherwise)
     int64_t off = 0;
     for (size_t i = 0; i < sizes.size(); ++i) {
       const Tensor& p = i < (size_t)L ? F[i] : M[i - L];
-      views.push_back(sizes[i] ? flat.narrow(0, off, sizes[i]).view(p.sizes()) : Tensor());
+      if (sizes[i]) out[1 + i] = flat.narrow(0, off, sizes[i]).view(p.sizes());
       off += sizes[i];
     }
     std::vector<Tensor> Fc, Mc;
@@ -217,14 +218,14 @@ struct FusedSdfNode : public Node {
     Tensor ws = step_workspace(cc, cfg, stream);
     auto fp = ptrs(Fc), mp = ptrs(Mc);
     std::vector<float*> gf, gm;
-    for (int s = 0; s < L; ++s) gf.push_back(views[s].defined() ? views[s].data_ptr<float>() : nullptr);
-    for (int k = 0; k < 6; ++k) gm.push_back(views[L + k].defined() ? views[L + k].data_ptr<float>() : nullptr);
+    for (int s = 0; s < L; ++s) gf.push_back(out[1 + s].defined() ? out[1 + s].data_ptr<float>() : nullptr);
+    for (int k = 0; k < 6; ++k) gm.push_back(out[1 + L + k].defined() ? out[1 + L + k].data_ptr<float>() : nullptr);
     Tensor qc = q.defined() ? f32c(q) : Tensor();
     check(shine_interp_sdf_backward(t, &cfg, cc.data_ptr<float>(), perm.data_ptr<int>(), slots.data_ptr<int>(), g.data_ptr<float>(),
                                     qc.defined() ? qc.data_ptr<float>() : nullptr, n, fp.data(), st->rows.data(), mp.data(),
                                     gf.data(), need_m ? gm.data() : nullptr, ws.data_ptr(), (size_t)ws.numel(), stream),
           "shine_interp_sdf_backward");
-    for (size_t i = 0; i < views.size(); ++i) out[1 + i] = views[i];
+    flat.reset();
     return out;
   }
   void release_variables() override {

@@ -96,7 +96,7 @@ for case_i, (kind, lv, n) in enumerate(((CASES[0],) + tuple(CASES)) if CASES els
     g = torch.Generator(device="cuda").manual_seed(1)
     sigma = cfg.sigma_sigmoid
 
-    def make_loop(patched, ext="1"):
+    def make_loop(patched, ext="1", single_thread=False):
         feats, mlp = list(octree.parameters()), list(dec.parameters())
         if patched:
             opt = optim.setup_optimizer(cfg, feats, mlp)
@@ -109,6 +109,7 @@ for case_i, (kind, lv, n) in enumerate(((CASES[0],) + tuple(CASES)) if CASES els
 
         def loop():
             os.environ["SHINE_TIER_A_EXT"] = ext  # (read per call: _ext.module())
+            torch.autograd.set_multithreading_enabled(not single_thread)
             autograd_ops.FUSE_WITH_COORD_GRAD = patched
             coord, sdf_label, weight = synth.draw_batch(wl.pool, n, g)
             if eik:
@@ -138,7 +139,9 @@ for case_i, (kind, lv, n) in enumerate(((CASES[0],) + tuple(CASES)) if CASES els
         adam_b.step(zero_grad=True)
 
     loops = {"utils unpatched, Python nodes (r03)": make_loop(False, "0"), "dropin, Python nodes (r04)": make_loop(True, "0"),
-             "dropin, C++ nodes (r05)": make_loop(True, "1"), "tier B (fused step + fused Adam)": tier_b}
+             "dropin, C++ nodes (r05)": make_loop(True, "1"),
+             "dropin, C++ nodes, backward on the calling thread": make_loop(True, "1", True),
+             "tier B (fused step + fused Adam)": tier_b}
     times = {k: [] for k in loops}
     for fn in loops.values():
         for _ in range(5):
