@@ -30,6 +30,11 @@ for anything it does not cover, each with an opt-out environment variable (= "0"
 `FeatureOctree.cal_regularization` (shine_incre.py:156) needs no re-binding: it is a method of the replaced class, and runs as one
 autograd node over two launches whenever it follows a `query_feature` (autograd_ops.OctreeRegularizer).
 
+The drivers are single-threaded, so the drop-in also lets autograd run a backward on the CALLING thread
+(`torch.autograd.set_multithreading_enabled(False)`: the engine's hand-over to its device thread and back is a third of a BCE
+iteration's host time at the reference's batch size — 0.32 -> 0.21 ms, profiles/r05_tier_a_bench.log); SHINE_DROPIN_SINGLE_THREAD_BACKWARD=0
+leaves the engine's default, `uninstall()` restores it.
+
 The re-binding needs `utils.tools` / `utils.loss` to be importable when this module is imported (the drivers import it from the
 reference's root directory, first line); `patch_utils()` can be called again later, `status()` says what is in place.
 """
@@ -66,15 +71,23 @@ def install():
     pkg.feature_octree = fo
     pkg.decoder = de
     _INSTALLED = True
+    if _on("SHINE_DROPIN_SINGLE_THREAD_BACKWARD"):
+        import torch
+
+        _STATUS_KEEP["autograd_multithreading"] = torch.autograd.is_multithreading_enabled()
+        torch.autograd.set_multithreading_enabled(False)
     patch_utils()
 
 
 _STATUS = {}
+_STATUS_KEEP = {}
 
 
 def status():
     """what patch_utils() re-bound (name -> True / the reason it did not)"""
-    return dict(_STATUS)
+    import torch
+
+    return dict(_STATUS, single_thread_backward=not torch.autograd.is_multithreading_enabled())
 
 
 def _on(var):
@@ -178,6 +191,10 @@ def uninstall():
     from . import autograd_ops
 
     autograd_ops.FUSE_WITH_COORD_GRAD = False
+    if "autograd_multithreading" in _STATUS_KEEP:
+        import torch
+
+        torch.autograd.set_multithreading_enabled(_STATUS_KEEP.pop("autograd_multithreading"))
     _STATUS.clear()
     _INSTALLED = False
 

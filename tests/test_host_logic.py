@@ -73,3 +73,33 @@ def test_workload_cache_round_trips_the_built_workload(tmp_path, monkeypatch):
         assert (a.octree._node_keys[s] == b.octree._node_keys[s]).all() and (a.octree._node_ids[s] == b.octree._node_ids[s]).all()
     synth.build_workload("maicity", **dict(kw, frames=3))  # another key: another file
     assert len(list(tmp_path.iterdir())) == 2
+
+
+def test_own_rows_exchange_with_synthetic_peers_multiplies_by_the_world():
+    """dp.RowGatherReducer(synthetic_world=N) — bench.py's kitti-dp8-rank leg: without a process group the all-gather is N
+    copies of this rank's own message, each unpacked and added.  The reduced bucket is then N times the rank's own gradients on
+    the flagged rows (and the decoder tail), untouched rows stay zero, the flags are cleared for the next step."""
+    from shine_mapping_amd.dp import RowGatherReducer
+
+    g = torch.Generator().manual_seed(3)
+    feats = [torch.nn.Parameter(torch.zeros(r, 8)) for r in (17, 41)]
+    mlp = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))]
+    red = RowGatherReducer(feats, mlp, None, synthetic_world=4, capacity_rows=64)
+    red._ensure_flat()
+    rows = {0: [1, 5, 16], 1: [0, 7, 22, 40]}
+    want = []
+    for k, p in enumerate(feats):
+        p.grad.zero_()
+        for r in rows[k]:
+            p.grad[r] = torch.randn(8, generator=g)
+            red.flags[k][r] = 1
+        want.append(p.grad.clone())
+    for p in mlp:
+        p.grad.copy_(torch.randn(p.shape, generator=g))
+        want.append(p.grad.clone())
+    red.exchange()
+    assert red.world() == 4 and not red.overflowed()
+    for p, w in zip(feats + mlp, want):
+        assert torch.allclose(p.grad, 4.0 * w)
+    for k, f in enumerate(red.flags):  # cleared, except the always-exchanged trash rows
+        assert int(f[:-1].sum()) == 0 and int(f[-1]) == 1

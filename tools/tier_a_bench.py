@@ -22,7 +22,7 @@ def ref_get_gradient(inputs, outputs):  # utils/tools.py:175-185
                                only_inputs=True)[0]
 
 
-def tier_a_incremental(dev, frames, bs=4096, iters=50, warmup=2, levels=3, ext="1"):
+def tier_a_incremental(dev, frames, bs=4096, iters=50, warmup=2, levels=3, ext="1", single_thread=True):
     """BASELINE config 4 through the UNCHANGED driver's names: the loop body of shine_incre.py:100-195 verbatim
     on what `import shine_mapping_amd.dropin` binds them to — per frame  octree.update(incremental_on=True)  ->  setup_optimizer
     (a new Adam, :107-109)  ->  `iters` x {get_batch, query_feature, sdf, sdf_bce_loss(sum), lambda_forget * cal_regularization(),
@@ -32,6 +32,8 @@ def tier_a_incremental(dev, frames, bs=4096, iters=50, warmup=2, levels=3, ext="
     from shine_mapping_amd import Decoder, FeatureOctree, incre_learning
 
     os.environ["SHINE_TIER_A_EXT"] = ext
+    mt_before = torch.autograd.is_multithreading_enabled()
+    torch.autograd.set_multithreading_enabled(not single_thread)  # (dropin: backward on the calling thread)
     cfg = synth.make_config("ncd", device=dev, lr=0.01, opt_adam=True, adam_eps=1e-15, lr_level_reduce_ratio=1.0, tree_level_feat=levels)
     torch.manual_seed(0)
     octree, geo_mlp = FeatureOctree(cfg), Decoder(cfg)
@@ -69,12 +71,14 @@ def tier_a_incremental(dev, frames, bs=4096, iters=50, warmup=2, levels=3, ext="
         t3 = time.perf_counter()
         if fi >= warmup:
             t_frames.append(t3 - t0), t_update.append(t1 - t0), t_iter.append((t2 - t1) / iters), t_sweep.append(t3 - t2)
+    torch.autograd.set_multithreading_enabled(mt_before)
     med = statistics.median
     return {"frames_per_s": 1.0 / med(t_frames), "ms_per_frame": med(t_frames) * 1e3, "ms_per_iteration": med(t_iter) * 1e3,
             "split_ms": {"update + new optimiser": med(t_update) * 1e3, "%d iterations" % iters: med(t_iter) * iters * 1e3,
                          "importance sweep": med(t_sweep) * 1e3},
             "frames_timed": len(t_frames), "final_loss": float(cur_loss),
-            "autograd_nodes": "C++ extension (lib/_shine_ext.so)" if ext == "1" else "Python (SHINE_TIER_A_EXT=0)",
+            "autograd_nodes": ("C++ extension (lib/_shine_ext.so)" if ext == "1" else "Python (SHINE_TIER_A_EXT=0)") +
+                              (", backward on the calling thread" if single_thread else ", engine's device thread"),
             "what": "the loop body of shine_incre.py:100-195 verbatim on the drop-in's classes and re-bound functions; eager launches, "
                     "one host synchronisation per phase (the driver's T0..T3)"}
 
@@ -139,8 +143,8 @@ for case_i, (kind, lv, n) in enumerate(((CASES[0],) + tuple(CASES)) if CASES els
         adam_b.step(zero_grad=True)
 
     loops = {"utils unpatched, Python nodes (r03)": make_loop(False, "0"), "dropin, Python nodes (r04)": make_loop(True, "0"),
-             "dropin, C++ nodes (r05)": make_loop(True, "1"),
-             "dropin, C++ nodes, backward on the calling thread": make_loop(True, "1", True),
+             "dropin, C++ nodes, engine's device thread": make_loop(True, "1"),
+             "dropin (r05): C++ nodes, backward on the calling thread": make_loop(True, "1", True),
              "tier B (fused step + fused Adam)": tier_b}
     times = {k: [] for k in loops}
     for fn in loops.values():
@@ -163,8 +167,8 @@ for case_i, (kind, lv, n) in enumerate(((CASES[0],) + tuple(CASES)) if CASES els
 if __name__ == "__main__":  # config 4, Tier A: the incremental driver's frame, Python nodes then C++ nodes
     cfg_i = synth.make_config("ncd", device="cuda", tree_level_feat=3)
     fr = list(synth.make_frames(cfg_i, frames=10, beams=64, azimuths=900, seed=42, device="cuda"))
-    for ext in ("0", "1"):
-        r = tier_a_incremental("cuda", fr, ext=ext)
+    for ext, st in (("0", False), ("1", False), ("1", True)):
+        r = tier_a_incremental("cuda", fr, ext=ext, single_thread=st)
         print("ncd-incre tier A (%s): %.1f frames/s, %.2f ms/frame, %.3f ms/iteration, split %s" % (
             r["autograd_nodes"], r["frames_per_s"], r["ms_per_frame"], r["ms_per_iteration"],
             {k: round(v, 3) for k, v in r["split_ms"].items()}), flush=True)
