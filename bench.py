@@ -389,6 +389,8 @@ def run_incremental(args, dev, steps, warmup, with_cpu_baseline=True, cpu_second
     # the same configuration through the UNCHANGED driver's names (Tier A: shine_incre.py's loop body verbatim on the drop-in's
     # classes, every launch issued by Python; tools/tier_a_bench.py) next to the fused loop above (Tier B)
     try:
+        if args.no_tier_a:
+            raise RuntimeError("skipped (--no-tier-a)")
         from tier_a_bench import tier_a_incremental
 
         n_a = min(len(frames), 8)
@@ -1128,6 +1130,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of exactly --steps steps each; the line reports the median window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tier-a", action="store_true", help="ncd-incre: skip the Tier A (unchanged driver's loop) measurement")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default invocation: skip the abbreviated kitti / ncd-incre legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
