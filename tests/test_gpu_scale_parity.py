@@ -619,6 +619,49 @@ def test_tier_a_eikonal_loop_on_the_fused_node(name):
         autograd_ops.FUSE_WITH_COORD_GRAD = False
 
 
+@pytest.mark.parametrize("kind", ["maicity", "kitti"])
+def test_tier_a_loop_at_65k_points_matches_the_fused_step(kind):
+    """The drop-in loop body (query_feature -> sdf -> [get_gradient] -> sdf_bce_loss [+ eikonal] -> backward) on an UNORDERED batch
+    of 2^16 + 3 points — the fused node's backward then runs the 8-wave EXT build of the step kernel (corner ids one tile ahead,
+    a planned batch: slots by position, coordinates through perm) — against Tier B's fused step on the same batch."""
+    from shine_mapping_amd import StepOptions, autograd_ops, fused_train_step, get_gradient, sdf_bce_loss, synth
+
+    wl = _workload(kind, 3)
+    octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
+    n = (1 << 16) + 3
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    coord, label, weight = synth.draw_batch(wl.pool, n, gen)
+    params = list(octree.hier_features) + dec.fused_params()
+    eik = bool(cfg.ekional_loss_on)
+    opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=eik, weight_e=cfg.weight_e)
+    for p in params:
+        p.grad = None
+    loss_b, pred_b, _ = fused_train_step(octree, dec, coord, label, weight, opts)
+    torch.cuda.synchronize()
+    want = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    autograd_ops.FUSE_WITH_COORD_GRAD = True
+    try:
+        c = coord.clone().requires_grad_(eik)
+        pred = dec.sdf(octree.query_feature(c))
+        assert "FusedInterpSdf" in node_name(pred.grad_fn)
+        cur_loss = sdf_bce_loss(pred, label, cfg.sigma_sigmoid, torch.abs(weight), False, cfg.loss_reduction)
+        if eik:
+            g = get_gradient(c, pred) * cfg.sigma_sigmoid
+            cur_loss = cur_loss + cfg.weight_e * ((1.0 - g[weight > 0].norm(2, dim=-1)) ** 2).mean()
+        cur_loss.backward()
+    finally:
+        autograd_ops.FUSE_WITH_COORD_GRAD = False
+    torch.cuda.synchronize()
+    assert abs_err(pred, pred_b) <= 1e-5
+    assert abs(float(cur_loss) - float(loss_b)) <= 1e-5 * max(1.0, abs(float(loss_b)))
+    errs = decoder_grad_errs([p.grad for p in params[3:]], want[3:])
+    assert max(errs) <= TOL, errs
+    for k in range(3):
+        assert rel_err(params[k].grad, want[k]) <= TOL, "feature grad level %d" % k
+
+
 def test_query_feature_speculates_the_decoder_and_notices_changed_weights():
     """From the second iteration on, query_feature's launch also evaluates the decoder that consumed this octree's features last
     (the drivers' next line is `geo_mlp.sdf(feature)`, shine_batch.py:123-124), and Decoder.sdf launches nothing — but only while
