@@ -1065,6 +1065,41 @@ def test_tier_a_incremental_frames_match_the_oracle_trajectory():
     _incremental_trajectory(K=10, N=1024, BS=1024, n_frames=3, beams=16, azimuths=120, tier="A")
 
 
+def test_retired_table_arrays_are_accounted_and_trimmed():
+    """device arrays a growth replaces (a rehashed hash table, an outgrown scratch buffer) are retired inside
+    the table handle, not freed on the spot; FeatureOctree.retired_table_bytes() reports them and trim_tables() frees them —
+    after which the tables still answer queries as before.  The importance sweep's scratch is given back by release_scratch()."""
+    from shine_mapping_amd import Decoder, FeatureOctree, incre_learning, synth
+
+    cfg = synth.make_config("ncd", device="cuda")
+    frames = list(synth.make_frames(cfg, frames=6, beams=32, azimuths=240, seed=7, device="cuda"))
+    torch.manual_seed(0)
+    octree, dec = FeatureOctree(cfg), Decoder(cfg).cuda()
+    for coord, label, weight in frames:
+        octree.update(coord[weight > 0], incremental_on=True)
+    coord = frames[-1][0][:5000].contiguous()
+    with torch.no_grad():
+        before = octree.query_feature(coord).clone()
+        idx_before = [t.clone() for t in octree.get_indices(coord)]
+    held = octree.retired_table_bytes()
+    assert held > 0  # six frames of growth rehashed the tables at least once
+    assert octree.trim_tables() == held and octree.retired_table_bytes() == 0
+    with torch.no_grad():
+        assert torch.equal(octree.query_feature(coord), before)
+    assert all(torch.equal(a, b) for a, b in zip(octree.get_indices(coord), idx_before))
+    octree.trim_retired_above = 0  # the automatic form: update() trims whatever its growth retired
+    more = list(synth.make_frames(cfg, frames=12, beams=32, azimuths=240, seed=8, device="cuda"))[6:]
+    for c, l, w in more:
+        octree.update(c[w > 0], incremental_on=True)
+    assert octree.retired_table_bytes() == 0
+    data = type("Pool", (), {"coord_pool": frames[-1][0], "sdf_label_pool": frames[-1][1]})()
+    incre_learning.cal_feature_importance(data, octree, dec, cfg.sigma_sigmoid, 4096, 2, "sum")
+    torch.cuda.synchronize()
+    assert len(incre_learning._SCRATCH) == 1
+    incre_learning.release_scratch()
+    assert len(incre_learning._SCRATCH) == 0 and len(incre_learning._BUDGET) == 0
+
+
 def test_stale_pool_is_rejected_after_octree_growth():
     from shine_mapping_amd import StepOptions, fused_train_step
     from shine_mapping_amd.sampler import SortedPool

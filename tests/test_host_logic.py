@@ -103,3 +103,31 @@ def test_own_rows_exchange_with_synthetic_peers_multiplies_by_the_world():
         assert torch.allclose(p.grad, 4.0 * w)
     for k, f in enumerate(red.flags):  # cleared, except the always-exchanged trash rows
         assert int(f[:-1].sum()) == 0 and int(f[-1]) == 1
+
+
+def test_fused_adam_state_dict_has_torch_adams_layout():
+    """ADVICE r04 (high), the host half: FusedAdam.state_dict() / load_state_dict() in torch.optim.Adam's layout — what the
+    reference's save_checkpoint stores (utils/tools.py:200-213) — without a device: torch's Adam loads it, and a FusedAdam loads
+    torch's (the GPU test test_fused_adam_state_dict_round_trips_through_torch_adam continues both and compares the steps)."""
+    from shine_mapping_amd.optim import FusedAdam
+
+    ps = [torch.nn.Parameter(torch.randn(4, 8)) for _ in range(3)]
+    groups = [{"params": ps[:2], "lr": 0.01, "weight_decay": 1e-7}, {"params": [ps[2]], "lr": 0.005}]
+    fa = FusedAdam(groups)
+    assert fa.state_dict()["state"] == {}  # (torch creates a parameter's state at its first step)
+    for p in ps:
+        fa.state[p] = (torch.randn_like(p), torch.rand_like(p))
+        fa._age[p] = 3
+    fa.step_count = 3
+    sd = fa.state_dict()
+    ta = torch.optim.Adam([{"params": ps[:2], "lr": 0.3}, {"params": [ps[2]], "lr": 0.3}], betas=(0.5, 0.5), eps=1.0)
+    assert sorted(sd["param_groups"][0]) == sorted(ta.state_dict()["param_groups"][0])
+    ta.load_state_dict(sd)
+    assert ta.param_groups[0]["lr"] == 0.01 and ta.param_groups[0]["betas"] == (0.9, 0.99) and ta.param_groups[1]["lr"] == 0.005
+    assert float(ta.state[ps[0]]["step"]) == 3.0 and torch.equal(ta.state[ps[2]]["exp_avg"], fa.state[ps[2]][0])
+    fb = FusedAdam(groups, betas=(0.1, 0.1), eps=1.0)
+    fb.load_state_dict(ta.state_dict())
+    assert fb.betas == (0.9, 0.99) and fb.eps == 1e-15 and fb.step_count == 3 and fb._age[ps[1]] == 3
+    assert torch.equal(fb.state[ps[1]][1], fa.state[ps[1]][1]) and fb.param_groups[1]["lr"] == 0.005
+    with pytest.raises(ValueError):
+        FusedAdam(groups[:1]).load_state_dict(sd)
