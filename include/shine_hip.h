@@ -341,7 +341,9 @@ int shine_adam_step(int32_t n_tensors, float* const* params, float* const* grads
  *      to shine_train_step.  zero_ptr/zero_bytes (16-B aligned, may be NULL/0): a buffer cleared in the same pass —
  *      the flat gradient bucket, i.e. opt.zero_grad() for the fused step.  workspace == NULL returns the required
  *      bytes.  Replaces shine_morton_sort on the training path: ~3 small launches, and the fused kernel no longer
- *      hashes or probes. ------------------------------------------------------------------------------------------ */
+ *      hashes or probes.  Batches of <= 16384 points (the reference's batch size is 4096) are NOT reordered — perm_out is the
+ *      identity, one launch: the fused step does not see the order at that size — unless cfg->kernel_variant has bit 0x800 set
+ *      (a sample POOL that is planned once and drawn from many times wants the node order at any size). -------------------- */
 int shine_tables_set_ranks(shine_tables* t, int32_t slot, const int64_t* keys, const int32_t* ranks, int64_t n,
                            int64_t n_buckets, void* stream);
 int shine_plan_batch(const shine_tables* t, const shine_step_config* cfg, const float* coord, int64_t n,

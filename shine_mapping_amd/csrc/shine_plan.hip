@@ -15,6 +15,7 @@
 // Points of one node end up adjacent (what the fused kernel's run-length scatter needs), nodes follow the Z-order
 // (L2 locality), and the heavy MFMA kernel no longer hashes or probes: it reads its slots coalesced.
 // ~3 small launches instead of a histogram + 3..5 radix passes; order inside a bucket is arbitrary (atomics).
+// Batches of <= 16384 points (the reference's batch size is 4096) take ONE launch and are not reordered: k_plan_unsorted.
 #include <cstring>
 
 #include "shine_internal.hpp"
@@ -38,7 +39,7 @@ struct PlanArgs {
   int* local;        // [n] rank of the point inside its bucket (returned by the counting atomic)
   float4* zero_ptr;  // optional buffer to clear in the same pass (the flat gradient bucket), 16-B units
   long long zero_n16;
-  int ablate;  // debug (kernel_variant >> 8): 1 no counting atomics, 2 no probes (all miss), 4 no slot stores
+  int ablate;  // debug (kernel_variant >> 8): 1 no counting atomics, 2 no probes (all miss), 4 no slot stores, 8 sort small batches too
   int* slots_tmp;    // [n][L]
   int* perm;         // [n]
   int* slots_sorted; // [n][L]
@@ -49,15 +50,9 @@ struct PlanArgs {
 // group with ONE atomic (ballot + popcount); node buckets hold a handful of points each and use plain atomics.
 constexpr int MISS_BUCKETS = 64;
 
-__global__ __launch_bounds__(256) void k_plan_count(PlanArgs a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  // ride-along memset of the gradient bucket (what opt.zero_grad amounts to): streaming stores overlap with this
-  // kernel's dependent probe loads instead of costing a launch of their own
-  for (long long z = i; z < a.zero_n16; z += (long long)gridDim.x * 256) a.zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool live = i < a.n;
+// probe all levels for point i: writes its hash slots (slots_tmp) and returns the rank of the deepest node that holds it (-1: none)
+__device__ __forceinline__ int plan_probe(const PlanArgs& a, long long i) {
   int b = -1;
-  if (live && !(a.ablate & 2)) {
   const float x0 = a.coord[3 * i], x1 = a.coord[3 * i + 1], x2 = a.coord[3 * i + 2];
   const unsigned long long kleaf = morton3(quantize(x0, a.res_leaf), quantize(x1, a.res_leaf), quantize(x2, a.res_leaf));
   const int L = a.n_levels;
@@ -99,7 +94,18 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a) {
       if (found >= 0) b = rk;
     }
   }
-  }
+  return b;
+}
+
+__global__ __launch_bounds__(256) void k_plan_count(PlanArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  // ride-along memset of the gradient bucket (what opt.zero_grad amounts to): streaming stores overlap with this
+  // kernel's dependent probe loads instead of costing a launch of their own
+  for (long long z = i; z < a.zero_n16; z += (long long)gridDim.x * 256) a.zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool live = i < a.n;
+  int b = -1;
+  if (live && !(a.ablate & 2)) b = plan_probe(a, i);
   const bool miss = live && b < 0;
   const unsigned long long mm = __ballot(miss);
   int loc = 0;
@@ -128,6 +134,21 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PlanArgs a) {
   const int pos = a.count[a.bucket[i]] + a.local[i];  // count[] holds the exclusive offsets by now: no atomics
   a.perm[pos] = (int)i;
   for (int s = 0; s < L; ++s) a.slots_sorted[(long long)pos * L + s] = a.slots_tmp[i * L + s];
+}
+
+// The reference's batch size (4096 points: every shipped yaml; anything up to 16384) is planned WITHOUT the sort: at that size the
+// fused step is a few tiles per wave and bound by latency, not by its atomics or the L2 — what the node order buys a 2^18-point batch (merged node runs,
+// locality) is below the noise there, while the histogram over the tree's 10^5..10^7 node ranks costs four launches and ~25 us.
+// One launch: probe the slots, perm = identity (deterministic), clear the gradient bucket.  profiles/r05_ab_experiments.txt block 9
+// (a one-workgroup bitonic sort in LDS was measured first: 53-68 us on the device, VALU- and TA-bound on its single CU).
+constexpr int PLAN_UNSORTED_MAX = 16384;  // (measured: the step does not see the order up to here; at 65536 it is 1.6x slower unsorted)
+
+__global__ __launch_bounds__(256) void k_plan_unsorted(PlanArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (long long z = i; z < a.zero_n16; z += (long long)gridDim.x * 256) a.zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i >= a.n) return;
+  plan_probe(a, i);  // (slots_tmp IS slots_sorted here)
+  a.perm[i] = (int)i;
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -189,6 +210,13 @@ extern "C" int shine_plan_batch(const shine_tables* t, const shine_step_config* 
   a.slots_tmp = (int*)(w + o_slots);
   a.perm = (int*)perm_out;
   a.slots_sorted = (int*)slots_out;
+  if (n <= PLAN_UNSORTED_MAX && !(a.ablate & 15)) {  // (kernel_variant 0x800: tests / measurement — the counting sort for every size)
+    a.slots_tmp = a.slots_sorted;
+    const long long pb = (n + 255) / 256, zb = (a.zero_n16 + 256 * 8 - 1) / (256 * 8);  // zeroing: ~8 float4 per thread
+    hipLaunchKernelGGL(k_plan_unsorted, dim3((unsigned)(pb > zb ? pb : zb < 2048 ? zb : 2048)), dim3(256), 0, st, a);
+    SHINE_HIP_CHECK(hipGetLastError());
+    return SHINE_OK;
+  }
   SHINE_HIP_CHECK(hipMemsetAsync(a.count, 0, nb * 4, st));
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   hipLaunchKernelGGL(k_plan_count, grid, block, 0, st, a);

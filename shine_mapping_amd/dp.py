@@ -113,8 +113,11 @@ def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
     return perm
 
 
-def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None, _debug_variant: int = 0, out=None):
-    """Order the batch by octree node (counting sort over the node ranks) and look up every point's hash slots.
+def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None, _debug_variant: int = 0, out=None, sort: bool = None):
+    """Order the batch by octree node (counting sort over the node ranks) and look up every point's hash slots.  Batches of
+    <= 16384 points (the reference's batch size is 4096) are left in the order given (perm = identity, ONE launch: the fused step
+    does not see the order at that size and the histogram runs over every node of the tree) unless sort=True — a sample pool that
+    is planned once and drawn from many times (sampler.SortedPool, the importance sweep) asks for the node order at any size.
 
     Returns (perm [N] int32, slots [N, L] int32), both on the device, to pass to fused_train_step(perm=, slots=).
     Cheaper than morton_order (3 small launches vs a multi-pass radix sort) and it moves the hash probing out of the
@@ -124,7 +127,7 @@ def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None, _debug_va
     coord = octree._check_coord(coord.detach())
     n = coord.shape[0]
     L = octree.featured_level_num
-    cfg = octree.step_config(kernel_variant=_debug_variant)
+    cfg = octree.step_config(kernel_variant=_debug_variant | (0x800 if sort else 0))
     lib = _lib.lib()
     stream = _lib.current_stream_handle()
     # ONE grow-only scratch buffer per device.  plan_batch never runs inside a captured graph, so replacing the buffer by a

@@ -598,11 +598,14 @@ class FeatureOctree(nn.Module):
             off += n
         return out
 
+    DEBUG_VARIANT_BITS = 0  # measurement only (tools/): OR-ed into every launch's kernel_variant, e.g. 0x800 = plan with the counting sort
+
     def _ext_state(self, ext):
         """The C++ extension's view of this octree (csrc/shine_torch_ext.cpp TierAState): table handle, scalar configuration,
         row counts — refreshed when the tables grew or were rebuilt (both bump _tables_epoch)."""
         d = self.__dict__
-        key = (self._tables_epoch, self._tables.handle.value if self._tables is not None else 0, len(self.hier_features))
+        key = (self._tables_epoch, self._tables.handle.value if self._tables is not None else 0, len(self.hier_features),
+               FeatureOctree.DEBUG_VARIANT_BITS)
         st = d.get("_ext_st")
         if st is None or d.get("_ext_key") != key:
             from . import _ext
@@ -627,6 +630,7 @@ class FeatureOctree(nn.Module):
             cfg.sort_bits[0], cfg.sort_bits[1], cfg.sort_bits[2] = bits
         for k, v in kw.items():
             setattr(cfg, k, v)
+        cfg.kernel_variant |= FeatureOctree.DEBUG_VARIANT_BITS
         return cfg
 
     def _sort_box(self):

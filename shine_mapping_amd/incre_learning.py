@@ -99,7 +99,7 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
         perm, slots = pool.perm, pool.slots
         coord_s, label_s = octree._check_coord(pool.coord), pool.sdf_label.to(torch.float32).contiguous()
     else:
-        perm, slots = plan_batch(octree, coord_pool)  # sorted position j holds pool sample perm[j]
+        perm, slots = plan_batch(octree, coord_pool, sort=True)  # sorted position j holds pool sample perm[j]
         p = perm.long()
         coord_s = octree._check_coord(coord_pool)[p].contiguous()
         label_s = label_pool[p].contiguous()

@@ -67,7 +67,7 @@ class SortedPool:
         self.rebuild(coord, sdf_label, weight)
 
     def rebuild(self, coord, sdf_label, weight):
-        perm, slots = plan_batch(self.octree, coord)
+        perm, slots = plan_batch(self.octree, coord, sort=True)  # (node order whatever the pool's size: it is drawn from many times)
         if self.canonical and perm.numel() > 1:
             order = canonical_order(perm, slots)
             perm, slots = perm[order].contiguous(), slots[order].contiguous()

@@ -334,39 +334,76 @@ def test_octree_pickle_roundtrip_keeps_tables():
 @pytest.mark.parametrize("name", ["maicity_bce_L4", "kitti_eik_L3", "linear_L2_nopoly"])
 def test_plan_batch_counting_sort_and_planned_step(name):
     """shine_plan_batch: perm is a permutation, points of one (deepest) node are adjacent, the slots agree with
-    get_indices' hits, and the fused step fed (perm, slots) reproduces the reference."""
+    get_indices' hits, and the fused step fed (perm, slots) reproduces the reference — for the counting sort (forced on these small
+    batches with kernel_variant 0x800: batches of <= 16384 points are not reordered by default) and for the default plan."""
     from shine_mapping_amd import dp, fused_train_step
 
     fx = load_golden(name)
-    cfg, octree, dec = product_from_golden(fx)
     coord = fx["coord"].cuda()
+    for variant in (0x800, 0):
+        cfg, octree, dec = product_from_golden(fx)
+        perm, slots = dp.plan_batch(octree, coord, _debug_variant=variant)
+        torch.cuda.synchronize()
+        n, L = coord.shape[0], cfg.tree_level_feat
+        p = perm.cpu().long()
+        assert torch.equal(torch.sort(p).values, torch.arange(n))
+        sl = slots.cpu()
+        assert sl.shape == (n, L)
+        ref_idx = fx["out"]["indices"]  # bottom-up; slots are top-down
+        for s in range(L):
+            hit_ref = (ref_idx[L - 1 - s][:, 0] >= 0)[p]
+            assert torch.equal(sl[:, s] >= 0, hit_ref), "level slot %d hit pattern" % s
+        if variant or n > 16384:  # points that share their deepest node are contiguous in the visiting order
+            deepest = torch.full((n,), -1, dtype=torch.int64)
+            for s in range(L):
+                deepest = torch.where(sl[:, s] >= 0, sl[:, s].long() + (s << 40), deepest)
+            change = (deepest[1:] != deepest[:-1]).sum().item() + 1
+            assert change == len(torch.unique(deepest)), "a node's points are split into several runs"
+        else:
+            assert torch.equal(p, torch.arange(n))
+        loss, pred, g = fused_train_step(octree, dec, coord, fx["sdf_label"].cuda(), fx["weight"].cuda(), step_options(fx),
+                                         want_grad_x=True, perm=perm, slots=slots)
+        ref = fx["out"]
+        assert abs_err(pred, ref["pred"]) <= TOL
+        if ref["g"] is not None:
+            assert rel_err(g, ref["g"]) <= TOL
+        for k, r in enumerate(ref["feat_grads"]):
+            assert rel_err(octree.hier_features[k].grad, r) <= TOL
+        for k, (pp, r) in enumerate(zip(dec.fused_params(), ref["mlp_grads"])):
+            assert rel_err(pp.grad, r) <= TOL
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 1000, 4096, 16383, 16384, 16385])
+def test_small_batches_are_planned_in_one_launch_and_not_reordered(n):
+    """Batches of <= 16384 points (the reference's batch size is 4096) are not sorted (k_plan_unsorted: the node order buys a one-tile-per-wave
+    step nothing and its histogram runs over every node of the tree): perm is the identity, every point's hash slots are the ones the
+    counting sort finds, the ride-along clear of the gradient bucket still happens, and the plan is deterministic.  16385 points: the
+    counting sort."""
+    from shine_mapping_amd import dp
+
+    fx = load_golden("kitti_eik_L3")
+    cfg, octree, dec = product_from_golden(fx)
+    g = torch.Generator().manual_seed(n)
+    base = fx["coord"]
+    coord = base[torch.randint(0, base.shape[0], (n,), generator=g)].clone()
+    coord[::7] += 0.9  # some points that miss everywhere
+    coord = coord.cuda()
     perm, slots = dp.plan_batch(octree, coord)
+    sperm, sslots = dp.plan_batch(octree, coord, _debug_variant=0x800)
     torch.cuda.synchronize()
-    n, L = coord.shape[0], cfg.tree_level_feat
-    p = perm.cpu().long()
-    assert torch.equal(torch.sort(p).values, torch.arange(n))
-    sl = slots.cpu()
-    assert sl.shape == (n, L)
-    ref_idx = fx["out"]["indices"]  # bottom-up; slots are top-down
-    for s in range(L):
-        hit_ref = (ref_idx[L - 1 - s][:, 0] >= 0)[p]
-        assert torch.equal(sl[:, s] >= 0, hit_ref), "level slot %d hit pattern" % s
-    # points that share their deepest node are contiguous in the visiting order
-    deepest = torch.full((n,), -1, dtype=torch.int64)
-    for s in range(L):
-        deepest = torch.where(sl[:, s] >= 0, sl[:, s].long() + (s << 40), deepest)
-    change = (deepest[1:] != deepest[:-1]).sum().item() + 1
-    assert change == len(torch.unique(deepest)), "a node's points are split into several runs"
-    loss, pred, g = fused_train_step(octree, dec, coord, fx["sdf_label"].cuda(), fx["weight"].cuda(), step_options(fx),
-                                     want_grad_x=True, perm=perm, slots=slots)
-    ref = fx["out"]
-    assert abs_err(pred, ref["pred"]) <= TOL
-    if ref["g"] is not None:
-        assert rel_err(g, ref["g"]) <= TOL
-    for k, r in enumerate(ref["feat_grads"]):
-        assert rel_err(octree.hier_features[k].grad, r) <= TOL
-    for k, (pp, r) in enumerate(zip(dec.fused_params(), ref["mlp_grads"])):
-        assert rel_err(pp.grad, r) <= TOL
+    p, sl, sp, ssl = perm.cpu().long(), slots.cpu(), sperm.cpu().long(), sslots.cpu()
+    assert torch.equal(torch.sort(p).values, torch.arange(n)) and torch.equal(torch.sort(sp).values, torch.arange(n))
+    assert torch.equal(p, torch.arange(n)) == (n <= 16384)
+    by_point, s_by_point = torch.empty_like(sl), torch.empty_like(ssl)
+    by_point[p] = sl
+    s_by_point[sp] = ssl
+    assert torch.equal(by_point, s_by_point)
+    for floats in (4, 1 << 20, (1 << 26) + 4):  # the gradient bucket rides on the launch
+        flat = torch.ones(floats, device="cuda")
+        perm3, slots3 = dp.plan_batch(octree, coord, zero=flat)
+        assert float(flat.abs().sum()) == 0.0
+        if n <= 16384:
+            assert torch.equal(perm3.cpu().long(), p) and torch.equal(slots3.cpu(), sl)
 
 
 def test_fused_regulariser_and_importance_sweep_match_reference():
