@@ -275,12 +275,12 @@ class FeatureSource:
         self.q = None     # d loss / d (d pred / d coord), stashed by InterpSdfGradCoord.backward
         self.spec = octree.__dict__.pop("_spec_result", None)  # (pred, decoder, its parameters, parameter epoch) or None
 
-    def speculated(self, decoder):
+    def speculated(self, decoder, mlp=None):
         """the decoder output query_feature's launch already computed, if it is `decoder`'s on unchanged parameters"""
         s = self.spec
         if s is None or s[1] is not decoder or s[3] != param_epoch():
             return None
-        if any(a is not b or a._version != v for a, b, v in zip(decoder.fused_params(), s[2], s[4])):
+        if any(a is not b or a._version != v for a, b, v in zip(mlp if mlp is not None else decoder.fused_params(), s[2], s[4])):
             return None
         return s[0]
 

@@ -9,11 +9,14 @@ tier never calls it — the fused HIP step reads the six parameter tensors direc
 The out-of-scope heads (time-conditioned, semantic; flags off in every shipped yaml) and other decoder shapes
 are plain torch composites, as in the reference.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _ext, _lib, autograd_ops
+from .autograd_ops import FusedInterpSdf, FusedMLP
 
 
 class Decoder(nn.Module):
@@ -40,31 +43,33 @@ class Decoder(nn.Module):
 
     # model/decoder.py:49-63
     def sdf(self, sum_features):
-        if (self.fusable and sum_features.is_cuda and sum_features.dtype == torch.float32 and sum_features.dim() == 2
-                and self._params_on(sum_features.device)):
-            from .autograd_ops import FusedInterpSdf, FusedMLP
-
+        if self.fusable and sum_features.is_cuda and sum_features.dtype == torch.float32 and sum_features.dim() == 2:
+            mlp = self.fused_params()
             src = getattr(sum_features, "_shine_src", None)
+            # (the six tensors query_feature's launch already evaluated this decoder on were checked there, a moment ago)
+            spec = src.speculated(self, mlp) if src is not None else None
+            if spec is None and not self._params_on(sum_features.device, mlp):
+                return self._sdf_composite(sum_features)
             if src is not None and torch.is_grad_enabled() and sum_features.requires_grad and src.fusable(sum_features):
                 # the untouched output of FeatureOctree.query_feature (shine_batch.py:123-124): interpolation + decoder as
                 # ONE autograd node whose backward is one fused launch
-                import weakref
-
-                src.octree.__dict__["_spec_decoder"] = weakref.ref(self)  # (the next query_feature evaluates this decoder too)
-                from . import _ext, autograd_ops
-
+                octree = src.octree
+                octree.__dict__["_spec_decoder"] = weakref.ref(self)  # (the next query_feature evaluates this decoder too)
                 ext = _ext.module()
-                feats, mlp = src.octree.feature_list(), self.fused_params()
+                feats = octree.feature_list()
                 if ext is not None and src.coord.is_cuda:  # the C++ node (csrc/shine_torch_ext.cpp)
-                    src.octree._require_tables(with_ranks=True, probe=False)  # (its backward plans the batch: node ranks)
-                    pred, link = ext.fused_sdf(src.octree._ext_state(ext), sum_features, src.coord, src.speculated(self), feats,
-                                               mlp, autograd_ops.DETERMINISTIC_BACKWARD)
+                    octree._require_tables(with_ranks=True, probe=False)  # (its backward plans the batch: node ranks)
+                    pred, link = ext.fused_sdf(octree._ext_state(ext), sum_features, src.coord, spec, feats, mlp,
+                                               autograd_ops.DETERMINISTIC_BACKWARD)
                     pred._shine_link = (src, tuple(feats) + tuple(mlp), link)
                     return pred
-                pred = FusedInterpSdf.apply(sum_features.detach(), src.coord, src.octree, src, src.speculated(self), *feats, *mlp)
+                pred = FusedInterpSdf.apply(sum_features.detach(), src.coord, octree, src, spec, *feats, *mlp)
                 pred._shine_link = (src, tuple(feats) + tuple(mlp), None)
                 return pred
-            return FusedMLP.apply(sum_features, *self.fused_params())
+            return FusedMLP.apply(sum_features, *mlp)
+        return self._sdf_composite(sum_features)
+
+    def _sdf_composite(self, sum_features):
         h = sum_features  # other shapes / devices: the reference's composite
         for l in self.layers:
             h = F.relu(l(h))
@@ -92,10 +97,10 @@ class Decoder(nn.Module):
         return torch.argmax(self.sem_label_prob(sum_features), dim=1)
 
     # ---- fused-path plumbing
-    def _params_on(self, device) -> bool:
+    def _params_on(self, device, mlp=None) -> bool:
         """the HIP decoder reads the six tensors in place: CUDA float32 contiguous on the input's device, or the composite runs"""
         return all(p.is_cuda and p.device == device and p.dtype == torch.float32 and p.is_contiguous()
-                   for p in self.fused_params())
+                   for p in (mlp if mlp is not None else self.fused_params()))
 
     def fused_params(self):
         """W1,b1,W2,b2,w3,b3 in the order libshine_hip expects."""

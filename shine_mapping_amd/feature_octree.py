@@ -23,7 +23,19 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _ext, _lib, autograd_ops
+
+_OPS = None
+
+
+def _ops():
+    """ops, imported on first use (ops imports this module's types) — not per call: a function-level import costs ~1 us"""
+    global _OPS
+    if _OPS is None:
+        from . import ops
+
+        _OPS = ops
+    return _OPS
 
 _CORNER_OFFSETS = np.array([[(j >> 2) & 1, (j >> 1) & 1, j & 1] for j in range(8)], dtype=np.int64)
 
@@ -608,8 +620,6 @@ class FeatureOctree(nn.Module):
                FeatureOctree.DEBUG_VARIANT_BITS)
         st = d.get("_ext_st")
         if st is None or d.get("_ext_key") != key:
-            from . import _ext
-
             if st is None:
                 st = d["_ext_st"] = ext.TierAState()
             st.set(int(self._tables.handle.value), bytes(self.step_config()), [int(r) for r in self.row_counts()],
@@ -695,15 +705,11 @@ class FeatureOctree(nn.Module):
     # ------------------------------------------------------------------ :237-244
     def query_feature(self, coord, faster=False):
         """`faster` (get_indices_fast, :267-286) is a CPU-side dedup trick; on the GPU both paths are the same."""
-        from .ops import octree_interp  # late import: ops imports this module's types
-
         # set_zero (:238) happens inside the forward kernel (shine_forward re-zeroes the trash rows): L python index ops and L
         # fill launches less per query
-        feat = octree_interp(self, coord)
+        feat = _ops().octree_interp(self, coord)
         if feat.requires_grad:  # lets Decoder.sdf fuse the two calls into one autograd node (autograd_ops.FusedInterpSdf)
-            from .autograd_ops import FeatureSource
-
-            feat._shine_src = FeatureSource(self, coord, feat)
+            feat._shine_src = autograd_ops.FeatureSource(self, coord, feat)
         return feat
 
     # ------------------------------------------------------------------ :246-255

@@ -12,7 +12,8 @@ import torch
 import torch.nn as nn
 from torch.autograd import grad
 
-from . import _lib
+from . import _ext, _lib
+from .autograd_ops import InterpSdfGradCoord
 
 
 class _SdfBce(torch.autograd.Function):
@@ -51,8 +52,6 @@ def sdf_bce_loss(pred, label, sigma, weight, weighted=False, bce_reduction="mean
     if (pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 1 and pred.shape[0] > 0 and label.shape == pred.shape
             and label.device == pred.device and bce_reduction in ("mean", "sum") and not isinstance(sigma, torch.Tensor)
             and (w is None or (w.shape == pred.shape and w.device == pred.device)) and not label.requires_grad):
-        from . import _ext
-
         ext = _ext.module()
         if ext is not None:  # the C++ node (csrc/shine_torch_ext.cpp)
             return ext.bce_loss(pred, label, w, float(sigma), bce_reduction == "sum")
@@ -65,12 +64,8 @@ def get_gradient(inputs, outputs):
     node and its own coord: one launch (autograd_ops.InterpSdfGradCoord); otherwise the reference's autograd call."""
     link = getattr(outputs, "_shine_link", None)
     if link is not None and link[0].coord is inputs and inputs.requires_grad and torch.is_grad_enabled():
-        from .autograd_ops import InterpSdfGradCoord
-
         src, params, ext_link = link
         if ext_link is not None:  # the fused node is the C++ one: so is this (csrc/shine_torch_ext.cpp)
-            from . import _ext
-
             ext = _ext.module()
             L = src.octree.featured_level_num
             return ext.grad_coord(src.octree._ext_state(ext), outputs, inputs, ext_link, list(params[:L]), list(params[L:]))

@@ -17,7 +17,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _ext, _lib, autograd_ops
 
 
 @dataclass
@@ -266,28 +266,24 @@ def octree_interp(octree, coord):
         coord.requires_grad or any(p.requires_grad for p in octree.hier_features)
     )
     if needs_grad:
-        from . import _ext
-
         ext = _ext.module()
         if ext is not None and coord.is_cuda and octree.featured_level_num <= 4:
             return _ext_query(ext, octree, coord)  # the C++ node (csrc/shine_torch_ext.cpp)
-        from .autograd_ops import OctreeInterp  # Tier A
-
-        return OctreeInterp.apply(coord, octree, *octree.feature_list())
+        return autograd_ops.OctreeInterp.apply(coord, octree, *octree.feature_list())
     return _interp_forward(octree, coord)
 
 
 def _ext_query(ext, octree, coord):
     """autograd_ops.OctreeInterp.forward on the C++ side: shine_forward, with the decoder that consumed this octree's features
     last riding on the launch (FeatureSource.speculated)."""
-    from .autograd_ops import param_epoch
-
     octree._require_tables()
     dec = octree.__dict__.get("_spec_decoder")
     dec = dec() if dec is not None else None
-    mlp = dec.fused_params() if (dec is not None and dec.fusable and dec._params_on(coord.device)) else []
+    mlp = dec.fused_params() if (dec is not None and dec.fusable) else []
+    if mlp and not dec._params_on(coord.device, mlp):
+        mlp = []
     feat, pred = ext.query_feature(octree._ext_state(ext), coord, octree.feature_list(), mlp)
-    octree.__dict__["_spec_result"] = (pred, dec, mlp, param_epoch(), [p._version for p in mlp]) if mlp else None
+    octree.__dict__["_spec_result"] = (pred, dec, mlp, autograd_ops.param_epoch(), [p._version for p in mlp]) if mlp else None
     octree._defer_indices(coord)
     return feat
 
