@@ -12,6 +12,7 @@
 //   grad_coord       get_gradient(coord, pred) (utils/tools.py:175-185): shine_forward's closed-form d pred / d coord; its
 //                    backward leaves d loss / d g with the fused node (shared Link)
 //   bce_loss         sdf_bce_loss (utils/loss.py:17-24): shine_bce_loss, loss and d loss / d pred in one launch
+//   cal_regularization  FeatureOctree.cal_regularization (model/feature_octree.py:246-255): a node only while a gradient is live
 //   adam_step        FusedAdam.step (utils/tools.py:57-83's Adam): shine_adam_step without Python-side pointer arrays
 //
 // Everything the nodes do not cover — a differentiable backward through the fused node, a driver that touches the feature
@@ -261,6 +262,59 @@ struct BceNode : public Node {
   void release_variables() override { dpred.reset(); }
 };
 
+// reg = cal_regularization() (model/feature_octree.py:246-255; autograd_ops.OctreeRegularizer): the rows the octree's last
+// query addressed are flagged (shine_mark_touched) and summed by one row-parallel launch that clears the flags again.  A node
+// exists only while a level's features_last_frame is still a detached copy (`live`): from the second frame on the reference holds
+// an attached clone and d reg / d F cancels (:160) — then the value is a constant of the graph and nothing runs in backward.
+void mark_query_rows(const TierAState& st, const Tensor& c, const std::vector<Tensor>& flags, void* stream) {
+  std::vector<unsigned char*> fl;
+  for (auto& f : flags) fl.push_back(f.data_ptr<unsigned char>());
+  check(shine_mark_touched(reinterpret_cast<const shine_tables*>(st.tables), &st.cfg, c.data_ptr<float>(), nullptr, nullptr,
+                           c.size(0), st.rows.data(), fl.data(), stream),
+        "shine_mark_touched");
+}
+
+struct RegNode : public Node {
+  std::string name() const override { return "OctreeRegularizer[ext]"; }
+  std::shared_ptr<TierAState> st;
+  Tensor coord;                        // detached, float32 contiguous
+  std::vector<SavedVariable> feats;
+  std::vector<Tensor> last, imp, flags;  // detached
+  std::vector<bool> on;                // per level: the gradient is live and wanted
+  variable_list apply(variable_list&& grads) override {
+    const int L = st->L();
+    variable_list out(L);
+    if (!grads[0].defined()) return out;
+    if (at::GradMode::is_enabled()) throw std::runtime_error("cal_regularization's node is differentiable once");
+    at::NoGradGuard ng;
+    std::vector<Tensor> F;
+    for (auto& f : feats) F.push_back(f32c(f.unpack()));
+    void* stream = cur_stream(coord);
+    mark_query_rows(*st, coord, flags, stream);  // (forward's launch cleared the flags)
+    std::vector<float*> gp;
+    std::vector<int32_t> gon;
+    std::vector<unsigned char*> fl;
+    for (int s = 0; s < L; ++s) {
+      if (on[s]) out[s] = at::zeros_like(F[s]);
+      gp.push_back(on[s] ? out[s].data_ptr<float>() : nullptr);
+      gon.push_back(on[s] ? 1 : 0);
+      fl.push_back(flags[s].data_ptr<unsigned char>());
+    }
+    Tensor scratch = at::empty({1}, coord.options().dtype(at::kDouble));
+    auto fp = ptrs(F), lp = ptrs(last), ip = ptrs(imp);
+    check(shine_regularize(L, fp.data(), lp.data(), ip.data(), gp.data(), fl.data(), st->rows.data(), gon.data(), 1.0f,
+                           scratch.data_ptr<double>(), 0, 0, stream),
+          "shine_regularize");
+    Tensor g = grads[0].to(at::kFloat);
+    for (int s = 0; s < L; ++s)
+      if (on[s]) out[s].mul_(g);
+    return out;
+  }
+  void release_variables() override {
+    for (auto& f : feats) f.reset_data();
+  }
+};
+
 bool requires_any(const Tensor& c, const std::vector<Tensor>& a, const std::vector<Tensor>& b = {}) {
   if (c.defined() && c.requires_grad()) return true;
   for (auto& t : a)
@@ -402,6 +456,62 @@ Tensor bce_loss(const Tensor& pred, const Tensor& label, const c10::optional<Ten
   return loss;
 }
 
+// FeatureOctree.cal_regularization for the coordinates of the octree's last query.  flags: one uint8 per row and level, all zero
+// (left zero again).  live[s]: level s's features_last_frame is a detached copy (its gradient does not cancel).
+Tensor cal_regularization(const std::shared_ptr<TierAState>& st, const Tensor& coord, const std::vector<Tensor>& feats,
+                          const std::vector<Tensor>& last, const std::vector<Tensor>& imp, const std::vector<Tensor>& flags,
+                          const std::vector<bool>& live) {
+  const int L = st->L();
+  TORCH_CHECK((int)feats.size() == L && (int)last.size() == L && (int)imp.size() == L && (int)flags.size() == L && (int)live.size() == L,
+              "cal_regularization: one tensor per featured level");
+  TORCH_CHECK(coord.is_cuda() && coord.dim() == 2 && coord.size(1) == 3, "coord must be a CUDA tensor of shape [N,3]");
+  Tensor reg;
+  std::vector<bool> on(L, false);
+  bool need_grad = false;
+  for (int s = 0; s < L; ++s) {
+    on[s] = live[s] && at::GradMode::is_enabled() && feats[s].requires_grad();
+    need_grad = need_grad || on[s];
+  }
+  Tensor c;
+  std::vector<Tensor> lastc, impc;
+  {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    c = f32c(coord.detach());
+    void* stream = cur_stream(c);
+    std::vector<Tensor> F;
+    for (int s = 0; s < L; ++s) {
+      TORCH_CHECK(flags[s].scalar_type() == at::kByte && flags[s].is_contiguous() && flags[s].numel() >= st->rows[s] + 1,
+                  "cal_regularization: one uint8 flag per row");
+      F.push_back(f32c(feats[s].detach()));
+      lastc.push_back(f32c(last[s].detach()));
+      impc.push_back(f32c(imp[s].detach()));
+    }
+    mark_query_rows(*st, c, flags, stream);
+    Tensor out = at::zeros({1}, c.options().dtype(at::kDouble));
+    std::vector<float*> gp(L, nullptr);
+    std::vector<int32_t> gon(L, 0);
+    std::vector<unsigned char*> fl;
+    for (auto& f : flags) fl.push_back(f.data_ptr<unsigned char>());
+    auto fp = ptrs(F), lp = ptrs(lastc), ip = ptrs(impc);
+    check(shine_regularize(L, fp.data(), lp.data(), ip.data(), gp.data(), fl.data(), st->rows.data(), gon.data(), 0.0f,
+                           out.data_ptr<double>(), 1, 0, stream),
+          "shine_regularize");
+    reg = out.select(0, 0).to(at::kFloat);
+  }
+  if (need_grad) {
+    auto node = make_node<RegNode>(feats);
+    node->st = st;
+    node->coord = c;
+    for (auto& f : feats) node->feats.emplace_back(f, false);
+    node->last = lastc;
+    node->imp = impc;
+    node->flags = flags;
+    node->on = on;
+    torch::autograd::create_gradient_edge(reg, node);
+  }
+  return reg;
+}
+
 void adam_step(const std::vector<Tensor>& params, const std::vector<Tensor>& grads, const std::vector<Tensor>& m,
                const std::vector<Tensor>& v, const std::vector<double>& lr, const std::vector<double>& wd, double b1, double b2,
                double eps, int64_t step, bool zero_grad, const std::vector<c10::optional<Tensor>>& flags) {
@@ -454,6 +564,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("fused_sdf", &fused_sdf);
   m.def("grad_coord", &grad_coord);
   m.def("bce_loss", &bce_loss);
+  m.def("cal_regularization", &cal_regularization);
   m.def("adam_step", &adam_step);
   m.def("config_bytes", []() { return (int64_t)sizeof(shine_step_config); });
 }

@@ -725,11 +725,42 @@ class FeatureOctree(nn.Module):
                 and len(self.features_last_frame) == self.featured_level_num
                 and all(a.shape == p.shape and b.shape == p.shape and a.is_cuda and b.is_cuda
                         for a, b, p in zip(self.importance_weight, self.features_last_frame, self.hier_features))):
-            from .autograd_ops import OctreeRegularizer
-
-            if OctreeRegularizer.levels_with_gradient(self) is not None:
-                return OctreeRegularizer.apply(self, coord, *self.feature_list())
+            live = self._reg_live_levels()
+            if live is not None:
+                ext = _ext.module()
+                if ext is not None:  # the C++ node (csrc/shine_torch_ext.cpp) — a node at all only while a gradient is live
+                    self._require_tables()
+                    return ext.cal_regularization(self._ext_state(ext), coord, self.feature_list(), list(self.features_last_frame),
+                                                  list(self.importance_weight), self._reg_row_flags(coord.device), live)
+                return autograd_ops.OctreeRegularizer.apply(self, coord, *self.feature_list())
         return self._cal_regularization_composite()
+
+    def _reg_live_levels(self):
+        """OctreeRegularizer.levels_with_gradient, remembered for as long as the tensors it looked at are the same objects (they
+        change once per frame, the loop asks once per iteration)"""
+        d = self.__dict__
+        hit = d.get("_reg_live")
+        last, feats = self.features_last_frame, self.hier_features
+        if (hit is not None and len(hit[0]) == len(last) and len(hit[1]) == len(feats)
+                and all(a is b and a.requires_grad == r for a, b, r in zip(hit[0], last, hit[2]))
+                and all(a is b for a, b in zip(hit[1], feats))):
+            return hit[3]
+        live = autograd_ops.OctreeRegularizer.levels_with_gradient(self)
+        d["_reg_live"] = (tuple(last), tuple(feats), tuple(x.requires_grad for x in last), live)
+        return live
+
+    def _reg_row_flags(self, dev):
+        """the regulariser's per-row byte flags (all zero between its launches)"""
+        d = self.__dict__
+        flags = d.get("_reg_flags")
+        if flags is None or any(f.shape[0] != p.shape[0] or f.device != dev for f, p in zip(flags, self.hier_features)):
+            flags = d["_reg_flags"] = _ops().touched_flags(self)
+            d["_reg_flags_dirty"] = False
+        if d.get("_reg_flags_dirty"):  # a forward of the Python node whose backward never came left its rows flagged
+            for f in flags:
+                f.zero_()
+            d["_reg_flags_dirty"] = False
+        return flags
 
     def _cal_regularization_composite(self):
         regularization = 0.0

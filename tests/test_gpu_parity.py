@@ -406,6 +406,58 @@ def test_small_batches_are_planned_in_one_launch_and_not_reordered(n):
             assert torch.equal(perm3.cpu().long(), p) and torch.equal(slots3.cpu(), sl)
 
 
+@pytest.mark.parametrize("attached", [False, True])
+def test_regulariser_cpp_node_equals_python_node_and_reference_composite(attached, monkeypatch):
+    """FeatureOctree.cal_regularization (model/feature_octree.py:246-255) through the C++ extension, the Python node and the
+    reference's composite (unique + gathers) on the same query: same value; with a DETACHED features_last_frame (first frame) the
+    same gradient 2 * importance * (F - F_last) on the query's rows; with the reference's attached clone (:160, later frames) the
+    nodes leave no gradient at all (the composite's cancels up to rounding) and the C++ path does not even create a node."""
+    fx = load_golden("ncd_reg_L3")
+    coord = fx["coord"].cuda()
+    res = {}
+    for mode in ("ext", "python", "composite"):
+        monkeypatch.setenv("SHINE_TIER_A_EXT", "1" if mode == "ext" else "0")
+        cfg, octree, dec = product_from_golden(fx)
+        vals = [v.detach() for v in octree.features_last_frame]
+        octree.features_last_frame = vals
+        if attached:
+            octree.features_last_frame = [p.clone() for p in octree.hier_features]
+            with torch.no_grad():
+                for t, v in zip(octree.features_last_frame, vals):
+                    t.copy_(v)
+        octree.query_feature(coord)
+        if mode == "composite":
+            octree.hierarchical_indices  # (materialised: the composite path)
+            reg = octree._cal_regularization_composite()
+        else:
+            reg = octree.cal_regularization()
+            reg2 = octree.cal_regularization()  # (the flags are clean again: the second call sees the same rows)
+            assert float(reg2) == float(reg)
+        name = reg.grad_fn.name() if reg.grad_fn is not None else None
+        if reg.requires_grad:
+            (reg * 3.0).backward()
+        torch.cuda.synchronize()
+        res[mode] = (float(reg), [None if p.grad is None else p.grad.clone() for p in octree.hier_features], name)
+    v_ref = res["composite"][0]
+    assert v_ref > 0
+    for mode in ("ext", "python"):
+        assert abs(res[mode][0] - v_ref) <= 1e-5 * v_ref, (mode, res[mode][0], v_ref)
+    assert res["ext"][2] == (None if attached else "OctreeRegularizer[ext]"), res["ext"][2]
+    assert "OctreeRegularizer" in res["python"][2] and "[ext]" not in res["python"][2]
+    for k in range(len(res["composite"][1])):
+        g_ref = res["composite"][1][k]
+        for mode in ("ext", "python"):
+            g = res[mode][1][k]
+            if attached:
+                assert g is None or float(g.abs().max()) == 0.0
+            else:
+                assert rel_err(g, g_ref) <= 1e-5, (mode, k)
+    if attached:  # the composite's own gradient is rounding noise around zero
+        scale = 3.0 * 2.0 * max(float((i * (p - l).abs()).max()) for i, p, l in zip(
+            octree.importance_weight, octree.hier_features, octree.features_last_frame))
+        assert all(float(g.abs().max()) <= 1e-5 * max(scale, 1e-30) for g in res["composite"][1])
+
+
 def test_fused_regulariser_and_importance_sweep_match_reference():
     """config ncd_incre_reg: fused step (sum reduction) + shine_regularize on the touched rows reproduces the
     reference loss (BCE + lambda * reg) and grads; cal_feature_importance (fused) reproduces the oracle's sweep."""

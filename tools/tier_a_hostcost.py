@@ -9,6 +9,58 @@ from shine_mapping_amd import autograd_ops, losses, optim, synth
 
 os.environ["SHINE_TIER_A_EXT"] = "1"
 torch.autograd.set_multithreading_enabled(False)
+pc = time.perf_counter
+
+
+def incremental():
+    """config 4's iteration (shine_incre.py:114-181 on the drop-in's names: + cal_regularization, sum reduction), frames >= 2"""
+    from shine_mapping_amd import Decoder, FeatureOctree, incre_learning
+
+    dev = "cuda"
+    cfg = synth.make_config("ncd", device=dev, lr=0.01, opt_adam=True, adam_eps=1e-15, lr_level_reduce_ratio=1.0, tree_level_feat=3)
+    frames = list(synth.make_frames(cfg, frames=6, beams=64, azimuths=900, seed=42, device=dev))
+    torch.manual_seed(0)
+    octree, geo_mlp = FeatureOctree(cfg), Decoder(cfg)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    names = ["get_batch", "query_feature", "sdf", "abs", "sdf_bce_loss(sum)", "0.+loss", "cal_regularization", "+= lambda * reg",
+             "zero_grad", "backward", "opt.step"]
+    acc, count = [0.0] * len(names), 0
+    for fi, (coord, label, weight) in enumerate(frames):
+        octree.update(coord[weight > 0], incremental_on=True)
+        opt = optim.setup_optimizer(cfg, list(octree.parameters()), list(geo_mlp.parameters()))
+        pool = type("P", (), {"coord": coord, "sdf_label": label, "weight": weight})()
+        torch.cuda.synchronize()
+        for it in range(50):
+            t = [pc()]
+            c, sdf_label, w = synth.draw_batch(pool, 4096, gen); t.append(pc())
+            feature = octree.query_feature(c); t.append(pc())
+            sdf_pred = geo_mlp.sdf(feature); t.append(pc())
+            w = torch.abs(w); t.append(pc())
+            sdf_loss = losses.sdf_bce_loss(sdf_pred, sdf_label, cfg.sigma_sigmoid, w, False, "sum"); t.append(pc())
+            cur_loss = 0.
+            cur_loss += sdf_loss; t.append(pc())
+            reg_loss = octree.cal_regularization(); t.append(pc())
+            cur_loss += cfg.lambda_forget * reg_loss; t.append(pc())
+            opt.zero_grad(set_to_none=True); t.append(pc())
+            cur_loss.backward(); t.append(pc())
+            opt.step(); t.append(pc())
+            if fi >= 2 and it >= 5:
+                count += 1
+                for i in range(len(names)):
+                    acc[i] += t[i + 1] - t[i]
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)
+        data = type("D", (), {"coord_pool": coord, "sdf_label_pool": label})()
+        incre_learning.cal_feature_importance(data, octree, geo_mlp, cfg.sigma_sigmoid, 4096, 2, "sum")
+    print("ncd-incre (config 4) iteration, dropin C++ nodes, calling-thread backward, frames >= 2: %.1f us (sum of statements)" %
+          (sum(acc) / count * 1e6))
+    for nm, a in zip(names, acc):
+        print("  %-20s %6.1f us" % (nm, a / count * 1e6))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "incre":
+    incremental()
+    sys.exit(0)
 kind, n, lv = (sys.argv[1] if len(sys.argv) > 1 else "maicity"), 4096, 3
 wl = synth.build_workload(kind, frames=30, device="cuda", seed=42, tree_level_feat=lv)
 octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
@@ -18,7 +70,6 @@ sigma = cfg.sigma_sigmoid
 opt = optim.setup_optimizer(cfg, list(octree.parameters()), list(dec.parameters()))
 NAMES = ["get_batch", "query_feature", "sdf", "mask+abs", "sdf_bce_loss", "0.+loss", "zero_grad", "backward", "opt.step"]
 acc = [0.0] * len(NAMES)
-pc = time.perf_counter
 
 
 def loop(timed):
