@@ -58,8 +58,70 @@ def incremental():
         print("  %-20s %6.1f us" % (nm, a / count * 1e6))
 
 
+def eikonal():
+    """the eikonal loop (shine_batch.py:115-210 with ekional_loss_on) on the drop-in's names; `g[surface_mask]` (:183) makes the
+    host wait for the device in every iteration"""
+    n, lv = 4096, 3
+    wl = synth.build_workload("kitti", frames=30, device="cuda", seed=42, tree_level_feat=lv)
+    octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
+    cfg.opt_adam, cfg.adam_eps, cfg.lr_level_reduce_ratio = True, 1e-15, 1.0
+    g = torch.Generator(device="cuda").manual_seed(1)
+    sigma = cfg.sigma_sigmoid
+    opt = optim.setup_optimizer(cfg, list(octree.parameters()), list(dec.parameters()))
+    names = ["get_batch", "requires_grad_", "query_feature", "sdf", "weight > 0", "get_gradient * sigma", "abs", "sdf_bce_loss",
+             "g[surface_mask]  (sync)", "norm .. mean, += w_e *", "zero_grad", "backward", "opt.step"]
+    acc, count = [0.0] * len(names), 0
+    autograd_ops.FUSE_WITH_COORD_GRAD = True
+    for it in range(350):
+        t = [pc()]
+        coord, sdf_label, weight = synth.draw_batch(wl.pool, n, g); t.append(pc())
+        coord.requires_grad_(True); t.append(pc())
+        feature = octree.query_feature(coord); t.append(pc())
+        sdf_pred = dec.sdf(feature); t.append(pc())
+        surface_mask = weight > 0; t.append(pc())
+        gr = losses.get_gradient(coord, sdf_pred) * sigma; t.append(pc())
+        weight = torch.abs(weight); t.append(pc())
+        cur_loss = 0.
+        cur_loss += losses.sdf_bce_loss(sdf_pred, sdf_label, sigma, weight, False, cfg.loss_reduction); t.append(pc())
+        gs = gr[surface_mask]; t.append(pc())
+        cur_loss += cfg.weight_e * ((gs.norm(2, dim=-1) - 1.0) ** 2).mean(); t.append(pc())
+        opt.zero_grad(set_to_none=True); t.append(pc())
+        cur_loss.backward(); t.append(pc())
+        opt.step(); t.append(pc())
+        if it >= 50:
+            count += 1
+            for i in range(len(names)):
+                acc[i] += t[i + 1] - t[i]
+    torch.cuda.synchronize()
+    autograd_ops.FUSE_WITH_COORD_GRAD = False
+    # the driver's own eikonal term (shine_batch.py:141-142, 182-185) on a LEAF tensor in place of get_gradient's result: torch only
+    tt = [0.0, 0.0]
+    for it in range(250):
+        coord, sdf_label, weight = synth.draw_batch(wl.pool, n, g)
+        leaf = torch.randn(n, 3, device="cuda", requires_grad=True)
+        surface_mask = weight > 0
+        torch.cuda.synchronize()
+        t0 = pc()
+        gr = leaf * sigma
+        loss = cfg.weight_e * ((gr[surface_mask].norm(2, dim=-1) - 1.0) ** 2).mean()
+        t1 = pc()
+        loss.backward()
+        t2 = pc()
+        if it >= 50:
+            tt[0] += t1 - t0
+            tt[1] += t2 - t1
+    print("the driver's eikonal term alone (torch ops on a leaf tensor, idle device): forward %.1f us, backward %.1f us" %
+          (tt[0] / 200 * 1e6, tt[1] / 200 * 1e6))
+    print("kitti L3 N=4096 BCE + eikonal, dropin C++ nodes, calling-thread backward: %.1f us (sum of statements)" % (sum(acc) / count * 1e6))
+    for nm, a in zip(names, acc):
+        print("  %-26s %6.1f us" % (nm, a / count * 1e6))
+
+
 if len(sys.argv) > 1 and sys.argv[1] == "incre":
     incremental()
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "eik":
+    eikonal()
     sys.exit(0)
 kind, n, lv = (sys.argv[1] if len(sys.argv) > 1 else "maicity"), 4096, 3
 wl = synth.build_workload(kind, frames=30, device="cuda", seed=42, tree_level_feat=lv)
