@@ -252,8 +252,8 @@ size_t shine_train_step_workspace_bytes(const shine_step_config* cfg, int64_t n)
  * (SURVEY.md §8d), 0, 0}.  bench.py derives its `roofline.mfma_*` figures from these instead of hard-coding them. */
 int shine_train_step_info(const shine_step_config* cfg, int64_t n, int64_t* out);
 /* which build of the fused step a launch of n points on tables of rows[s] rows (trash row excluded) would run: *far_out = 1 for
- * the build for feature tables beyond the 256 MiB Infinity Cache (corner ids one tile ahead, next tile's rows touched into the
- * L2), 0 for the cache-resident build.  The choice is by table size; cfg->kernel_variant's low byte 5 / 6 forces one or the
+ * the build for feature tables beyond the 256 MiB Infinity Cache (closed node runs merged in a per-wave corner lattice in LDS
+ * before they become atomics), 0 for the cache-resident build.  The choice is by table size; cfg->kernel_variant's low byte 5 / 6 forces one or the
  * other (A/B measurements, parity tests). */
 int shine_train_step_regime(const shine_step_config* cfg, const int64_t* rows, int64_t n, int32_t* far_out);
 /* the stand-alone form of the `touched` pass of shine_train_step: mark (set to 1) in touched[s][rows_s] every feature row
