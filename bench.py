@@ -66,8 +66,14 @@ MFMA16_CYCLES = 32.0       # v_mfma_f32_16x16x4_f32 issue interval per SIMD (gui
 VALU_CYCLES = 2.5
 
 WORKLOADS = {
-    "maicity": dict(preset="maicity", points=1 << 18, levels=4, frames=60, azimuths=450),
-    "kitti": dict(preset="kitti", points=1 << 20, levels=3, frames=120, azimuths=450),
+    # SURVEY.md 8(d)'s scan recipe in full since round 5: sensor poses 1 m apart (100 on the street, 600 on the polyline) x 64 beams
+    # x 1800 azimuths -> pools of 65 M / 378 M samples (rounds 1-4: 60 x 450 and 120 x 450 scans, pools of 9.6 M / 18.8 M; the same
+    # box reads 3.10 -> 3.04 and 4.18 -> 3.95 G samples/s: denser rays find 12 % more of the map, and a draw from the larger pool
+    # costs more — profiles/r05_bench_recipe_vs_thin.txt)
+    "maicity": dict(preset="maicity", points=1 << 18, levels=4, frames=100, azimuths=1800),
+    "kitti": dict(preset="kitti", points=1 << 20, levels=3, frames=600, azimuths=1800),
+    "maicity-thin": dict(preset="maicity", points=1 << 18, levels=4, frames=60, azimuths=450),  # rounds 1-4's scans, for continuity
+    "kitti-thin": dict(preset="kitti", points=1 << 20, levels=3, frames=120, azimuths=450),
     "kitti-large": dict(preset="kitti_large", points=1 << 20, levels=3, frames=2800, azimuths=300),
     "ncd-incre": dict(preset="ncd", points=4096, levels=3, frames=24, azimuths=900),
 }
@@ -947,14 +953,19 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, with_cpu_ba
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": "%s: %s, batch mode, %d points/iter/GPU, %d-level octree (levels %d..%d), F=8, decoder "
-                        "8-32-32-1, %s; synthetic scans: %d poses x 64 beams x %d azimuths (SURVEY.md 8(d)'s recipe asks for "
-                        "100 x 64 x 1800: the map is the full one, the sample pool is thinner)" % (workload,
+                        "8-32-32-1, %s; synthetic scans: %d poses x 64 beams x %d azimuths (%s)" % (workload,
                                            {"maicity": "MaiCity-like 100 m street canyon",
+                                            "maicity-thin": "MaiCity-like 100 m street canyon",
                                             "kitti": "KITTI-like 600 m polyline with two turns",
+                                            "kitti-thin": "KITTI-like 600 m polyline with two turns",
                                             "kitti-large": "KITTI-like 8.4 km serpentine (map larger than the "
                                                            "256 MiB Infinity Cache)"}[workload],
                                            points, levels, cfg.tree_level_world - levels + 1, cfg.tree_level_world,
-                                           "BCE+eikonal" if cfg.ekional_loss_on else "BCE", frames, spec["azimuths"]),
+                                           "BCE+eikonal" if cfg.ekional_loss_on else "BCE", frames, spec["azimuths"],
+                                           "SURVEY.md 8(d)'s scan recipe: poses 1 m apart, 64 x 1800 rays each"
+                                           if spec["azimuths"] == 1800 and not (args.frames and own) else
+                                           "thinner than SURVEY.md 8(d)'s 64 x 1800 rays per pose 1 m apart: the map is the full "
+                                           "one, the sample pool is smaller"),
             "points_per_iter_per_gpu": points, "levels": levels, "frames": frames,
             "pool_samples": int(pool.sdf_label.shape[0]), "corner_rows": rows,
             "feature_table_bytes": int(sum(rows) * 32),
