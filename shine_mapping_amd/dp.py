@@ -312,6 +312,7 @@ class RowGatherReducer(GradReducer):
         # all-gather becomes that many device copies of this rank's own message, and every copy is unpacked and added: the
         # pack, the receive-side writes and the unpack of an N-rank exchange are all there, only the wire is not
         self.synthetic_world = int(synthetic_world) if dist is None else 0
+        self.peer_messages = None  # synthetic world: int32 [(world - 1) * words], the other ranks' packed messages (else: copies)
         self.async_op = bool(async_op)  # issue the all-gather asynchronously (it then runs on the backend's own stream, under
         #                                 whatever the caller launches next — the next micro-batch); finish() waits for it
         self.n_feat = len(list(feature_params))
@@ -358,17 +359,15 @@ class RowGatherReducer(GradReducer):
     def _words(self):
         return 4 + self.capacity + self.capacity * self.F + self.tail_n
 
-    def exchange(self, finish=True):
-        """pack this rank's flagged rows (moving them out of the bucket) and all-gather; finish=True also adds every
-        gathered message back (finish=False after all but the last micro-batch of a step)"""
+    def pack(self):
+        """MOVE this rank's flagged rows (ids + values; the bucket's copies are cleared), the trash rows and the decoder grads
+        into one fixed-size message -> int32 [4 + capacity + capacity * F + tail_n] (word 0: rows held, word 1: overflow)."""
         self._ensure_flat()
         if self.capacity is None:
             self._measure_capacity()
         flat, dev = self._flat_padded, self._flat_padded.device
-        world = self.world()
-        words = self._words()
         tail_off = self.n_rows * self.F
-        msg = torch.empty(words, dtype=torch.int32, device=dev)
+        msg = torch.empty(self._words(), dtype=torch.int32, device=dev)
         if flat.is_cuda:
             lib = _lib.lib()
             stream = _lib.current_stream_handle()
@@ -383,6 +382,30 @@ class RowGatherReducer(GradReducer):
                                            self._ws[0].data_ptr(), C.byref(need), stream), "shine_rows_pack")
         else:
             self._pack_torch(flat, msg, tail_off)
+        self.last_bytes = self._words() * 4
+        return msg
+
+    def add_messages(self, gathered, world, first=True):
+        """add `world` messages (one all-gather's result, rank order) into the bucket; first=False: a later micro-batch of the
+        same step (its decoder tail is added to, not written over, what the first one left)"""
+        self._ensure_flat()
+        flat = self._flat_padded
+        tail_off = self.n_rows * self.F
+        if flat.is_cuda:
+            # tail_n is part of the message stride for EVERY message; the later micro-batches of a step add their tails
+            _lib.check(_lib.lib().shine_rows_unpack_add(gathered.data_ptr(), world, self.capacity, flat.data_ptr(), tail_off,
+                                                        self.tail_n, 0 if first else 1, self._overflow.data_ptr(),
+                                                        _lib.current_stream_handle()), "shine_rows_unpack_add")
+        else:
+            self._unpack_torch(flat, gathered, world, tail_off, first)
+
+    def exchange(self, finish=True):
+        """pack this rank's flagged rows (moving them out of the bucket) and all-gather; finish=True also adds every
+        gathered message back (finish=False after all but the last micro-batch of a step)"""
+        msg = self.pack()
+        dev = msg.device
+        world = self.world()
+        words = self._words()
         work = None
         if self.dist is not None:  # (also with one rank: the collective is then a copy, and the same code path is exercised)
             gathered = torch.empty(world * words, dtype=torch.int32, device=dev)
@@ -391,30 +414,24 @@ class RowGatherReducer(GradReducer):
             else:
                 self.dist.all_gather_into_tensor(gathered, msg, group=self.group)
         elif self.synthetic_world > 1:
-            gathered = msg.repeat(self.synthetic_world)
+            if self.peer_messages is not None:  # the other ranks' REAL messages of one step (benchlib.run_dp_rank)
+                gathered = torch.cat([msg, self.peer_messages])
+            else:
+                gathered = msg.repeat(self.synthetic_world)
         else:
             gathered = msg
         self._pending.append((gathered, work, msg))  # (msg is kept alive until the collective has read it)
-        self.last_bytes = words * 4
         if finish:
             self.finish()
 
     def finish(self):
         """add every gathered message (all ranks, all micro-batches) back into the bucket"""
-        flat = self._flat_padded
         world = self.world()
-        tail_off = self.n_rows * self.F
         first = True
         for gathered, work, _ in self._pending:
             if work is not None:
                 work.wait()  # the current stream waits for the collective (no host block on the NCCL / RCCL backend)
-            if flat.is_cuda:
-                # tail_n is part of the message stride for EVERY message; the later micro-batches of a step add their tails
-                _lib.check(_lib.lib().shine_rows_unpack_add(gathered.data_ptr(), world, self.capacity, flat.data_ptr(), tail_off,
-                                                            self.tail_n, 0 if first else 1, self._overflow.data_ptr(),
-                                                            _lib.current_stream_handle()), "shine_rows_unpack_add")
-            else:
-                self._unpack_torch(flat, gathered, world, tail_off, first)
+            self.add_messages(gathered, world, first)
             first = False
         self._pending = []
 

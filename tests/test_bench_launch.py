@@ -74,3 +74,54 @@ def test_explicit_torchrun_form_matches():
     assert r.returncode == 0, r.stderr[-2000:]
     rec = _json_line(r.stdout)
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2
+
+
+def _load_bench():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_the_printed_record_stays_small_and_strict():
+    """round 5's record was ONE 22 kB line with four legs embedded and the driver could not parse it.  The
+    formatter (bench.compact / compact_dp_rank / emit) on that very record — the canned full record of a real default run,
+    profiles/r05_bench_default.json.log — must give lines of < 4096 bytes that strict JSON parsers accept, carrying the
+    contract's fields, `roofline` and `cpu_baseline`; and hostile values (NaN, long strings) must not break the line."""
+    import io
+    from contextlib import redirect_stdout
+
+    bench = _load_bench()
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_default.json.log")).read().strip().splitlines()[-1])
+    legs = full.pop("configs")
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        for name, leg in legs.items():
+            line = bench.compact_dp_rank(leg) if name == "kitti-dp8-rank" else bench.compact(leg)
+            bench.emit({"leg": name, "full_record": None, **line})
+        bench.emit(bench.compact(full, "gpurun_out/bench_records/maicity.json"))
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 5 and sum(len(ln) for ln in lines) < 8192
+    for ln in lines:
+        assert len(ln) < bench.RECORD_LIMIT
+        json.loads(ln, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))  # strict: no NaN / Infinity
+    last = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in last, k
+    assert last["value"] == float("%.5g" % full["value"]) and "workload" in last["config"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"} <= set(last["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(last["cpu_baseline"])
+    assert [json.loads(ln).get("leg") for ln in lines[:-1]] == list(legs)
+    # hostile values
+    bad = dict(full)
+    bad["config"] = dict(full["config"], workload="x" * 9000, launch="y" * 9000)
+    bad["cpu_baseline"] = dict(full["cpu_baseline"], sample="z" * 9000, value=float("nan"))
+    bad["roofline"] = dict(full["roofline"], frac=float("inf"))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit(bench.compact(bad))
+    ln = buf.getvalue().strip()
+    assert len(ln) < bench.RECORD_LIMIT and json.loads(ln)["roofline"]["frac"] is None

@@ -1510,3 +1510,93 @@ def test_graphed_iteration_without_the_eager_first_iteration(native):
     assert abs(float(a.loss) - float(b.loss)) <= 1e-6 * abs(float(a.loss))
     for x, y in zip(list(o1.hier_features) + d1.fused_params(), list(o2.hier_features) + d2.fused_params()):
         assert rel_err(y.detach(), x.detach()) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_config_5_shape_eight_real_rank_messages():
+    """BASELINE config 5 at its own shape on ONE device: ONE global sorted draw of 2^22 samples on the
+    KITTI-like map (600 m polyline, L = 3, BCE + eikonal); ranks 0..7 run their contiguous slices of 2^19 back to back through the
+    fused step with the GLOBAL normalisers (one mean over the batch and one surface count: shine_batch.py:174-185, 208-210), each
+    packs ITS own-rows message (shine_rows_pack), and the eight REAL messages are added back in rank order
+    (shine_rows_unpack_add) — what dp.RowGatherReducer's all-gather delivers on an 8-GPU node.  Held to
+      (i)   the single-process step on the whole 2^22 batch (the same sums in another order: <= 1e-6 of max-abs),
+      (ii)  the dense exchange (the eight dense buckets summed), likewise,
+      (iii) the CPU oracle in wide-accumulation mode, rank by rank: rank r's share of the global mean is the oracle's own
+            train_step on slice r with reduction "sum" and weight_e * ns_r * N / Ns, divided by N (linearity of the two means);
+            each rank's dense bucket and the reduced bucket are within 1e-4 of max-abs of it,
+    and no message overflows under the real capacity rule (1.5 x the max over ranks of the first exchange + 1024), measured on
+    ANOTHER draw than the one that is checked."""
+    from oracle import shine_oracle as so
+    from shine_mapping_amd import StepOptions, benchlib, fused_train_step, synth
+    from shine_mapping_amd.sampler import SortedPool
+
+    world, points = 8, 1 << 19
+    n_global = world * points
+    wl = synth.build_workload("kitti", frames=120, device="cuda", seed=42, tree_level_feat=3, azimuths=450)
+    octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
+    with torch.no_grad():
+        for p in octree.hier_features:
+            p.mul_(5.0)
+    octree._require_tables(with_ranks=True)
+    sp = SortedPool(octree, wl.pool.coord, wl.pool.sdf_label, wl.pool.weight, seed=1000, canonical=True)
+    opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=True, weight_e=cfg.weight_e, n_global=n_global)
+    params = list(octree.hier_features) + dec.fused_params()
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    first = benchlib.rank_messages(octree, dec, sp, opts, points, world, draw_no=0)  # the capacity is measured here ...
+    red = first["reducer"]
+    cap = red.capacity
+    rm = benchlib.rank_messages(octree, dec, sp, opts, points, world, draw_no=5, reducer=red, keep_dense=True)  # ... and used here
+    assert red.capacity == cap and not red.overflowed()
+    assert all(int(m[1]) == 0 for m in rm["messages"]) and max(rm["rows"]) <= cap
+    assert rm["rows"] == rm["flagged"]  # every flagged row travelled
+    print("config-5 shape: rows per rank message min %d / max %d (capacity %d, dense bucket %d rows); first draw max %d" % (
+        min(rm["rows"]), max(rm["rows"]), cap, red.n_rows, max(first["rows"])))
+    red.add_messages(torch.cat(rm["messages"]), world)
+    torch.cuda.synchronize()
+    assert not red.overflowed()
+    reduced = red.flat.clone()
+    nf = red.n_rows * red.F
+    # (i) one process, the whole batch
+    red.flat.zero_()
+    sp.draws = 5
+    whole = sp.draw(n_global)
+    loss, pred, _ = fused_train_step(octree, dec, None, None, None, opts, n_surf=rm["n_surf"], pool=sp, idx=whole)
+    torch.cuda.synchronize()
+    single = red.flat.clone()
+    for name, sl in (("feature grads", slice(0, nf)), ("decoder grads", slice(nf, nf + red.tail_n))):
+        scale = float(single[sl].abs().max())
+        assert float((reduced[sl] - single[sl]).abs().max()) <= 1e-6 * scale, "own-rows exchange vs single process: " + name
+        # (ii) the dense exchange: the eight dense buckets summed in rank order
+        dense = torch.stack([d[sl].double() for d in rm["dense"]]).sum(0)
+        assert float((dense - single[sl].double()).abs().max()) <= 1e-6 * scale, "dense exchange vs single process: " + name
+    # (iii) the oracle, rank by rank (wide accumulation; the voxel ids and fractional coordinates are the reference's fp32 ones)
+    ns = int(rm["n_surf"])
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    total = None
+    sizes = [p.numel() for p in params]
+    for r in range(world):
+        idx_r = whole[r * points:(r + 1) * points]
+        c, l, w = (t.cpu() for t in sp.get_batch(idx_r))
+        ocfg, oct_, mlp = oracle_from_product_restricted(octree, dec, cfg, c)
+        so.to_wide(oct_, mlp)
+        ocfg.loss_reduction = "sum"
+        ocfg.weight_e = cfg.weight_e * int((w > 0).sum()) * n_global / ns
+        ref = so.train_step(oct_, mlp, c, l, w, ocfg)
+        want = torch.cat([t.reshape(-1) for t in ref["feat_grads"] + ref["mlp_grads"]]) / n_global
+        total = want if total is None else total + want
+        got = rm["dense"][r][:want.numel()].double().cpu()
+        off = 0
+        for k, sz in enumerate(sizes):
+            scale_r = float(want[off:off + sz].abs().max())
+            assert float((got[off:off + sz] - want[off:off + sz]).abs().max()) <= TOL * max(scale_r, 1e-30), \
+                "rank %d tensor %d vs the oracle's share" % (r, k)
+            off += sz
+        del ref, oct_, mlp
+    off = 0
+    red_cpu, single_cpu = reduced[:total.numel()].double().cpu(), single[:total.numel()].double().cpu()
+    for k, sz in enumerate(sizes):
+        scale = float(total[off:off + sz].abs().max())
+        assert float((red_cpu[off:off + sz] - total[off:off + sz]).abs().max()) <= TOL * scale, "reduced tensor %d vs oracle" % k
+        assert float((single_cpu[off:off + sz] - total[off:off + sz]).abs().max()) <= TOL * scale, "single tensor %d vs oracle" % k
+        off += sz

@@ -76,7 +76,7 @@ def tier_a_incremental(dev, frames, bs=4096, iters=50, warmup=2, levels=3, ext="
     return {"frames_per_s": 1.0 / med(t_frames), "ms_per_frame": med(t_frames) * 1e3, "ms_per_iteration": med(t_iter) * 1e3,
             "split_ms": {"update + new optimiser": med(t_update) * 1e3, "%d iterations" % iters: med(t_iter) * iters * 1e3,
                          "importance sweep": med(t_sweep) * 1e3},
-            "frames_timed": len(t_frames), "final_loss": float(cur_loss),
+            "frames_timed": len(t_frames), "final_loss": float(cur_loss.detach()),
             "autograd_nodes": ("C++ extension (lib/_shine_ext.so)" if ext == "1" else "Python (SHINE_TIER_A_EXT=0)") +
                               (", backward on the calling thread" if single_thread else ", engine's device thread"),
             "what": "the loop body of shine_incre.py:100-195 verbatim on the drop-in's classes and re-bound functions; eager launches, "
