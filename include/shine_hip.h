@@ -70,7 +70,12 @@ typedef struct shine_step_config {
   int32_t decoder_grad_on; /* 0 when the decoder is frozen             (utils/tools.py:188-191) */
   int32_t sorted_input;    /* 0: visit the batch as given; 1: through perm[] (shine_plan_batch / shine_morton_sort);
                               2: POOL mode — coord/label/weight/slots are a node-ordered sample pool, perm[] holds the
-                              batch's sorted sample indices (shine_sample_sorted), outputs are written at batch position */
+                              batch's sorted sample indices (shine_sample_sorted), outputs are written at batch position;
+                              3: POOL mode with the pool as ONE 16-byte-aligned 32-byte record per sample — `coord` is the record
+                              base: {x, y, z, label | weight, slot[0..L-1], 0...} for n_levels <= 3, {x, y, z, label | slot[0..3]}
+                              for n_levels = 4 (`weight` then stays a separate array, needed by eikonal / loss_weight_on only);
+                              sdf_label is ignored, `slots` must be non-NULL and is not read (pass the record base) — a drawn
+                              sample costs one cache line instead of four (shine_train_step, shine_mark_touched) */
   int32_t kernel_variant;  /* low byte — 0 (or 4): the fused step (shine_step_v3.hip: planned / pool batches, <= 4 featured
                               levels; 5 / 6 force / forbid its build for tables beyond the Infinity Cache, which 0 picks by
                               table size).  The CHECK library (libshine_check.so, tests / tools only) adds 1: the lane-per-point

@@ -69,6 +69,20 @@ __device__ __forceinline__ void lattice_close(float* lat, float* gbase, int pack
   if (!same && T >= 0) atomic_add_f32(gbase + ((unsigned int)T << 3) + sq, V);
 }
 
+// RECORD pools (a.pool_mode == 2, cfg->sorted_input 3): the pool is ONE 32-byte record per sample instead of four arrays read at
+// the same sparse sorted positions — {x, y, z, label | weight, slot[0 .. L-1], pad} for L <= 3, {x, y, z, label | slot[0 .. 3]} for
+// L = 4 (the weight, read by the eikonal / weighted builds only, stays a separate array there) — so a drawn sample costs one
+// cache line, not four (2^20 samples x 4 lines x 128 B were 537 of the kitti step's 762 MB of HBM traffic).
+// a.coord is the record base.  rec_words: the record as dwords; the hash slot of level g sits at dword REC_SLOT0 + g.
+template <int L>
+struct RecLayout {
+  static constexpr int SLOT0 = L == 4 ? 4 : 5;  // first slot dword
+  static constexpr bool WEIGHT_INSIDE = L < 4;  // dword 4
+};
+__device__ __forceinline__ const int* rec_words(const V1Args& a, long long sample) {
+  return reinterpret_cast<const int*>(a.coord) + 8 * sample;
+}
+
 template <int L, int WAVES, bool EIK, bool PROF, bool EXT = false, bool MARK = false, bool SLICED = false, bool FAR = false>
 __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES, FAR>& sm, const int bid, const int nbid,
                                           const StepSlice* sl = nullptr) {
@@ -175,19 +189,33 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES, FAR
     if (bid == 0 && tid == 0) reinterpret_cast<double*>(a.partials + PART_LOSS)[3] = (double)ns;
   }
 
+  // pool batches of the one-step launches are RECORD pools (prepare_step_v3 refuses the array form); the sliced sweep keeps the
+  // arrays (its frame pools are small and planned once)
+  const bool rec = !SLICED && a.pool_mode != 0;  // (wave-uniform: scalar branches)
+  const bool soa_pool = SLICED && a.pool_mode != 0;
+  const bool need_w = (EIK && !EXT) || a.weighted;
   if (nvalid) {
     np = SL_PERM ? (long long)np1 : begin + pt;
-    const long long si = a.pool_mode ? np : begin + pt;
-    if (lvl_on_i) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
-    nx0 = a.coord[3 * np];
-    nx1 = a.coord[3 * np + 1];
-    nx2 = a.coord[3 * np + 2];
-    nlabel = a.label[np];
-    if ((EIK && !EXT) || a.weighted) nweight = a.weight[np];
+    if (rec) {
+      const int* r = rec_words(a, np);
+      if (lvl_on_i) nslot = r[RecLayout<L>::SLOT0 + g];
+      const float4 c = *reinterpret_cast<const float4*>(r);
+      nx0 = c.x, nx1 = c.y, nx2 = c.z, nlabel = c.w;
+      if (need_w) nweight = RecLayout<L>::WEIGHT_INSIDE ? __int_as_float(r[4]) : a.weight[np];
+    } else {
+      const long long si = soa_pool ? np : begin + pt;
+      if (lvl_on_i) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
+      nx0 = a.coord[3 * np];
+      nx1 = a.coord[3 * np + 1];
+      nx2 = a.coord[3 * np + 2];
+      nlabel = a.label[np];
+      if (need_w) nweight = a.weight[np];
+    }
   }
   int fslot = -1;  // AHEAD: the hash slot of the tile after the one n* describes
   if (AHEAD && lvl_on_i && second + pt < end)
-    fslot = __builtin_nontemporal_load(a.slots + (a.pool_mode ? (long long)np2 : second + pt) * L + g);
+    fslot = rec ? rec_words(a, np2)[RecLayout<L>::SLOT0 + g]
+                : __builtin_nontemporal_load(a.slots + (soa_pool ? (long long)np2 : second + pt) * L + g);
 
   if (WAVES == 4 && use_img) {  // (opA and bias are adjacent in StepShared: the image is their concatenation)
 #pragma unroll
@@ -391,17 +419,28 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES, FAR
         fib = lv_vals[2u * fs + 1u];
         fslot = -1;
         if (lvl_on && ni2 < end)
-          fslot = __builtin_nontemporal_load(a.slots + (a.pool_mode ? (long long)np3 : ni2) * L + g);
+          fslot = rec ? rec_words(a, np3)[RecLayout<L>::SLOT0 + g]  // (brings the record's line in: tile t+2's point data hit it)
+                      : __builtin_nontemporal_load(a.slots + (soa_pool ? (long long)np3 : ni2) * L + g);
       }
       if (nvalid) {
         np = SL_PERM ? (long long)np2 : ni;
-        const long long si = a.pool_mode ? np : ni;
-        if (!AHEAD && lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
-        nx0 = __builtin_nontemporal_load(a.coord + 3 * np);
-        nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
-        nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
-        nlabel = __builtin_nontemporal_load(a.label + np);
-        if ((EIK && !EXT) || a.weighted) nweight = __builtin_nontemporal_load(a.weight + np);
+        if (rec) {
+          const int* r = rec_words(a, np);
+          if (!AHEAD && lvl_on) nslot = r[RecLayout<L>::SLOT0 + g];
+          const f32x4 c = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(r));
+          nx0 = c[0], nx1 = c[1], nx2 = c[2], nlabel = c[3];
+          if (need_w)
+            nweight = RecLayout<L>::WEIGHT_INSIDE ? __int_as_float(__builtin_nontemporal_load(r + 4))
+                                                  : __builtin_nontemporal_load(a.weight + np);
+        } else {
+          const long long si = soa_pool ? np : ni;
+          if (!AHEAD && lvl_on) nslot = __builtin_nontemporal_load(a.slots + si * L + g);
+          nx0 = __builtin_nontemporal_load(a.coord + 3 * np);
+          nx1 = __builtin_nontemporal_load(a.coord + 3 * np + 1);
+          nx2 = __builtin_nontemporal_load(a.coord + 3 * np + 2);
+          nlabel = __builtin_nontemporal_load(a.label + np);
+          if (need_w) nweight = __builtin_nontemporal_load(a.weight + np);
+        }
       }
       if (AHEAD) {
         np2 = np3;

@@ -65,6 +65,8 @@ struct V1Args {
   int weighted;   // 1: every sample's BCE term (and its gradient) is multiplied by |weight| (utils/loss.py:18-19)
   int pool_mode;  // 1: coord/label/weight/slots are a node-ordered POOL indexed by perm[i] (sorted sample indices,
                   //    shine_sample_sorted); pred / grad_x are written at the batch position i.  0: a batch.
+                  // 2: the same with the pool as ONE 32-byte record per sample (cfg->sorted_input 3, shine_step_body.hpp
+                  //    RecLayout): coord = the record base, label / slots unused, weight a separate array for L = 4 only
   int ablate;  // debug only (kernel_variant >> 8): 1 no feature atomics, 2 no weight-grad phase, 4 no scatter phase,
                // 8 no row gathers, 16 no probe (every point misses), 32 skip the partial-sum reduction launch,
                // 64 deterministic accumulation: one wave of one workgroup walks the whole stream (tests)
@@ -172,12 +174,17 @@ inline int fill_step_args(V1Args* a, const shine_tables* t, const shine_step_con
                           const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows,
                           const float* const* mlp, float* pred_out, float* grad_x_out, float* const* grad_feats,
                           float* const* grad_mlp, double* loss_parts, unsigned char* const* touched) {
-  if (n < 0 || !feats || !rows || !mlp || !grad_feats || (n > 0 && (!coord || !sdf_label)))
+  const bool rec_pool = cfg->sorted_input == 3;  // a pool of 32-byte records behind `coord`
+  if (n < 0 || !feats || !rows || !mlp || !grad_feats || (n > 0 && (!coord || (!sdf_label && !rec_pool))))
     return set_error(SHINE_E_INVALID, "shine_train_step: null argument");
+  if (rec_pool && (reinterpret_cast<uintptr_t>(coord) & 15))
+    return set_error(SHINE_E_INVALID, "shine_train_step: a record pool must be 16-byte aligned");
   if (cfg->n_levels > LCAP) return set_error(SHINE_E_INVALID, "shine_train_step: the MFMA kernels handle up to 4 featured levels");
-  if (cfg->eikonal_on && (!weight || !n_surf))
+  const bool weight_inside = rec_pool && cfg->n_levels < 4;  // (the record holds it)
+  if (cfg->eikonal_on && ((!weight && !weight_inside) || !n_surf))
     return set_error(SHINE_E_INVALID, "shine_train_step: eikonal needs weight and n_surf");
-  if (cfg->loss_weight_on && !weight) return set_error(SHINE_E_INVALID, "shine_train_step: loss_weight_on needs weight");
+  if (cfg->loss_weight_on && !weight && !weight_inside)
+    return set_error(SHINE_E_INVALID, "shine_train_step: loss_weight_on needs weight");
   LevelSet ls = {};
   int rc = make_level_set(t, cfg, feats, rows, grad_feats, &ls);
   if (rc != SHINE_OK) return rc;
@@ -222,7 +229,7 @@ inline int fill_step_args(V1Args* a, const shine_tables* t, const shine_step_con
   a->decoder_grad_on = cfg->decoder_grad_on;
   a->poly = cfg->poly_int_on;
   a->weighted = cfg->loss_weight_on ? 1 : 0;
-  a->pool_mode = cfg->sorted_input == 2 ? 1 : 0;
+  a->pool_mode = cfg->sorted_input == 2 ? 1 : rec_pool ? 2 : 0;
   if (a->pool_mode && !perm) return set_error(SHINE_E_INVALID, "shine_train_step: pool mode needs the sample indices in perm");
   a->ablate = cfg->kernel_variant >> 8;
   a->sigma = cfg->sigma;

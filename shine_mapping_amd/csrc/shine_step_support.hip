@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_mark_touched(V1Args a) {
   const long long p = a.perm ? (long long)a.perm[i] : i;
   // slots are in VISITING order for a planned batch, but indexed by pool sample id in pool mode (like the main kernel)
   const long long si = a.pool_mode ? p : i;
-  if (!a.slots) {
+  if (!a.slots && a.pool_mode != 2) {
     x0 = a.coord[3 * p];
     x1 = a.coord[3 * p + 1];
     x2 = a.coord[3 * p + 2];
@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void k_mark_touched(V1Args a) {
   for (int s = 0; s < L; ++s) {
     if (!a.touched[s]) continue;
     int sl;
-    if (a.slots) {
+    if (a.pool_mode == 2) {  // a pool of 32-byte records (shine_step_body.hpp RecLayout): slots at dword 4 (L = 4) / 5
+      sl = reinterpret_cast<const int*>(a.coord)[8 * p + (L == 4 ? 4 : 5) + s];
+    } else if (a.slots) {
       sl = a.slots[si * L + s];
     } else {
       LevelDev Lv = {};
@@ -288,7 +290,7 @@ extern "C" int shine_mark_touched(const shine_tables* t, const shine_step_config
   a.slots = slots;
   a.n = n;
   a.n_levels = cfg->n_levels;
-  a.pool_mode = cfg->sorted_input == 2 ? 1 : 0;
+  a.pool_mode = cfg->sorted_input == 2 ? 1 : cfg->sorted_input == 3 ? 2 : 0;
   if (a.pool_mode && !perm) return set_error(SHINE_E_INVALID, "shine_mark_touched: pool mode needs the sample indices");
   hipLaunchKernelGGL(k_mark_touched, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   SHINE_HIP_CHECK(hipGetLastError());

@@ -115,7 +115,11 @@ int prepare_step_v3(StepLaunch* out, const shine_tables* t, const shine_step_con
                     const int64_t* n_surf, int64_t n, const float* const* feats, const int64_t* rows, const float* const* mlp,
                     float* pred_out, float* grad_x_out, float* const* grad_feats, float* const* grad_mlp, double* loss_parts,
                     unsigned char* const* touched, void* workspace, size_t workspace_bytes) {
-  if (!slots) return set_error(SHINE_E_INVALID, "shine_train_step_v3: needs a planned batch (slots)");
+  if (!slots && cfg->sorted_input != 3)  // (a record pool carries its slots)
+    return set_error(SHINE_E_INVALID, "shine_train_step_v3: needs a planned batch (slots)");
+  if (cfg->sorted_input == 2)
+    return set_error(SHINE_E_INVALID, "shine_train_step_v3: a pool batch is drawn from a RECORD pool (sorted_input 3: one 32-byte "
+                                      "record per sample); the array form (2) is the importance sweep's");
   V1Args& a = out->a;
   a = V1Args{};
   int rc = fill_step_args(&a, t, cfg, coord, sdf_label, weight, perm, slots, n_surf, n, feats, rows, mlp, pred_out,

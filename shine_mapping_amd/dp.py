@@ -169,9 +169,12 @@ def mark_touched(octree, pool, idx: torch.Tensor, flags=None):
     t = octree._require_tables(probe=False)  # (memoised slots)
     if flags is None:
         flags = [torch.zeros(p.shape[0], dtype=torch.uint8, device=p.device) for p in octree.hier_features]
-    cfg = octree.step_config(sorted_input=2)
+    if getattr(pool, "rec", None) is not None:  # a pool of 32-byte records: the slots are read out of the records
+        cfg, base, slots = octree.step_config(sorted_input=3), pool.rec, pool.rec
+    else:
+        cfg, base, slots = octree.step_config(sorted_input=2), pool.coord, pool.slots
     _lib.check(
-        _lib.lib().shine_mark_touched(t.handle, C.byref(cfg), pool.coord.data_ptr(), idx.data_ptr(), pool.slots.data_ptr(),
+        _lib.lib().shine_mark_touched(t.handle, C.byref(cfg), base.data_ptr(), idx.data_ptr(), slots.data_ptr(),
                                       idx.numel(), octree.row_counts(), _lib.ptr_array([f.data_ptr() for f in flags]),
                                       _lib.current_stream_handle()),
         "shine_mark_touched",

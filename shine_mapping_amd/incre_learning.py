@@ -96,8 +96,9 @@ def cal_feature_importance(data, octree, mlp, sigma, bs, down_rate=1, loss_reduc
         if pool.size != sample_count or pool.tables_epoch != octree._tables_epoch or pool.coord.device != dev:
             raise ValueError("cal_feature_importance(pool=...): the pool must be the SortedPool of this frame's data, planned "
                              "on the current octree")
-        perm, slots = pool.perm, pool.slots
-        coord_s, label_s = octree._check_coord(pool.coord), pool.sdf_label.to(torch.float32).contiguous()
+        perm = pool.perm
+        coord_s, label_s, _, slots = pool.soa()  # (the sweep's entry point takes the contiguous arrays)
+        coord_s, label_s = octree._check_coord(coord_s), label_s.to(torch.float32)
     else:
         perm, slots = plan_batch(octree, coord_pool, sort=True)  # sorted position j holds pool sample perm[j]
         p = perm.long()

@@ -152,13 +152,21 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
             raise ValueError("pool mode needs idx = SortedPool.draw(n) (CUDA int32)")
         if pool.tables_epoch != octree._tables_epoch:
             raise RuntimeError("the octree grew since the pool was planned: call SortedPool.rebuild()")
-        coord, sdf_label, weight, perm, slots = pool.coord, pool.sdf_label, pool.weight, idx, pool.slots
         if eik_needs_count(opts) and n_surf is None:
             n_surf = (pool.weight[idx.long()] > 0).sum()
-    coord = octree._check_coord(coord.detach())
+    variant = int(opts.kernel_variant) & 0xff
+    # a pool of 32-byte records (sampler.SortedPool.rec; cfg.sorted_input 3): the record base goes in as `coord` — and, unread, as
+    # `slots`: the records carry them —, the weight array only for 4-level trees; the check library's kernel takes the arrays
+    rec_mode = pool_mode and getattr(pool, "rec", None) is not None and variant != 1
+    if rec_mode:
+        coord, sdf_label, weight, perm, slots = pool.rec, None, pool._weight_sep, idx, pool.rec
+    elif pool_mode:
+        coord, sdf_label, weight, slots = pool.soa()
+        perm = idx
+    if not rec_mode:
+        coord = octree._check_coord(coord.detach())
     n = idx.numel() if pool_mode else coord.shape[0]
     dev = coord.device
-    variant = int(opts.kernel_variant) & 0xff
     if not pool_mode and slots is None and variant != 1:
         # a batch without a plan (what the reference's get_batch hands over): neighbouring lanes would hit unrelated nodes and
         # the fused kernel takes the hash slots from the plan — order it by octree node and look the slots up first
@@ -168,11 +176,12 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         from .dp import plan_batch
 
         perm, slots = plan_batch(octree, coord)
-    sdf_label = _f32(sdf_label, "sdf_label")
+    if not rec_mode:
+        sdf_label = _f32(sdf_label, "sdf_label")
     eik = bool(opts.ekional_loss_on)
-    if bool(opts.loss_weight_on) and weight is None:
+    if bool(opts.loss_weight_on) and weight is None and not rec_mode:
         raise ValueError("loss_weight_on needs the sample weights")
-    if eik or weight is not None:
+    if (eik and not rec_mode) or weight is not None:
         weight = _f32(weight, "weight")
     if opts.loss_reduction not in ("mean", "sum"):
         raise ValueError("loss_reduction must be 'mean' or 'sum'")
@@ -185,7 +194,7 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
     cfg = octree.step_config(
         sigma=float(opts.sigma), weight_e=float(opts.weight_e), eikonal_on=1 if eik else 0,
         reduction_sum=1 if opts.loss_reduction == "sum" else 0, decoder_grad_on=1 if dec_grad else 0,
-        sorted_input=2 if pool_mode else (0 if perm is None else 1), n_global=n_global,
+        sorted_input=(3 if rec_mode else 2) if pool_mode else (0 if perm is None else 1), n_global=n_global,
         kernel_variant=int(opts.kernel_variant) | (0x4000 if getattr(opts, "deterministic", False) else 0),
         loss_weight_on=1 if opts.loss_weight_on else 0,
         inv_n=(1.0 if opts.loss_reduction == "sum" else 1.0 / max(n_global, 1)),
@@ -239,7 +248,7 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         (lambda *a: library.shine_iter_graph_set_step(graph.handle, *a[:-1]))  # (the same arguments minus the stream)
     _lib.check(
         entry(
-            t.handle, C.byref(cfg), coord.data_ptr(), sdf_label.data_ptr(),
+            t.handle, C.byref(cfg), coord.data_ptr(), sdf_label.data_ptr() if sdf_label is not None else None,
             weight.data_ptr() if weight is not None else None,
             perm.data_ptr() if perm is not None else None,
             slots.data_ptr() if slots is not None else None,

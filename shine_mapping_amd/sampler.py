@@ -73,18 +73,54 @@ class SortedPool:
             perm, slots = perm[order].contiguous(), slots[order].contiguous()
         p = perm.long()
         self.perm = perm  # sorted position j holds source sample perm[j] (cal_feature_importance(pool=...) re-uses the plan)
-        self.coord = coord[p].contiguous()
-        self.sdf_label = sdf_label[p].contiguous()
-        self.weight = weight[p].contiguous()
         self._surf_bits = None
         self._chunks = {}  # (bs, down_rate) -> importance_chunks(...)
-        self.slots = slots  # already in pool (= visiting) order
+        self._soa = None
         self.size = int(coord.shape[0])
+        self.device = coord.device
+        L = int(slots.shape[1])
+        self.levels = L
+        if L <= 4 and coord.is_cuda:
+            # ONE 32-byte record per sample (csrc/shine_step_body.hpp RecLayout): {x, y, z, label | weight, slot[0..L-1], pad} for
+            # L <= 3, {x, y, z, label | slot[0..3]} + a separate weight array for L = 4.  The fused step reads a drawn sample —
+            # a sparse sorted position of a pool of 10^7-10^8 — as one cache line instead of four (coord, label, weight, slots).
+            rec = torch.zeros((self.size, 8), dtype=torch.int32, device=coord.device)
+            recf = rec.view(torch.float32)
+            recf[:, 0:3] = coord[p]
+            recf[:, 3] = sdf_label[p]
+            if L < 4:
+                recf[:, 4] = weight[p]
+                rec[:, 5:5 + L] = slots
+                self._weight_sep = None
+            else:
+                rec[:, 4:8] = slots
+                self._weight_sep = weight[p].contiguous()
+            self.rec = rec
+            # the four arrays as (strided) views of the records: fine for torch indexing — pool.weight[idx.long()],
+            # pool.slots[idx.long()] —; library calls that want the contiguous arrays take soa()
+            self.coord, self.sdf_label = recf[:, 0:3], recf[:, 3]
+            self.weight = recf[:, 4] if L < 4 else self._weight_sep
+            self.slots = rec[:, 5:5 + L] if L < 4 else rec[:, 4:8]
+        else:  # (more than 4 featured levels: the check library's kernel only; CPU tensors: host-side tests)
+            self.rec = None
+            self.coord = coord[p].contiguous()
+            self.sdf_label = sdf_label[p].contiguous()
+            self.weight = weight[p].contiguous()
+            self.slots = slots  # already in pool (= visiting) order
         self.tables_epoch = self.octree._tables_epoch
         # sampler scratch of other pool sizes is dead weight (a graph captured for the old pool is invalid anyway: the
         # tables epoch moved); without this an object rebuilt every frame pins one buffer per distinct frame size
         for k in [k for k in self._ws if k[1] != self.size]:
             del self._ws[k]
+
+    def soa(self):
+        """(coord [P,3], sdf_label [P], weight [P], slots [P,L]) as CONTIGUOUS arrays — what the pool-mode entry points other than
+        the fused step take (the importance sweep, the check library's kernel).  Materialised from the records on first use and
+        kept until the next rebuild: frame pools (10^5 samples) pay nothing noticeable; a batch-mode pool of 10^8 samples should
+        not need it on its hot path (the fused step, shine_mark_touched and the draw read the records)."""
+        if self._soa is None:
+            self._soa = tuple(t.contiguous() for t in (self.coord, self.sdf_label, self.weight, self.slots))
+        return self._soa
 
     def importance_chunks(self, bs, down_rate=1):
         """The chunks of cal_feature_importance as segments of this pool's sorted positions (importance_chunks below), cached: it
@@ -112,7 +148,7 @@ class SortedPool:
         only if that step really was the last user of the pool's device stream state (tracked on the host) — otherwise both
         passes run.  A captured graph of {draw(pass1_done=True), step with the rider} must not be interleaved with other
         graph_safe draws of the same pool between replays."""
-        dev = self.coord.device
+        dev = self.device
         lib = _lib.lib()
         stream = _lib.current_stream_handle()
         sliced = n_global is not None and (int(n_global) != n or slice_begin)
@@ -171,7 +207,7 @@ class SortedPool:
           * StepOptions.next_draw: the fused step's reduction launch carries the first pass of the NEXT large draw (n_global:
             the size of the global draw when this rank draws a slice of it), which draw(..., pass1_done=True) completes.
         Keeps the device stream state of graph_safe draws."""
-        dev = self.coord.device
+        dev = self.device
         nsp = int(n_global) if n_global is not None else int(n)
         ws = self._ws.get((nsp, self.size))
         if ws is None:
@@ -211,9 +247,12 @@ class SortedPool:
 
     def surf_parts_buffer(self, n=None):
         """int64[64] buffer for draw(n, surf_parts=...): the partial surface counts of a batch (SHINE_SURF_PARTS)"""
-        return torch.zeros(SURF_PARTS, dtype=torch.int64, device=self.coord.device)
+        return torch.zeros(SURF_PARTS, dtype=torch.int64, device=self.device)
 
     def get_batch(self, idx):
         """(coord, sdf_label, weight) of a drawn batch, for code that wants the tensors (Tier A / debugging)."""
         i = idx.long()
-        return self.coord[i], self.sdf_label[i], self.weight[i]
+        if self.rec is None:
+            return self.coord[i], self.sdf_label[i], self.weight[i]
+        r = self.rec[i].view(torch.float32)  # (one gather of the drawn records)
+        return r[:, 0:3].contiguous(), r[:, 3].contiguous(), (r[:, 4].contiguous() if self._weight_sep is None else self._weight_sep[i])
