@@ -35,14 +35,21 @@ def module():
     from . import _lib
 
     _lib.lib()  # the C ABI library first: the extension links against it
-    spec = importlib.util.spec_from_file_location("_shine_ext", EXT_PATH)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    import ctypes
+    try:
+        spec = importlib.util.spec_from_file_location("_shine_ext", EXT_PATH)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        import ctypes
 
-    if mod.config_bytes() != ctypes.sizeof(_lib.StepConfig):
-        raise RuntimeError("_shine_ext.so was built against another shine_step_config: rebuild (python -m shine_mapping_amd.build)")
-    mod.set_callbacks(_interp_backward, _fused_split, _read_done)
+        if mod.config_bytes() != ctypes.sizeof(_lib.StepConfig):
+            raise ImportError("built against another shine_step_config")
+        mod.set_callbacks(_interp_backward, _fused_split, _read_done)
+    except Exception as e:  # e.g. undefined symbols after a torch upgrade: ONE warning, then the Python nodes every time
+        import warnings
+
+        warnings.warn("shine_mapping_amd: lib/_shine_ext.so did not load (%s: %s) — falling back to the Python autograd nodes; "
+                      "rebuild with `python -m shine_mapping_amd.build --force`" % (type(e).__name__, str(e)[:500]))
+        return None
     _mod = mod
     return _mod
 

@@ -639,7 +639,6 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, cpu_baselin
             opts_last = copy.copy(opts)
             opts_last.next_draw = rider
         primed = [False]
-
         def run_micro(idx, n_surf):
             """the rank's slice as m contiguous micro-batches: fused step (marks its rows) -> pack + all-gather; then add back"""
             loss = None

@@ -43,17 +43,40 @@ def _digest():
         if os.path.isfile(p):
             h.update(f.encode())
             h.update(open(p, "rb").read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(f for f in FLAGS if not os.path.isabs(f)).encode())  # (not the checkout's own path: the snapshot on a GPU box
+    #                                                                          lives elsewhere and must not rebuild for that)
     return h.hexdigest()
+
+
+def _ext_digest(hip_digest: str) -> str:
+    """the extension is host code against THIS interpreter's torch: its stamp also names the torch build and the C++ ABI flag, so
+    a torch upgrade rebuilds it instead of leaving a library with undefined symbols in place"""
+    try:
+        import torch
+
+        tag = "%s|abi%d" % (torch.__version__, int(torch._C._GLIBCXX_USE_CXX11_ABI))
+    except Exception as e:  # (no torch: the extension cannot be built either)
+        tag = "no-torch:%s" % type(e).__name__
+    return hashlib.sha256((hip_digest + "|" + tag).encode()).hexdigest()
+
+
+def _read(path):
+    return open(path).read() if os.path.isfile(path) else None
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "libshine_hip.stamp")
+    ext_stamp = os.path.join(LIBDIR, "_shine_ext.stamp")  # its own stamp: "built", or "failed" for this very input (not retried)
     dig = _digest()
-    if (not force and os.path.isfile(LIB) and os.path.isfile(CHECK_LIB) and os.path.isfile(EXT_LIB) and os.path.isfile(stamp)
-            and open(stamp).read() == dig):
+    ext_dig = _ext_digest(dig)
+    hip_fresh = (not force and os.path.isfile(LIB) and os.path.isfile(CHECK_LIB) and _read(stamp) == dig)
+    if hip_fresh:
+        st = _read(ext_stamp)
+        if (st == ext_dig and os.path.isfile(EXT_LIB)) or st == ext_dig + ":failed":
+            return LIB
+        _build_extension_optional(verbose, ext_stamp, ext_dig)
         return LIB
     if not os.path.isfile(HIPCC):
         raise RuntimeError("hipcc not found at %s; cannot build libshine_hip.so" % HIPCC)
@@ -88,16 +111,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
     link(LIB, product_objs)
     # the check library: the product's objects + the lane-per-point reference step
     link(CHECK_LIB, product_objs + check_objs)
-    build_extension(verbose)
-    open(stamp, "w").write(dig)
+    open(stamp, "w").write(dig)  # the HIP libraries stand on their own: the extension below is optional
+    _build_extension_optional(verbose, ext_stamp, ext_dig)
     return LIB
+
+
+def _build_extension_optional(verbose, ext_stamp, ext_dig):
+    """lib/_shine_ext.so is an accelerator of Tier A's host side, not a requirement: without a host g++ / matching torch headers
+    the Python autograd nodes (autograd_ops.py) serve — warn, remember the failure for this input, carry on."""
+    try:
+        build_extension(verbose)
+        open(ext_stamp, "w").write(ext_dig)
+    except Exception as e:
+        import warnings
+
+        if os.path.isfile(EXT_LIB):
+            os.remove(EXT_LIB)  # (a stale library from another torch would fail at import with undefined symbols)
+        open(ext_stamp, "w").write(ext_dig + ":failed")
+        warnings.warn("shine_mapping_amd: lib/_shine_ext.so (Tier A's C++ autograd nodes) was not built — the Python nodes are used "
+                      "instead (same launches, more host time per iteration): %s" % str(e)[:2000])
 
 
 def build_extension(verbose: bool = True) -> str:
     """lib/_shine_ext.so: csrc/shine_torch_ext.cpp against this interpreter's torch (host code only: plain g++)."""
     import sysconfig
 
-    import pybind11
     import torch
 
     ti = os.path.dirname(os.path.abspath(torch.__file__))
@@ -106,7 +144,7 @@ def build_extension(verbose: bool = True) -> str:
            "-DTORCH_EXTENSION_NAME=_shine_ext", "-DTORCH_API_INCLUDE_EXTENSION_H",
            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
            "-I" + os.path.join(ti, "include"), "-I" + os.path.join(ti, "include", "torch", "csrc", "api", "include"),
-           "-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include(),
+           "-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"],  # (pybind11: the headers torch bundles under its include/)
            os.path.join(CSRC, "shine_torch_ext.cpp"), "-o", EXT_LIB,
            "-L" + os.path.join(ti, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
            "-L" + LIBDIR, "-lshine_hip", "-Wl,-rpath," + os.path.join(ti, "lib"), "-Wl,-rpath,$ORIGIN"]

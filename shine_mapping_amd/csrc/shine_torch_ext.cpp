@@ -25,6 +25,7 @@
 #include <torch/csrc/autograd/functions/utils.h>
 #include <torch/csrc/autograd/saved_variable.h>
 
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -52,23 +53,69 @@ Tensor f32c(const Tensor& t) {  // (the kernels read float32 contiguous memory i
   return (t.scalar_type() == at::kFloat && t.is_contiguous()) ? t : t.contiguous().to(at::kFloat);
 }
 
+// Strong references to Python objects held from C++ and released under the GIL (a node may die on an autograd thread, or after
+// the interpreter: then the reference is leaked rather than touched).
+struct PyKeep {
+  py::object obj;
+  explicit PyKeep(py::object o) : obj(std::move(o)) {}
+  ~PyKeep() {
+    if (!obj) return;
+    if (Py_IsInitialized()) {
+      py::gil_scoped_acquire gil;
+      obj = py::object();
+    } else {
+      obj.release();
+    }
+  }
+};
+
 // What a FeatureOctree's launches need, refreshed by the Python side whenever the tables or the configuration change
-// (FeatureOctree._ext_state): the table handle, the scalar configuration, the row counts.
+// (FeatureOctree._ext_state): the table handle, the scalar configuration, the row counts.  Every autograd node takes a SNAPSHOT
+// (snapshot()): the handle / rows / configuration of ITS forward, a strong reference to the octree and its table object (the
+// Python nodes these replace kept ctx.octree: `del octree` before backward() must not free the handle under the node), and the
+// tables epoch of its forward — an update() between a forward and its backward (hash slots move, rows are appended) is refused
+// in apply() instead of planning the batch on other tables than the forward saw.
 struct TierAState {
   uintptr_t tables = 0;
   shine_step_config cfg;
   std::vector<int64_t> rows;
   int64_t py_id = 0;  // the octree's key in the Python-side registry (fallback callbacks)
   bool async_growth = false;
+  int64_t epoch = 0;                                 // FeatureOctree._tables_epoch when this state was set
+  std::shared_ptr<std::atomic<int64_t>> epoch_now;   // ... and now (the Python side stores every change: set_epoch)
+  std::shared_ptr<PyKeep> weak;                      // (weakref(octree), weakref(its _DeviceTables)): the live state is held by
+                                                     // the octree itself and must not keep it alive
+  std::shared_ptr<PyKeep> keep;                      // snapshots only: (octree, tables), strong
   int L() const { return cfg.n_levels; }
-  void set(uintptr_t handle, const std::string& cfg_bytes, std::vector<int64_t> r, int64_t id, bool async_) {
+  void set(uintptr_t handle, const std::string& cfg_bytes, std::vector<int64_t> r, int64_t id, bool async_, int64_t epoch_,
+           py::object owner) {
     if (cfg_bytes.size() != sizeof(shine_step_config)) throw std::runtime_error("TierAState.set: shine_step_config size mismatch");
     tables = handle;
     std::memcpy(&cfg, cfg_bytes.data(), sizeof(cfg));
     rows = std::move(r);
     py_id = id;
     async_growth = async_;
+    epoch = epoch_;
+    if (!epoch_now) epoch_now = std::make_shared<std::atomic<int64_t>>(epoch_);
+    epoch_now->store(epoch_);
+    weak = std::make_shared<PyKeep>(std::move(owner));
     if ((int)rows.size() != cfg.n_levels) throw std::runtime_error("TierAState.set: one row count per featured level");
+  }
+  // (called with the GIL held: from the Python-facing entry points)
+  std::shared_ptr<TierAState> snapshot() const {
+    auto s = std::make_shared<TierAState>(*this);
+    if (weak && weak->obj) {
+      py::tuple w = weak->obj.cast<py::tuple>();
+      py::list strong;
+      for (auto ref : w) strong.append(ref());  // (None for an object that is already gone: nothing to keep)
+      s->keep = std::make_shared<PyKeep>(std::move(strong));
+    }
+    return s;
+  }
+  void check_epoch(const char* who) const {
+    if (epoch_now && epoch_now->load() != epoch)
+      throw std::runtime_error(std::string(who) + ": the octree's tables changed (update()) between this node's forward and its "
+                               "backward; run backward() before growing the octree, or query again");
   }
 };
 
@@ -117,7 +164,9 @@ struct InterpNode : public Node {
   std::vector<SavedVariable> feats;
   int64_t py_id = 0;
   bool need_coord = false;
+  std::shared_ptr<TierAState> st;  // snapshot: keeps the octree (the registry behind py_id holds weak references) and the epoch
   variable_list apply(variable_list&& grads) override {
+    st->check_epoch("query_feature's backward");
     py::gil_scoped_acquire gil;
     if (!grads[0].defined()) return variable_list(1 + feats.size());
     py::list fl;
@@ -149,6 +198,7 @@ struct FusedSdfNode : public Node {
     link->q = Tensor();
     variable_list out(1 + L + 6);
     if (!g.defined() && !q.defined()) return out;
+    st->check_epoch("the fused query_feature -> sdf node's backward");
     Tensor c = coord.unpack();
     std::vector<Tensor> F, M;
     for (auto& f : feats) F.push_back(f.unpack());
@@ -215,7 +265,7 @@ struct FusedSdfNode : public Node {
     for (auto& m : M) Mc.push_back(f32c(m));
     cfg.sorted_input = 1;
     cfg.decoder_grad_on = need_m ? 1 : 0;
-    cfg.kernel_variant = deterministic ? 0x4000 : 0;
+    cfg.kernel_variant |= deterministic ? 0x4000 : 0;  // (OR: FeatureOctree.DEBUG_VARIANT_BITS travel in st->cfg)
     Tensor ws = step_workspace(cc, cfg, stream);
     auto fp = ptrs(Fc), mp = ptrs(Mc);
     std::vector<float*> gf, gm;
@@ -286,6 +336,7 @@ struct RegNode : public Node {
     variable_list out(L);
     if (!grads[0].defined()) return out;
     if (at::GradMode::is_enabled()) throw std::runtime_error("cal_regularization's node is differentiable once");
+    st->check_epoch("cal_regularization's backward");
     at::NoGradGuard ng;
     std::vector<Tensor> F;
     for (auto& f : feats) F.push_back(f32c(f.unpack()));
@@ -365,6 +416,7 @@ std::pair<Tensor, c10::optional<Tensor>> query_feature(const std::shared_ptr<Tie
     node->coord = SavedVariable(coord, false);
     for (auto& f : feats) node->feats.emplace_back(f, false);
     node->py_id = st->py_id;
+    node->st = st->snapshot();
     node->need_coord = coord.requires_grad();
     torch::autograd::create_gradient_edge(feat, node);
   }
@@ -397,7 +449,7 @@ std::pair<Tensor, std::shared_ptr<Link>> fused_sdf(const std::shared_ptr<TierASt
   node->coord = SavedVariable(coord, false);
   for (auto& f : feats) node->feats.emplace_back(f, false);
   for (auto& m : mlp) node->mlp.emplace_back(m, false);
-  node->st = st;
+  node->st = st->snapshot();
   node->link = link;
   node->deterministic = deterministic;
   for (auto& t : inputs) node->need.push_back(t.requires_grad());
@@ -500,7 +552,7 @@ Tensor cal_regularization(const std::shared_ptr<TierAState>& st, const Tensor& c
   }
   if (need_grad) {
     auto node = make_node<RegNode>(feats);
-    node->st = st;
+    node->st = st->snapshot();
     node->coord = c;
     for (auto& f : feats) node->feats.emplace_back(f, false);
     node->last = lastc;
@@ -551,8 +603,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "Tier A autograd nodes of shine_mapping_amd in C++ (shine_torch_ext.cpp)";
   py::class_<TierAState, std::shared_ptr<TierAState>>(m, "TierAState")
       .def(py::init<>())
-      .def("set", [](TierAState& s, uintptr_t handle, py::bytes cfg, std::vector<int64_t> rows, int64_t id, bool async_) {
-        s.set(handle, std::string(cfg), std::move(rows), id, async_);
+      .def("set", [](TierAState& s, uintptr_t handle, py::bytes cfg, std::vector<int64_t> rows, int64_t id, bool async_,
+                     int64_t epoch, py::object owner) {
+        s.set(handle, std::string(cfg), std::move(rows), id, async_, epoch, std::move(owner));
+      })
+      .def("set_epoch", [](TierAState& s, int64_t epoch) {  // FeatureOctree._tables_epoch's setter
+        if (s.epoch_now) s.epoch_now->store(epoch);
       });
   py::class_<Link, std::shared_ptr<Link>>(m, "Link").def("pending", [](Link& l) { return l.q.defined(); });
   m.def("set_callbacks", [](py::object interp_backward, py::object fused_split, py::object read_done) {

@@ -17,6 +17,7 @@ There is no CPU fallback: every query goes through the HIP library and raises if
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List
 
 import numpy as np
@@ -310,7 +311,7 @@ class FeatureOctree(nn.Module):
             self._node_ids[s] = np.concatenate((self._node_ids[s], ids))
             self._node_sorted[s] = np.sort(np.concatenate((known, fresh)))
             self._pending[s].append((fresh, ids))  # uploaded to the device hash table at the next query
-            self._tables_epoch += 1
+            self._bump_epoch()
 
     def _append_rows(self, s, first, added, incremental_on, dev):
         """The feature-side half of update() for one level that received new nodes (:135-160)."""
@@ -413,7 +414,7 @@ class FeatureOctree(nn.Module):
         self._dict_cache = None
         if side is main:
             self._ranks_uploaded = False
-        self._tables_epoch += 1
+        self._bump_epoch()
         if self.retired_table_bytes() > self.trim_retired_above:
             self.trim_tables()
 
@@ -612,6 +613,14 @@ class FeatureOctree(nn.Module):
 
     DEBUG_VARIANT_BITS = 0  # measurement only (tools/): OR-ed into every launch's kernel_variant, e.g. 0x800 = plan with the counting sort
 
+    def _bump_epoch(self):
+        """the tables changed (nodes added, handle rebuilt): planned pools are stale, and so is every pending C++ autograd node of
+        this octree — the extension's state learns the new epoch at once (csrc/shine_torch_ext.cpp TierAState::check_epoch)"""
+        self._tables_epoch = getattr(self, "_tables_epoch", 0) + 1
+        st = self.__dict__.get("_ext_st")
+        if st is not None:
+            st.set_epoch(int(self._tables_epoch))
+
     def _ext_state(self, ext):
         """The C++ extension's view of this octree (csrc/shine_torch_ext.cpp TierAState): table handle, scalar configuration,
         row counts — refreshed when the tables grew or were rebuilt (both bump _tables_epoch)."""
@@ -623,7 +632,8 @@ class FeatureOctree(nn.Module):
             if st is None:
                 st = d["_ext_st"] = ext.TierAState()
             st.set(int(self._tables.handle.value), bytes(self.step_config()), [int(r) for r in self.row_counts()],
-                   _ext.register(self), self._growth_stream is not None)
+                   _ext.register(self), self._growth_stream is not None, int(self._tables_epoch),
+                   (weakref.ref(self), weakref.ref(self._tables)))  # (weak: this state lives in the octree's own __dict__)
             d["_ext_key"] = key
         return st
 
@@ -865,7 +875,7 @@ class FeatureOctree(nn.Module):
             self._grow_box(self._node_keys[0])
         self._tables = None
         self._ranks_uploaded = False
-        self._tables_epoch = getattr(self, "_tables_epoch", 0) + 1
+        self._bump_epoch()
         self._pending = [[(self._node_keys[s], self._node_ids[s])] if self._node_keys[s].size else []
                          for s in range(self.featured_level_num)]
 

@@ -100,7 +100,8 @@ def forward_sdf(octree, decoder, coord, want_feat=False, want_indices=False, wan
 
 def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,
                      n_surf: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None, touched=None,
-                     pool=None, idx: Optional[torch.Tensor] = None, pending: Optional[dict] = None, graph=None):
+                     pool=None, idx: Optional[torch.Tensor] = None, pending: Optional[dict] = None, graph=None,
+                     grad_buffers=None):
     """One training iteration's forward+backward (no optimiser): the fused Tier-B step, raw form.
 
     coord [N,3], sdf_label [N], weight [N] (sign: + surface / - free space, utils/data_sampler.py:102-103).
@@ -114,9 +115,13 @@ def fused_train_step(octree, decoder, coord, sdf_label, weight, opts: StepOption
     FusedAdam.finish_iteration(pending, ...) needs, and `loss` is valid after that call.
     `graph` (loop.IterationGraph, with `pending`): nothing is launched — the launch this call would make becomes the step node
     of the library-built iteration graph (shine_iter_graph_set_step); outputs are valid after the graph ran.
+    `grad_buffers` = (L feature-grad tensors, 6 decoder-grad tensors): accumulate into THESE (zero-filled by the caller) instead of
+    the parameters' `.grad`.
     """
+    gfeat, gmlp = grad_buffers if grad_buffers is not None else (None, None)
     return _fused_launch(octree, decoder, coord, sdf_label, weight, opts, want_grad_x=want_grad_x, perm=perm,
-                         n_surf=n_surf, slots=slots, touched=touched, pool=pool, idx=idx, pending=pending, graph=graph)
+                         n_surf=n_surf, slots=slots, touched=touched, pool=pool, idx=idx, pending=pending, graph=graph,
+                         gfeat=gfeat, gmlp=gmlp)
 
 
 def train_step(octree, decoder, coord, sdf_label, weight, opts: StepOptions, want_grad_x=False, perm=None,

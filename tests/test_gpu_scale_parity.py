@@ -1629,3 +1629,57 @@ def test_config_5_shape_eight_real_rank_messages():
         assert float((red_cpu[off:off + sz] - total[off:off + sz]).abs().max()) <= TOL * scale, "reduced tensor %d vs oracle" % k
         assert float((single_cpu[off:off + sz] - total[off:off + sz]).abs().max()) <= TOL * scale, "single tensor %d vs oracle" % k
         off += sz
+
+
+@pytest.mark.gpu
+def test_cpp_nodes_hold_their_octree_and_refuse_tables_that_changed():
+    """the C++ autograd nodes (csrc/shine_torch_ext.cpp) take a SNAPSHOT of the octree's launch state at their
+    forward — table handle, row counts, a strong reference to the octree and its table object, the tables epoch.
+      * `del octree` between forward and backward: the Python nodes these replace kept ctx.octree; the C++ ones must too (the handle
+        would be destroyed under the backward's plan otherwise) — the gradients equal the ones of a run that kept the octree;
+      * an update() between a node's forward and its backward (rows appended, hash slots moved): refused with a clear error
+        instead of planning the batch on other tables than the forward saw."""
+    import gc
+    import weakref
+
+    from shine_mapping_amd import _ext
+
+    if _ext.module() is None:
+        pytest.skip("lib/_shine_ext.so not built")
+    fx = load_golden("maicity_bce_L3")
+    coord, label = fx["coord"].cuda(), fx["sdf_label"].cuda()
+
+    def run(drop):
+        cfg, octree, dec = product_from_golden(fx)
+        params = list(octree.hier_features) + dec.fused_params()
+        pred = dec.sdf(octree.query_feature(coord))
+        assert "[ext]" in pred.grad_fn.name()
+        loss = (pred * label).sum()
+        alive = weakref.ref(octree)
+        if drop:
+            del octree
+            gc.collect()
+            assert alive() is not None  # the node holds it
+        loss.backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in params]
+
+    kept, dropped = run(False), run(True)
+    for a, b in zip(kept, dropped):
+        assert rel_err(a, b) <= 1e-6
+    # growth between forward and backward (the incremental configuration's fixture: importance weights present)
+    fx = load_golden("ncd_reg_L3")
+    coord = fx["coord"].cuda()
+    cfg, octree, dec = product_from_golden(fx)
+    pred = dec.sdf(octree.query_feature(coord))
+    far = (coord.detach() * 0.5 + torch.tensor([0.41, -0.37, 0.29], device="cuda")).clamp(-0.99, 0.99)
+    rows_before = [int(p.shape[0]) for p in octree.hier_features]
+    octree.update(far, incremental_on=True)
+    assert [int(p.shape[0]) for p in octree.hier_features] != rows_before  # it did grow
+    with pytest.raises(RuntimeError, match="tables changed"):
+        pred.sum().backward()
+    # ... and a fresh query on the grown octree works
+    pred = dec.sdf(octree.query_feature(coord))
+    pred.sum().backward()
+    torch.cuda.synchronize()
+    assert all(p.grad is not None for p in octree.hier_features)

@@ -3,7 +3,9 @@
 of the ordered stream (the product's count: one 64-lane atomic = 8 row-atomics per run) against the number of DISTINCT corner
 rows per window of W consecutive points (what merging by corner inside a tile / a wave's range / a workgroup's range would issue).
 
-    python tools/atomics_count.py [maicity|kitti] [points] [levels]
+    python tools/atomics_count.py [maicity|kitti|kitti_large] [points] [levels] [frames] [azimuths]
+(kitti_large 1048576 3 2800 300 = bench.py's kitti-large: windows of 512 points = one wave's tile range of the full-chip launch,
+4096 = one workgroup's)
 """
 import os
 import sys
@@ -17,7 +19,9 @@ from shine_mapping_amd.sampler import SortedPool  # noqa: E402
 kind = sys.argv[1] if len(sys.argv) > 1 else "maicity"
 pts = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 18
 lv = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-wl = synth.build_workload(kind, frames=60, device="cuda", seed=42, tree_level_feat=lv, azimuths=450)
+frames = int(sys.argv[4]) if len(sys.argv) > 4 else 60
+az = int(sys.argv[5]) if len(sys.argv) > 5 else 450
+wl = synth.build_workload(kind, frames=frames, device="cuda", seed=42, tree_level_feat=lv, azimuths=az)
 octree = wl.octree
 octree._require_tables(with_ranks=True)
 sp = SortedPool(octree, wl.pool.coord, wl.pool.sdf_label, wl.pool.weight)
@@ -35,7 +39,7 @@ for k, ids in enumerate(hi):
     runs = int((chg & hit).sum())
     line = "  level %d (bottom-up): hits %d, node runs %d -> %d row-atomics" % (k, int(hit.sum()), runs, runs * 8)
     tot_runs += runs
-    for W in (16, 64, 128, 1024, pts):
+    for W in (16, 64, 512, 4096, 32768, pts):
         n_win = (pts + W - 1) // W
         win = torch.arange(pts, device=ids.device) // W
         key = (win[:, None] * (1 << 40) + ids)[hit]  # (window, corner row)

@@ -55,6 +55,33 @@ __global__ __launch_bounds__(256) void k_scatter(Tabs t, const int* ids, const u
   }
 }
 
+// Round 6: what the SAME scatter stream costs when a row is updated without the L2's atomic units — a plain read-modify-write
+// (valid in the step only for rows a wave owns exclusively; here the races are ignored: the question is the memory system's
+// rate).  mode 0: DEPTH independent loads in flight per wave, then DEPTH adds + stores; mode 1: stores only (the upper bound).
+template <int DEPTH, int MODE>
+__global__ __launch_bounds__(256) void k_scatter_rmw(Tabs t, const int* ids, const unsigned char* lvl, long long m) {
+  const long long nb = gridDim.x, b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane >> 3, q = lane & 7;
+  const long long lo = b * m / nb, hi = (b + 1) * m / nb;
+  for (long long e0 = lo + wv * DEPTH; e0 < hi; e0 += 4 * DEPTH) {
+    float* p[DEPTH];
+    float v[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) {
+      const long long e = e0 + k;
+      const int id = e < hi ? ids[e * 8 + c] : -1;
+      p[k] = id >= 0 ? t.grad[lvl[e < hi ? e : lo]] + (size_t)(unsigned int)id * 8 + q : nullptr;
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < DEPTH; ++k) v[k] = p[k] ? *p[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k)
+      if (p[k]) *p[k] = MODE == 0 ? v[k] + 1.0f : 1.0f;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_both(Tabs t, const int* gids, const unsigned char* glvl, long long gm, const int* sids,
                                                const unsigned char* slvl, long long sm, float* out) {
   const long long nb = gridDim.x / 2, b = blockIdx.x / 2;
@@ -91,5 +118,17 @@ extern "C" int rr_both(const float* const* feat, float* const* grad, const int* 
   Tabs t = {};
   for (int l = 0; l < 4; ++l) t.feat[l] = feat[l], t.grad[l] = grad[l];
   hipLaunchKernelGGL(k_both, dim3(2 * blocks), dim3(256), 0, (hipStream_t)stream, t, gids, glvl, gm, sids, slvl, sm, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rr_scatter_rmw(float* const* grad, const int* ids, const unsigned char* lvl, long long m, int blocks, int depth,
+                              int mode, void* stream) {
+  Tabs t = {};
+  for (int l = 0; l < 4; ++l) t.grad[l] = grad[l];
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 1) hipLaunchKernelGGL((k_scatter_rmw<8, 1>), dim3(blocks), dim3(256), 0, st, t, ids, lvl, m);
+  else if (depth == 1) hipLaunchKernelGGL((k_scatter_rmw<1, 0>), dim3(blocks), dim3(256), 0, st, t, ids, lvl, m);
+  else if (depth == 4) hipLaunchKernelGGL((k_scatter_rmw<4, 0>), dim3(blocks), dim3(256), 0, st, t, ids, lvl, m);
+  else hipLaunchKernelGGL((k_scatter_rmw<8, 0>), dim3(blocks), dim3(256), 0, st, t, ids, lvl, m);
   return (int)hipGetLastError();
 }

@@ -58,7 +58,7 @@ def timed(fn, reps=10):
     return min(best)
 
 
-for blocks in (1024, 2048, 4096):
+for blocks in (1024, 2048, 4096, 8192):
     tg = timed(lambda: lib.rr_gather(fp, C.c_void_p(g_ids.data_ptr()), C.c_void_p(g_lvl.data_ptr()), C.c_longlong(g_ids.shape[0]),
                                      C.c_void_p(out.data_ptr()), blocks, C.c_void_p(st)))
     ts = timed(lambda: lib.rr_scatter(gp, C.c_void_p(s_ids.data_ptr()), C.c_void_p(s_lvl.data_ptr()), C.c_longlong(s_ids.shape[0]),
@@ -66,5 +66,12 @@ for blocks in (1024, 2048, 4096):
     tb = timed(lambda: lib.rr_both(fp, gp, C.c_void_p(g_ids.data_ptr()), C.c_void_p(g_lvl.data_ptr()), C.c_longlong(g_ids.shape[0]),
                                    C.c_void_p(s_ids.data_ptr()), C.c_void_p(s_lvl.data_ptr()), C.c_longlong(s_ids.shape[0]),
                                    C.c_void_p(out.data_ptr()), blocks // 2, C.c_void_p(st)))
+    rmw = {}
+    if hasattr(lib, "rr_scatter_rmw"):
+        for name, depth, mode in (("rmw x1", 1, 0), ("rmw x4", 4, 0), ("rmw x8", 8, 0), ("store x8", 8, 1)):
+            rmw[name] = timed(lambda: lib.rr_scatter_rmw(gp, C.c_void_p(s_ids.data_ptr()), C.c_void_p(s_lvl.data_ptr()),
+                                                         C.c_longlong(s_ids.shape[0]), blocks, depth, mode, C.c_void_p(st)))
+        print("  %4d workgroups x 256, the scatter stream WITHOUT atomics (plain row read-modify-write, loads in flight per wave): %s" % (
+            blocks, ", ".join("%s %.1f us" % kv for kv in rmw.items())), flush=True)
     print("  %4d workgroups x 256: gather %.1f us (%.2f TB/s of row bytes), scatter %.1f us (%.1f atomics/ns), both in one launch %.1f us" % (
         blocks, tg, rows_g * 32 / tg / 1e6, ts, rows_s * 8 / ts / 1e3, tb), flush=True)
