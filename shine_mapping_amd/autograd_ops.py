@@ -346,7 +346,7 @@ class FusedInterpSdf(torch.autograd.Function):
         g = _f32c(g) if g is not None else torch.zeros(n, dtype=torch.float32, device=dev)
         sizes = [p.numel() if nf else 0 for p, nf in zip(feats, need_f)] + [p.numel() if need_m else 0 for p in mlp]
         flat = torch.empty((sum(sizes) + 3) // 4 * 4, dtype=torch.float32, device=dev)
-        perm, slots = plan_batch(octree, c, zero=flat)  # (the plan's first pass also clears the gradient buffer)
+        perm, slots = plan_batch(octree, c, zero=flat, sort=False)  # (the plan's first pass also clears the gradient buffer)
         views, off = [], 0
         for p, sz in zip(params, sizes):
             views.append(flat[off:off + sz].view_as(p) if sz else None)

@@ -113,11 +113,13 @@ def morton_order(octree, coord: torch.Tensor) -> torch.Tensor:
     return perm
 
 
-def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None, _debug_variant: int = 0, out=None, sort: bool = None):
-    """Order the batch by octree node (counting sort over the node ranks) and look up every point's hash slots.  Batches of
-    <= 16384 points (the reference's batch size is 4096) are left in the order given (perm = identity, ONE launch: the fused step
-    does not see the order at that size and the histogram runs over every node of the tree) unless sort=True — a sample pool that
-    is planned once and drawn from many times (sampler.SortedPool, the importance sweep) asks for the node order at any size.
+def plan_batch(octree, coord: torch.Tensor, zero: torch.Tensor = None, _debug_variant: int = 0, out=None, sort: bool = True):
+    """Order the batch by octree node (counting sort over the node ranks) and look up every point's hash slots: `perm` IS the node
+    order (sort=True, the default of this public function: consumers such as sampler.canonical_order, incre_learning.
+    chunk_partition or a SortedPool rely on it — ADVICE r05).  sort=False is the per-iteration form of the step's own callers
+    (ops._fused_launch, the Tier A backward): batches of <= 16384 points (the reference's batch size is 4096) are left in the
+    order given (perm = identity, ONE launch: the fused step does not see the order at that size and the histogram runs over every
+    node of the tree); larger ones are sorted either way.
 
     Returns (perm [N] int32, slots [N, L] int32), both on the device, to pass to fused_train_step(perm=, slots=).
     Cheaper than morton_order (3 small launches vs a multi-pass radix sort) and it moves the hash probing out of the

@@ -24,16 +24,21 @@ for anything it does not cover, each with an opt-out environment variable (= "0"
                                      (lets the eikonal configurations use the fused node)            SHINE_DROPIN_FUSED_GRADIENT
 
     utils.incre_learning.cal_feature_importance -> incre_learning.cal_feature_importance: the chunk loop of
-                                     utils/incre_learning.py:8-40 as two launches per 64 chunks (shine_incre.py:185-188 imports
-                                     it after this module, so the driver's name binds to it)   SHINE_DROPIN_FUSED_IMPORTANCE
+                                     utils/incre_learning.py:8-40 as two launches per 64 chunks.  The driver binds the name at
+                                     shine_incre.py:15 (`from utils.incre_learning import cal_feature_importance`): with the
+                                     drop-in imported FIRST (line 1) it picks up this one; names a module bound before the
+                                     drop-in was imported are re-bound too (rebind_imported_names: `__main__` and the two
+                                     drivers, only where they still hold the reference's original)   SHINE_DROPIN_FUSED_IMPORTANCE
 
 `FeatureOctree.cal_regularization` (shine_incre.py:156) needs no re-binding: it is a method of the replaced class, and runs as one
 autograd node over two launches whenever it follows a `query_feature` (autograd_ops.OctreeRegularizer).
 
-The drivers are single-threaded, so the drop-in also lets autograd run a backward on the CALLING thread
+The drivers are single-threaded, so for THEM the drop-in also lets autograd run a backward on the CALLING thread
 (`torch.autograd.set_multithreading_enabled(False)`: the engine's hand-over to its device thread and back is a third of a BCE
-iteration's host time at the reference's batch size — 0.32 -> 0.21 ms, profiles/r05_tier_a_bench.log); SHINE_DROPIN_SINGLE_THREAD_BACKWARD=0
-leaves the engine's default, `uninstall()` restores it.
+iteration's host time at the reference's batch size — 0.32 -> 0.21 ms, profiles/r05_tier_a_bench.log).  That switch is
+process-wide, so it is flipped only when the process IS one of the reference's drivers (`__main__` is shine_batch.py /
+shine_incre.py) or SHINE_DROPIN_SINGLE_THREAD_BACKWARD=1 asks for it (importing the drop-in into a process with
+other autograd users must not change their threading); =0 never; `uninstall()` restores what it found.
 
 The re-binding needs `utils.tools` / `utils.loss` to be importable when this module is imported (the drivers import it from the
 reference's root directory, first line); `patch_utils()` can be called again later, `status()` says what is in place.
@@ -71,7 +76,7 @@ def install():
     pkg.feature_octree = fo
     pkg.decoder = de
     _INSTALLED = True
-    if _on("SHINE_DROPIN_SINGLE_THREAD_BACKWARD"):
+    if _single_thread_backward_wanted():
         import torch
 
         _STATUS_KEEP["autograd_multithreading"] = torch.autograd.is_multithreading_enabled()
@@ -92,6 +97,37 @@ def status():
 
 def _on(var):
     return os.environ.get(var, "1") != "0"
+
+
+DRIVER_FILES = ("shine_batch.py", "shine_incre.py")
+
+
+def _single_thread_backward_wanted():
+    """process-wide switch: on for the reference's own (single-threaded) drivers, or when asked for explicitly"""
+    v = os.environ.get("SHINE_DROPIN_SINGLE_THREAD_BACKWARD")
+    if v is not None:
+        return v != "0"
+    main = sys.modules.get("__main__")
+    return os.path.basename(getattr(main, "__file__", "") or "") in DRIVER_FILES
+
+
+_REBOUND = []  # (module, name, original) of rebind_imported_names, for uninstall()
+
+
+def rebind_imported_names(triples):
+    """`from utils.x import name` copies a function into the importing module: a driver (or `__main__`) that ran those imports
+    BEFORE the drop-in was imported still holds the reference's originals.  triples: [(name, original, replacement)]; module
+    attribute `name` is re-bound only where it still IS the original.  -> number of names re-bound"""
+    mods = [m for k, m in list(sys.modules.items())
+            if m is not None and (k == "__main__" or k in ("shine_batch", "shine_incre"))]
+    n = 0
+    for mod in mods:
+        for name, orig, new in triples:
+            if new is not orig and vars(mod).get(name) is orig:
+                setattr(mod, name, new)
+                _REBOUND.append((mod, name, orig))
+                n += 1
+    return n
 
 
 def patch_utils():
@@ -171,6 +207,12 @@ def patch_utils():
         else:
             ul.sdf_bce_loss = ul._shine_reference["sdf_bce_loss"]
             _STATUS["sdf_bce_loss"] = "off (SHINE_DROPIN_FUSED_LOSS=0)"
+    # names the importing module copied before this ran (drop-in imported after `from utils.tools import *`, shine_incre.py:13-15)
+    triples = []
+    for mod in (ut, ul, ui):
+        for attr, orig in getattr(mod, "_shine_reference", {}).items():
+            triples.append((attr, orig, getattr(mod, attr)))
+    _STATUS["names_rebound_in_loaded_drivers"] = rebind_imported_names(triples)
     return status()
 
 
@@ -188,6 +230,9 @@ def uninstall():
         mod = sys.modules.get(name)
         for attr, fn in getattr(mod, "_shine_reference", {}).items():
             setattr(mod, attr, fn)
+    while _REBOUND:
+        mod, name, orig = _REBOUND.pop()
+        setattr(mod, name, orig)
     from . import autograd_ops
 
     autograd_ops.FUSE_WITH_COORD_GRAD = False

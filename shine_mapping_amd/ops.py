@@ -180,7 +180,7 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         # dp.morton_order) is replaced by the plan's node order: the step does not depend on the visiting order.
         from .dp import plan_batch
 
-        perm, slots = plan_batch(octree, coord)
+        perm, slots = plan_batch(octree, coord, sort=False)  # (the step does not see the order of a small batch: one launch)
     if not rec_mode:
         sdf_label = _f32(sdf_label, "sdf_label")
     eik = bool(opts.ekional_loss_on)

@@ -388,8 +388,9 @@ def test_small_batches_are_planned_in_one_launch_and_not_reordered(n):
     coord = base[torch.randint(0, base.shape[0], (n,), generator=g)].clone()
     coord[::7] += 0.9  # some points that miss everywhere
     coord = coord.cuda()
-    perm, slots = dp.plan_batch(octree, coord)
-    sperm, sslots = dp.plan_batch(octree, coord, _debug_variant=0x800)
+    perm, slots = dp.plan_batch(octree, coord, sort=False)  # the per-iteration form of the step's own callers
+    sperm, sslots = dp.plan_batch(octree, coord)            # the public default: node order at any size
+    assert torch.equal(sperm, dp.plan_batch(octree, coord, _debug_variant=0x800)[0])
     torch.cuda.synchronize()
     p, sl, sp, ssl = perm.cpu().long(), slots.cpu(), sperm.cpu().long(), sslots.cpu()
     assert torch.equal(torch.sort(p).values, torch.arange(n)) and torch.equal(torch.sort(sp).values, torch.arange(n))
@@ -400,7 +401,7 @@ def test_small_batches_are_planned_in_one_launch_and_not_reordered(n):
     assert torch.equal(by_point, s_by_point)
     for floats in (4, 1 << 20, (1 << 26) + 4):  # the gradient bucket rides on the launch
         flat = torch.ones(floats, device="cuda")
-        perm3, slots3 = dp.plan_batch(octree, coord, zero=flat)
+        perm3, slots3 = dp.plan_batch(octree, coord, zero=flat, sort=False)
         assert float(flat.abs().sum()) == 0.0
         if n <= 16384:
             assert torch.equal(perm3.cpu().long(), p) and torch.equal(slots3.cpu(), sl)

@@ -473,7 +473,12 @@ def test_dropin_rebinds_the_reference_utils_functions():
         "import utils.tools as ut, utils.loss as ul, utils.incre_learning as ui\n"
         "orig = (ut.setup_optimizer, ut.get_gradient, ul.sdf_bce_loss)\n"
         "orig_sweep = ui.cal_feature_importance\n"
+        "from utils.incre_learning import cal_feature_importance  # (a driver that ran its imports BEFORE the drop-in's, :15)\n"
+        "mt = torch.autograd.is_multithreading_enabled()\n"
         "import shine_mapping_amd.dropin as d\n"
+        "assert cal_feature_importance is ui.cal_feature_importance is not orig_sweep  # ... has its name re-bound (ADVICE r05)\n"
+        "assert d.status()['names_rebound_in_loaded_drivers'] == 1 and orig_sweep is not ui.cal_feature_importance\n"
+        "assert torch.autograd.is_multithreading_enabled() == mt  # (process-wide switch: only for the drivers' own processes)\n"
         "from shine_mapping_amd import losses, optim, autograd_ops\n"
         "st = d.status()\n"
         "assert st['setup_optimizer'] is True and st['get_gradient'] is True and st['sdf_bce_loss'] is True, st\n"
@@ -499,6 +504,7 @@ def test_dropin_rebinds_the_reference_utils_functions():
         "c = torch.randn(7, 3, requires_grad=True)\n"
         "assert torch.equal(ns['get_gradient'](c, (c ** 2).sum(1)), orig[1](c, (c ** 2).sum(1)))\n"
         "d.uninstall()\n"
+        "assert cal_feature_importance is orig_sweep\n"
         "assert (ut.setup_optimizer, ut.get_gradient, ul.sdf_bce_loss) == orig and not autograd_ops.FUSE_WITH_COORD_GRAD\n"
         "assert ui.cal_feature_importance is orig_sweep\n"
         "os.environ['SHINE_DROPIN_FUSED_LOSS'] = '0'\n"
