@@ -60,6 +60,21 @@ typedef struct shine_next_draw {
                               shine_step_config.next_draw only */
 } shine_next_draw;
 
+/* FeatureOctree.cal_regularization (model/feature_octree.py:246-255) riding on the query's launch (shine_forward, cfg->reg_rider):
+ * every row the batch addresses — unique(hierarchical_indices) without -1 — adds sum_f importance[row][f] * (F[row][f] -
+ * F_last[row][f])^2 ONCE per launch (a row is claimed by an atomic exchange of its stamp with the launch's epoch).  The VALUE only
+ * (config 4 from its second frame on: features_last_frame is an attached clone, its gradient cancels, :160).  All arrays top-down
+ * like the feature tables; stamp[s]: device uint32[rows_s + 1], zero-filled when created; epoch: > 0, strictly increasing from
+ * launch to launch of one octree; acc: device float[8] (zero-filled when created): this launch accumulates into acc[epoch & 7] and
+ * clears acc[(epoch + 1) & 7] for the next one. */
+typedef struct shine_reg_rider {
+  const float* last[SHINE_MAX_LEVELS];   /* features_last_frame */
+  const float* imp[SHINE_MAX_LEVELS];    /* importance_weight */
+  uint32_t* stamp[SHINE_MAX_LEVELS];
+  uint32_t epoch;
+  float* acc;
+} shine_reg_rider;
+
 /* scalar configuration of one hot-path call (plain-old-data, passed by pointer from the host) */
 typedef struct shine_step_config {
   int32_t n_levels;        /* L = tree_level_feat                      (utils/config.py:78)  */
@@ -105,6 +120,7 @@ typedef struct shine_step_config {
                               (decoder grads, trash-row grads, loss terms) in the workspace: shine_finish_iteration consumes
                               them in the optimiser's launch.  loss_parts is then written by that call, and adam_state /
                               zero_f64 are served by the fused kernel itself. */
+  const shine_reg_rider* reg_rider; /* host pointer or NULL: shine_forward also evaluates the regulariser (see shine_reg_rider) */
 } shine_step_config;
 
 /* ---- library ------------------------------------------------------------------------- */

@@ -23,6 +23,13 @@ class NextDraw(C.Structure):  # include/shine_hip.h shine_next_draw
                 ("idx_out", C.c_void_p), ("surf_bits", C.c_void_p), ("surf_parts", C.c_void_p), ("workspace", C.c_void_p)]
 
 
+class RegRider(C.Structure):
+    """struct shine_reg_rider (include/shine_hip.h)."""
+
+    _fields_ = [("last", C.c_void_p * 8), ("imp", C.c_void_p * 8), ("stamp", C.c_void_p * 8), ("epoch", C.c_uint32),
+                ("acc", C.c_void_p)]
+
+
 class StepConfig(C.Structure):
     """struct shine_step_config (include/shine_hip.h)."""
 
@@ -49,6 +56,7 @@ class StepConfig(C.Structure):
         ("n_surf_parts", C.c_int32),
         ("next_draw", C.POINTER(NextDraw)),
         ("defer_reduce", C.c_int32),
+        ("reg_rider", C.POINTER(RegRider)),
     ]
 
 

@@ -28,6 +28,12 @@ struct FwdArgs {
   long long n;
   int n_levels;
   float sigma;
+  // cfg->reg_rider (include/shine_hip.h shine_reg_rider): cal_regularization's value on the rows this batch addresses
+  const float* reg_last[SHINE_MAX_LEVELS];
+  const float* reg_imp[SHINE_MAX_LEVELS];
+  unsigned int* reg_stamp[SHINE_MAX_LEVELS];
+  float* reg_acc;  // null: off
+  unsigned int reg_epoch;
 };
 
 template <int LMAX, bool POLY, bool GRADX>
@@ -45,6 +51,8 @@ __global__ __launch_bounds__(256) void k_forward_points(FwdArgs a) {
   }
   const int rows = opaque(H);
   const long long stride = (long long)gridDim.x * 256;
+  float reg_sum = 0.f;  // (rider) this thread's share of the regulariser
+  if (a.reg_acc && blockIdx.x == 0 && threadIdx.x == 0) a.reg_acc[(a.reg_epoch + 1u) & 7u] = 0.f;  // the NEXT launch's accumulator
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < a.n; p += stride) {
     const float x0 = a.coord[3 * p], x1 = a.coord[3 * p + 1], x2 = a.coord[3 * p + 2];
     int slot[LMAX];
@@ -114,6 +122,28 @@ __global__ __launch_bounds__(256) void k_forward_points(FwdArgs a) {
       o[0] = make_float4(f[0], f[1], f[2], f[3]);
       o[1] = make_float4(f[4], f[5], f[6], f[7]);
     }
+    if (a.reg_acc) {  // (wave-uniform) the regulariser rides: every addressed row counts once per launch — whoever swaps its stamp
+      // to this launch's epoch first adds the row's term (unique(hierarchical_indices) without -1, feature_octree.py:250-254)
+      for (int s = 0; s < L; ++s) {
+        if (slot[s] < 0) continue;
+        const LevelDev& Lv = a.ls.lv[s];
+        const int4 i0 = Lv.vals[2u * (unsigned int)slot[s]], i1 = Lv.vals[2u * (unsigned int)slot[s] + 1u];
+        const int ids[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+        for (int c = 0; c < 8; ++c) {
+          const unsigned int row = (unsigned int)ids[c];
+          if (atomicExch(a.reg_stamp[s] + row, a.reg_epoch) == a.reg_epoch) continue;
+          const float4* fr = reinterpret_cast<const float4*>(Lv.feat + row * (unsigned int)F);
+          const float4* lr = reinterpret_cast<const float4*>(a.reg_last[s] + row * (unsigned int)F);
+          const float4* ir = reinterpret_cast<const float4*>(a.reg_imp[s] + row * (unsigned int)F);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float4 fv = fr[h], lv = lr[h], iv = ir[h];
+            const float d0 = fv.x - lv.x, d1 = fv.y - lv.y, d2 = fv.z - lv.z, d3 = fv.w - lv.w;
+            reg_sum += (iv.x * (d0 * d0) + iv.y * (d1 * d1)) + (iv.z * (d2 * d2) + iv.w * (d3 * d3));
+          }
+        }
+      }
+    }
     if (!with_mlp) continue;
     float h1[H];
     {
@@ -167,6 +197,10 @@ __global__ __launch_bounds__(256) void k_forward_points(FwdArgs a) {
       a.grad_x[3 * p + 1] = a.sigma * g1;
       a.grad_x[3 * p + 2] = a.sigma * g2;
     }
+  }
+  if (a.reg_acc) {  // (every thread is here: the grid-stride loop has ended for all of them)
+    const float r = wave_sum(reg_sum);
+    if ((threadIdx.x & 63) == 0 && r != 0.f) atomicAdd(a.reg_acc + (a.reg_epoch & 7u), r);
   }
 }
 
@@ -288,6 +322,18 @@ extern "C" int shine_forward(const shine_tables* t, const shine_step_config* cfg
   a.grad_x = grad_x_out;
   if (idx_out)
     for (int i = 0; i < cfg->n_levels; ++i) a.idx_out[i] = (long long*)idx_out[i];
+  if (const shine_reg_rider* rr = cfg->reg_rider) {
+    if (!rr->acc || rr->epoch == 0) return set_error(SHINE_E_INVALID, "shine_forward: reg_rider needs acc and an epoch > 0");
+    for (int s = 0; s < cfg->n_levels; ++s) {
+      if (!rr->last[s] || !rr->imp[s] || !rr->stamp[s] || ((size_t)rr->last[s] & 15) || ((size_t)rr->imp[s] & 15))
+        return set_error(SHINE_E_INVALID, "shine_forward: reg_rider needs 16-byte aligned last / imp tables and a stamp array per level");
+      a.reg_last[s] = rr->last[s];
+      a.reg_imp[s] = rr->imp[s];
+      a.reg_stamp[s] = rr->stamp[s];
+    }
+    a.reg_acc = rr->acc;
+    a.reg_epoch = rr->epoch;
+  }
   const bool poly = cfg->poly_int_on != 0;
   if (cfg->n_levels <= 4) launch_forward<4>(a, poly, (hipStream_t)stream);
   else launch_forward<SHINE_MAX_LEVELS>(a, poly, (hipStream_t)stream);

@@ -69,6 +69,14 @@ struct PyKeep {
   }
 };
 
+// cal_regularization's value riding on query_feature's launch (include/shine_hip.h shine_reg_rider): the tensors the rider reads,
+// set once per frame by the Python side (FeatureOctree._reg_rider), and the launch counter that stamps the rows
+struct RegRiderState {
+  std::vector<Tensor> last, imp, stamp;  // per level: features_last_frame, importance_weight (float32 contiguous), uint32 stamps
+  Tensor acc;                            // float32[8]
+  uint32_t epoch = 0;
+};
+
 // What a FeatureOctree's launches need, refreshed by the Python side whenever the tables or the configuration change
 // (FeatureOctree._ext_state): the table handle, the scalar configuration, the row counts.  Every autograd node takes a SNAPSHOT
 // (snapshot()): the handle / rows / configuration of ITS forward, a strong reference to the octree and its table object (the
@@ -86,6 +94,7 @@ struct TierAState {
   std::shared_ptr<PyKeep> weak;                      // (weakref(octree), weakref(its _DeviceTables)): the live state is held by
                                                      // the octree itself and must not keep it alive
   std::shared_ptr<PyKeep> keep;                      // snapshots only: (octree, tables), strong
+  std::shared_ptr<RegRiderState> reg;                // null: query_feature does not evaluate the regulariser
   int L() const { return cfg.n_levels; }
   void set(uintptr_t handle, const std::string& cfg_bytes, std::vector<int64_t> r, int64_t id, bool async_, int64_t epoch_,
            py::object owner) {
@@ -385,13 +394,16 @@ std::shared_ptr<N> make_node(const variable_list& inputs) {
 // ---------------------------------------------------------------------------------------------------------------- calls
 
 // -> (feat [n, 8], pred [n] or None).  mlp: empty, or the six tensors of the decoder whose output rides on the launch.
-std::pair<Tensor, c10::optional<Tensor>> query_feature(const std::shared_ptr<TierAState>& st, const Tensor& coord,
-                                                       const std::vector<Tensor>& feats, const std::vector<Tensor>& mlp) {
+// reg (third result): with st->reg set, the regulariser of THIS query as a 0-dim view of the rider's accumulator ring — valid until
+// seven more queries of the octree have run (FeatureOctree.cal_regularization clones it)
+std::tuple<Tensor, c10::optional<Tensor>, c10::optional<Tensor>> query_feature(const std::shared_ptr<TierAState>& st,
+                                                                              const Tensor& coord, const std::vector<Tensor>& feats,
+                                                                              const std::vector<Tensor>& mlp) {
   const int L = st->L();
   TORCH_CHECK((int)feats.size() == L, "query_feature: one table per featured level");
   TORCH_CHECK(coord.is_cuda() && coord.scalar_type() == at::kFloat && coord.dim() == 2 && coord.size(1) == 3,
               "coord must be a CUDA float32 tensor of shape [N,3]");
-  Tensor feat, pred;
+  Tensor feat, pred, reg;
   {
     at::AutoDispatchBelowADInplaceOrView guard;
     Tensor c = coord.detach().contiguous();
@@ -403,8 +415,23 @@ std::pair<Tensor, c10::optional<Tensor>> query_feature(const std::shared_ptr<Tie
     for (auto& m : mlp) Mc.push_back(f32c(m.detach()));
     if (!Mc.empty()) pred = at::empty({n}, c.options());
     auto fp = ptrs(Fc), mp = ptrs(Mc);
+    shine_step_config cfg = st->cfg;
+    shine_reg_rider rider;
+    if (st->reg && n > 0) {
+      RegRiderState& rs = *st->reg;
+      std::memset(&rider, 0, sizeof(rider));
+      for (int s = 0; s < L; ++s) {
+        rider.last[s] = rs.last[s].data_ptr<float>();
+        rider.imp[s] = rs.imp[s].data_ptr<float>();
+        rider.stamp[s] = reinterpret_cast<uint32_t*>(rs.stamp[s].data_ptr<int32_t>());
+      }
+      rider.acc = rs.acc.data_ptr<float>();
+      rider.epoch = ++rs.epoch;
+      cfg.reg_rider = &rider;
+      reg = rs.acc.select(0, (int64_t)(rider.epoch & 7u));
+    }
     if (n > 0)
-      check(shine_forward(reinterpret_cast<const shine_tables*>(st->tables), &st->cfg, c.data_ptr<float>(), n, fp.data(),
+      check(shine_forward(reinterpret_cast<const shine_tables*>(st->tables), &cfg, c.data_ptr<float>(), n, fp.data(),
                           st->rows.data(), Mc.empty() ? nullptr : mp.data(), feat.data_ptr<float>(),
                           pred.defined() ? pred.data_ptr<float>() : nullptr, nullptr, nullptr, stream),
             "shine_forward");
@@ -420,7 +447,7 @@ std::pair<Tensor, c10::optional<Tensor>> query_feature(const std::shared_ptr<Tie
     node->need_coord = coord.requires_grad();
     torch::autograd::create_gradient_edge(feat, node);
   }
-  return {feat, pred.defined() ? c10::optional<Tensor>(pred) : c10::nullopt};
+  return {feat, pred.defined() ? c10::optional<Tensor>(pred) : c10::nullopt, reg.defined() ? c10::optional<Tensor>(reg) : c10::nullopt};
 }
 
 // pred = Decoder.sdf(feature) for the untouched feature of query_feature(coord) -> (pred, link)
@@ -609,6 +636,28 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       })
       .def("set_epoch", [](TierAState& s, int64_t epoch) {  // FeatureOctree._tables_epoch's setter
         if (s.epoch_now) s.epoch_now->store(epoch);
+      })
+      // cal_regularization's value rides on query_feature (RegRiderState); empty lists switch it off
+      .def("set_reg", [](TierAState& s, std::vector<Tensor> last, std::vector<Tensor> imp, std::vector<Tensor> stamp, Tensor acc) {
+        if (last.empty()) {
+          s.reg.reset();
+          return;
+        }
+        const size_t L = (size_t)s.L();
+        TORCH_CHECK(last.size() == L && imp.size() == L && stamp.size() == L, "set_reg: one tensor per featured level");
+        TORCH_CHECK(acc.is_cuda() && acc.scalar_type() == at::kFloat && acc.numel() == 8, "set_reg: acc is a CUDA float32[8]");
+        for (size_t k = 0; k < L; ++k) {
+          TORCH_CHECK(last[k].is_cuda() && last[k].scalar_type() == at::kFloat && last[k].is_contiguous() &&
+                      imp[k].is_cuda() && imp[k].scalar_type() == at::kFloat && imp[k].is_contiguous() &&
+                      last[k].size(0) == s.rows[k] + 1 && imp[k].size(0) == s.rows[k] + 1,
+                      "set_reg: features_last_frame / importance_weight as contiguous CUDA float32 [rows + 1, 8]");
+          TORCH_CHECK(stamp[k].is_cuda() && stamp[k].scalar_type() == at::kInt && stamp[k].numel() >= s.rows[k] + 1,
+                      "set_reg: one int32 stamp per row");
+        }
+        auto keep_epoch = s.reg ? s.reg->epoch : 0u;  // (stamps may be re-used: the epoch never goes back)
+        s.reg = std::make_shared<RegRiderState>();
+        s.reg->last = std::move(last), s.reg->imp = std::move(imp), s.reg->stamp = std::move(stamp), s.reg->acc = std::move(acc);
+        s.reg->epoch = keep_epoch;
       });
   py::class_<Link, std::shared_ptr<Link>>(m, "Link").def("pending", [](Link& l) { return l.q.defined(); });
   m.def("set_callbacks", [](py::object interp_backward, py::object fused_split, py::object read_done) {

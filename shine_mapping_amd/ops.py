@@ -296,9 +296,12 @@ def _ext_query(ext, octree, coord):
     mlp = dec.fused_params() if (dec is not None and dec.fusable) else []
     if mlp and not dec._params_on(coord.device, mlp):
         mlp = []
-    feat, pred = ext.query_feature(octree._ext_state(ext), coord, octree.feature_list(), mlp)
+    st = octree._ext_state(ext)
+    octree._reg_rider(st)  # (incremental mapping: cal_regularization's value rides on this launch — set up once per frame)
+    feat, pred, reg = ext.query_feature(st, coord, octree.feature_list(), mlp)
     octree.__dict__["_spec_result"] = (pred, dec, mlp, autograd_ops.param_epoch(), [p._version for p in mlp]) if mlp else None
     octree._defer_indices(coord)
+    octree.__dict__["_reg_riding"] = reg  # None, or this query's regulariser (a view of the rider's ring: clone to keep)
     return feat
 
 

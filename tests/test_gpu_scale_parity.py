@@ -1683,3 +1683,81 @@ def test_cpp_nodes_hold_their_octree_and_refuse_tables_that_changed():
     pred.sum().backward()
     torch.cuda.synchronize()
     assert all(p.grad is not None for p in octree.hier_features)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["maicity_bce_L3", "maicity_bce_L4", "kitti_eik_L3", "ncd_reg_L3"])
+def test_b3_gradient_against_the_exact_sum_at_the_scale_of_its_summands(name):
+    """decoder_grad_errs scales the ONE-element b3 gradient by the output layer's joint max-abs, because the sum
+    d loss / d b3 = sum_p delta_p cancels to ~1e-2 of its summands.  The strict check beside that one: against the EXACT sum (the
+    oracle in wide-accumulation mode) with an absolute tolerance derived from the summands, |err| <= 2e-5 x sum_p |delta_p| —
+    what fp32 accumulation in any order can move it by, three orders below a wrong delta or a dropped tile — and the same for
+    every other decoder tensor's entries against that tensor's own summand scale is implied by their 1e-4-of-max-abs checks."""
+    from oracle import shine_oracle as so
+    from shine_mapping_amd import fused_train_step
+
+    fx = load_golden(name)
+    cfg, octree, dec = product_from_golden(fx)
+    fused_train_step(octree, dec, fx["coord"].cuda(), fx["sdf_label"].cuda(), fx["weight"].cuda(), step_options(fx))
+    torch.cuda.synchronize()
+    ocfg, oct_, mlp = oracle_from_golden(fx)
+    so.to_wide(oct_, mlp)
+    wide = so.train_step(oct_, mlp, fx["coord"], fx["sdf_label"], fx["weight"], ocfg, regularize=False)
+    n = fx["coord"].shape[0]
+    inv_n = 1.0 if fx["cfg"].get("loss_reduction", "mean") == "sum" else 1.0 / n
+    delta = (torch.sigmoid(wide["pred"].double()) - torch.sigmoid(fx["sdf_label"].double() / fx["sigma"])) * inv_n
+    exact = float(wide["mlp_grads"][5].double().sum())
+    assert abs(float(delta.sum()) - exact) <= 1e-9 * float(delta.abs().sum())  # (the eikonal term sends nothing to a bias)
+    got = float(dec.fused_params()[5].grad.double().sum())
+    scale = float(delta.abs().sum())
+    print("b3 gradient %s: exact %.6e, HIP %.6e, |err| / sum|delta| = %.2e (cancellation: |sum| / sum|.| = %.2e)" % (
+        name, exact, got, abs(got - exact) / scale, abs(exact) / scale))
+    assert abs(got - exact) <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+def test_regulariser_riding_on_the_query_equals_its_own_launches(monkeypatch):
+    """Config 4 from its second frame on (features_last_frame an attached clone, model/feature_octree.py:160): the value of
+    cal_regularization() rides on query_feature's launch (csrc/shine_forward.hip, cfg->reg_rider: every addressed row claimed once
+    per launch through its stamp).  Over a dozen different queries in a row — the accumulator ring wraps, the stamps are re-used
+    with a growing epoch — every value must equal what the regulariser's own launches give for the same query (rider switched
+    off) and the reference's composite (unique + gathers, :246-255); a value taken from an earlier query stays what it was."""
+    from shine_mapping_amd import _ext, feature_octree
+
+    if _ext.module() is None:
+        pytest.skip("lib/_shine_ext.so not built")
+    fx = load_golden("ncd_reg_L3")
+    base = fx["coord"].cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+
+    def make():
+        cfg, octree, dec = product_from_golden(fx)
+        vals = [v.detach().clone() for v in octree.features_last_frame]
+        octree.features_last_frame = [p.clone() for p in octree.hier_features]  # attached clones
+        with torch.no_grad():
+            for t, v in zip(octree.features_last_frame, vals):
+                t.copy_(v)
+        return octree
+
+    queries = [base[torch.randint(0, base.shape[0], (int(n),), device="cuda", generator=g)] for n in
+               (4096, 17, 1, 300, 4096, 2048, 4096, 999, 4096, 4096, 64, 4096)]
+    monkeypatch.setattr(feature_octree, "RIDER_ENABLED", True)
+    octree = make()
+    riding, kept = [], []
+    for q in queries:
+        octree.query_feature(q)
+        assert octree.__dict__.get("_reg_riding") is not None  # it rode
+        r = octree.cal_regularization()
+        assert r.grad_fn is None and not r.requires_grad
+        kept.append(r)
+        riding.append(float(r))
+    assert [float(r) for r in kept] == riding  # (clones: later queries did not overwrite them)
+    monkeypatch.setattr(feature_octree, "RIDER_ENABLED", False)
+    octree2 = make()
+    for q, v in zip(queries, riding):
+        octree2.query_feature(q)
+        assert octree2.__dict__.get("_reg_riding") is None
+        own = float(octree2.cal_regularization())
+        octree2.hierarchical_indices  # (materialised: the composite reads them)
+        comp = float(octree2._cal_regularization_composite())
+        assert abs(v - own) <= 1e-5 * max(abs(own), 1e-30) and abs(v - comp) <= 1e-5 * max(abs(comp), 1e-30), (v, own, comp)
