@@ -279,6 +279,11 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default invocation: skip the abbreviated kitti / ncd-incre legs")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--draw-rider", default="auto", choices=["auto", "on", "off"],
+                    help="one rank: the step's reduction launch also draws the next batch and clears the next step's bucket (a step = "
+                         "two launches, two alternating gradient buckets) instead of a stand-alone draw launch in front of every "
+                         "step.  auto: for batches of <= 2^18 points, where the draw is launch-bound (measured: -4 %% step time at "
+                         "2^18, +1-3 %% at 2^20)")
     ap.add_argument("--preheat-ms", type=float, default=40.0,
                     help="untimed replays of the step before the warm-up steps, so that short runs see ramped-up clocks")
     ap.add_argument("--graph-steps", type=int, default=0,

@@ -60,6 +60,36 @@ typedef struct shine_next_draw {
                               shine_step_config.next_draw only */
 } shine_next_draw;
 
+/* The WHOLE next large sorted draw — and the next step's opt.zero_grad() — on the reduction launch of THIS step
+ * (shine_step_config.draw_rider): a batch-mode step is then two launches, the fused kernel and this one.  The sampler's two
+ * passes have a grid-wide dependency (pass 2 needs every block sum of pass 1), so they ride one step apart: step i's launch runs
+ * pass 2 of draw i + 1 (whose block sums step i - 1's launch left) and pass 1 of draw i + 2.  Everything a step hands to the next
+ * is kept twice and addressed by the step's PARITY (steps alternate 0, 1, 0, ...):
+ *   state        device uint64[2]: state[parity] = stream id of the draw THIS step used; the launch stores that + 1 into
+ *                state[1 - parity] (nothing in the launch reads it)
+ *   block_sum    two device double[(n + 1 + 1023) / 1024]: [1 - parity] holds pass 1 of the next draw, [parity] receives pass 1 of the
+ *                draw after it
+ *   surf_parts   (with surf_bits) two device int64[SHINE_SURF_PARTS]: [parity] — this step's count, consumed by its fused
+ *                kernel — is cleared, [1 - parity] receives the next draw's
+ *   zero_ptr     the NEXT step's gradient bucket (two buckets alternate: this step's own holds its results), cleared here; or NULL
+ * idx_out [n]: the next step's sorted sample indices (the fused kernel of this step has read its own by now).
+ * The draws are bit-identical to shine_sample_sorted with the same seed / stream ids.  shine_draw_rider_prime sets the chain up:
+ * draw 0 (stream id first_stream_id) into idx_out / surf_parts[0], pass 1 of draw 1 into block_sum[1], state[0], surf_parts[1] = 0;
+ * the first step then has parity 0. */
+typedef struct shine_draw_rider {
+  int64_t pool_size, n;
+  uint64_t seed;
+  uint64_t* state;
+  int32_t parity;
+  double* block_sum[2];
+  int32_t* idx_out;
+  const uint32_t* surf_bits;
+  int64_t* surf_parts[2];
+  float* zero_ptr;
+  int64_t zero_bytes;
+} shine_draw_rider;
+int shine_draw_rider_prime(const shine_draw_rider* r, uint64_t first_stream_id, void* stream);
+
 /* FeatureOctree.cal_regularization (model/feature_octree.py:246-255) riding on the query's launch (shine_forward, cfg->reg_rider):
  * every row the batch addresses — unique(hierarchical_indices) without -1 — adds sum_f importance[row][f] * (F[row][f] -
  * F_last[row][f])^2 ONCE per launch (a row is claimed by an atomic exchange of its stamp with the launch's epoch).  The VALUE only
@@ -121,6 +151,8 @@ typedef struct shine_step_config {
                               them in the optimiser's launch.  loss_parts is then written by that call, and adam_state /
                               zero_f64 are served by the fused kernel itself. */
   const shine_reg_rider* reg_rider; /* host pointer or NULL: shine_forward also evaluates the regulariser (see shine_reg_rider) */
+  const shine_draw_rider* draw_rider; /* host pointer or NULL: shine_train_step's reduction launch draws the next batch and clears
+                              the next step's gradient bucket (see shine_draw_rider).  Not with next_draw / defer_reduce. */
 } shine_step_config;
 
 /* ---- library ------------------------------------------------------------------------- */

@@ -30,6 +30,14 @@ class RegRider(C.Structure):
                 ("acc", C.c_void_p)]
 
 
+class DrawRider(C.Structure):
+    """struct shine_draw_rider (include/shine_hip.h)."""
+
+    _fields_ = [("pool_size", C.c_int64), ("n", C.c_int64), ("seed", C.c_uint64), ("state", C.c_void_p), ("parity", C.c_int32),
+                ("block_sum", C.c_void_p * 2), ("idx_out", C.c_void_p), ("surf_bits", C.c_void_p), ("surf_parts", C.c_void_p * 2),
+                ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_int64)]
+
+
 class StepConfig(C.Structure):
     """struct shine_step_config (include/shine_hip.h)."""
 
@@ -57,6 +65,7 @@ class StepConfig(C.Structure):
         ("next_draw", C.POINTER(NextDraw)),
         ("defer_reduce", C.c_int32),
         ("reg_rider", C.POINTER(RegRider)),
+        ("draw_rider", C.POINTER(DrawRider)),
     ]
 
 
@@ -64,6 +73,7 @@ _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
     "shine_version": (C.c_int, []),
+    "shine_draw_rider_prime": (C.c_int, [C.POINTER(DrawRider), C.c_uint64, _P]),
     "shine_error_string": (C.c_char_p, [C.c_int]),
     "shine_tables_create": (C.c_int, [C.c_int32, C.POINTER(_P)]),
     "shine_tables_destroy": (C.c_int, [_P]),

@@ -757,6 +757,93 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, cpu_baselin
 
         return dict(run=run, launch=launch, reducer=reducer, kind=kind, micro=m, keep=(graph_u, graph_1, flags))
 
+    def build_chain_runner():
+        """One rank, batches of >= 16 K points (round 6): a step is TWO launches.  The step's reduction launch also draws the NEXT
+        batch (pass 2 of draw i + 1, pass 1 of draw i + 2) and clears the NEXT step's gradient bucket (sampler.DrawChain,
+        cfg->draw_rider) — the stand-alone draw launch of rounds 3-5 (7 us + a launch gap of an 86 us step) is gone.  Two gradient
+        buckets alternate: step k accumulates into bucket k & 1, which stays intact — the step's result — until step k + 1's launch
+        clears it.  A captured graph bakes each step's parity in; `run` replays the graph of U steps only where the host's parity
+        says the device is at 0 and single-step graphs (one per parity) otherwise."""
+        import copy
+
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        reducer = shine_dp.TouchedRowReducer(feats, dec_params, None)
+        flat = (reducer.flat, torch.zeros_like(reducer.flat))
+        nf = len(feats)
+
+        def views_of(fl):
+            out, off = [], 0
+            for p in params:
+                out.append(fl[off: off + p.numel()].view_as(p))
+                off += p.numel()
+            return out[:nf], out[nf:]
+
+        views = (([p.grad for p in feats], [p.grad for p in dec_params]), views_of(flat[1]))
+        eik = bool(opts.ekional_loss_on)
+        chain = spool.draw_chain(points, idx_buf, buckets=flat, surf=eik)
+        chain_opts = []
+        for par in (0, 1):
+            o = copy.copy(opts)
+            o.draw_rider = chain.rider[par]
+            chain_opts.append(o)
+        chain.prime()
+
+        def step_body(par):
+            return fused_train_step(octree, decoder, None, None, None, chain_opts[par], n_surf=chain.surf_parts[par] if eik else None,
+                                    pool=spool, idx=idx_buf, grad_buffers=views[par])[0]
+
+        def eager(k):
+            out = None
+            for _ in range(k):
+                out = step_body(chain.parity)
+                chain.parity ^= 1
+            return out
+
+        launch, g1, gu, loss1, lossu = "eager", [None, None], None, [None, None], None
+        if not args.no_graph:
+            try:
+                eager(4)  # warm caches / allocate workspaces outside capture (an even number: parity back at 0)
+                barrier()
+                for par in (0, 1):
+                    g1[par] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1[par]):
+                        loss1[par] = step_body(par)
+                if U > 1:
+                    gu = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gu):
+                        for j in range(U):
+                            lossu = step_body(j & 1)
+                launch = ("hipgraph, %d step%s per replay, fresh batch per step; a step = 2 launches: the fused kernel and its "
+                          "reduction, which also draws the next batch and clears the next step's bucket (two buckets alternate)" % (
+                              U, "s" if U > 1 else ""))
+            except Exception as e:
+                print("graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
+                g1, gu, launch = [None, None], None, "eager"
+                torch.cuda.synchronize()
+
+        def run(k):
+            """exactly k steps -> the last step's loss (also kept as run.last_loss)"""
+            out = None
+            if g1[0] is None:
+                out = eager(k)
+            else:
+                while k > 0:
+                    if gu is not None and k >= U and chain.parity == 0:
+                        gu.replay()
+                        out, k = lossu, k - U
+                        chain.parity ^= U & 1
+                    else:
+                        g1[chain.parity].replay()
+                        out, k = loss1[chain.parity], k - 1
+                        chain.parity ^= 1
+            if out is not None:
+                run.last_loss = out
+            return out
+
+        run.last_loss = None
+        return dict(run=run, launch=launch, reducer=reducer, kind="dense", micro=1, keep=(gu, g1, chain, flat, views))
+
     exchange, micro, exchange_note, tuned = args.exchange, 1, None, None
     want_m = max(1, int(args.micro_batches))
     if not use_dist:
@@ -790,7 +877,13 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, cpu_baselin
         exchange, micro = ("gather", want_m if "x" in best else 1) if best.startswith("gather") else ("dense", 1)
     elif use_dist and exchange == "gather":
         micro = want_m
-    runner = build_runner(exchange, micro)
+    # auto: while the draw is launch-bound.  Same box, rocprofv3 (profiles/r06_timeline_two_launch_step.txt): 2^18 draws —
+    # reduction 5.2 + draw 6.9 us + a gap -> one launch of 8.8 us (step 86.8 -> 83.1 us); 2^20 draws — 5.3 + 24.0 -> 30.2 us and the
+    # fused kernel 3 us slower on its two alternating 42 MB buckets (step 265.5 -> 269.8 us): the rider's sampler blocks are quarters
+    # of the reduction kernel's 1024-thread blocks (16 waves at every barrier of the scan) and the draw is work-bound there.
+    want_rider = {"on": True, "off": False}.get(args.draw_rider, points <= (1 << 18))
+    chain_mode = not use_dist and points + 1 > 16 * 1024 and want_rider
+    runner = build_chain_runner() if chain_mode else build_runner(exchange, micro)
     if runner is None:  # an explicitly requested gather exchange that does not reproduce the dense all-reduce here
         exchange_note = "gather exchange (%d micro-batches) failed its check against the dense all-reduce: dense used" % micro
         exchange, micro = "dense", 1

@@ -227,3 +227,35 @@ extern "C" int shine_sample_sorted_finish(int64_t pool_size, int64_t n, int64_t 
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }
+
+// shine_draw_rider (include/shine_hip.h): set the chain of riding draws up — draw 0 with stream id `first_stream_id` into idx_out /
+// surf_parts[0], pass 1 of draw 1 into block_sum[1], state[0] = first_stream_id, surf_parts[1] = 0.  The first step has parity 0.
+namespace shine {
+__global__ void k_set_u64(unsigned long long* p, unsigned long long v) { *p = v; }
+}  // namespace shine
+
+extern "C" int shine_draw_rider_prime(const shine_draw_rider* r, uint64_t first_stream_id, void* stream) {
+  if (!r) return set_error(SHINE_E_INVALID, "shine_draw_rider_prime: null argument");
+  const long long n1 = (long long)r->n + 1, nblocks = (n1 + SB - 1) / SB;
+  if (r->n < 1 || r->pool_size < 1 || r->pool_size > 0x7fffffffll || !r->state || !r->idx_out || !r->block_sum[0] ||
+      !r->block_sum[1] || (r->surf_bits && (!r->surf_parts[0] || !r->surf_parts[1])))
+    return set_error(SHINE_E_INVALID, "shine_draw_rider_prime: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  long long* parts0 = r->surf_bits ? reinterpret_cast<long long*>(r->surf_parts[0]) : nullptr;
+  // draw 0: the stand-alone two-launch form (pass 1 clears surf_parts[0], pass 2 adds to it), block sums through block_sum[0]
+  hipLaunchKernelGGL(k_sample_pass1, dim3((unsigned)nblocks), dim3(256), 0, st, r->block_sum[0], n1, (unsigned long long)r->seed,
+                     (unsigned long long)first_stream_id, (const unsigned long long*)nullptr, (float4*)nullptr, 0ll, parts0);
+  hipLaunchKernelGGL(k_sample_pass2<false>, dim3((unsigned)(((long long)r->n - 1) / SB + 1)), dim3(256), 0, st,
+                     (const double*)r->block_sum[0], (int)nblocks, (long long)r->n, (long long)r->pool_size,
+                     (unsigned long long)r->seed, (unsigned long long)first_stream_id, (unsigned long long*)nullptr, (int*)r->idx_out, 0, 0ll,
+                     (long long)r->n, (const unsigned int*)r->surf_bits, parts0, (float4*)nullptr, 0ll);
+  // pass 1 of draw 1
+  hipLaunchKernelGGL(k_sample_pass1, dim3((unsigned)nblocks), dim3(256), 0, st, r->block_sum[1], n1, (unsigned long long)r->seed,
+                     (unsigned long long)first_stream_id + 1ull, (const unsigned long long*)nullptr, (float4*)nullptr, 0ll,
+                     (long long*)nullptr);
+  hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(r->state),
+                     (unsigned long long)first_stream_id);
+  if (r->surf_bits) SHINE_HIP_CHECK(hipMemsetAsync(r->surf_parts[1], 0, (size_t)SURF_PARTS * 8, st));
+  SHINE_HIP_CHECK(hipGetLastError());
+  return SHINE_OK;
+}

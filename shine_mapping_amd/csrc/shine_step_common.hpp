@@ -163,8 +163,25 @@ struct Pass1Args {
   long long* surf_parts;         // cleared here (pass 2 adds to them) or null
   int nblocks;                   // sampler blocks of 1024 draws
 };
-__global__ void k_reduce_partials(V1Args a, int nblocks, Pass1Args p1);
+// cfg->draw_rider (include/shine_hip.h shine_draw_rider): the whole next draw and the next step's zero-fill as extra blocks
+struct DrawRiderArgs {
+  const double* bs_next;   // pass 1 of the next draw (left by the previous step's launch)
+  double* bs_after;        // receives pass 1 of the draw after it
+  unsigned long long* state;
+  int parity;
+  int nblocks;             // sampler blocks of one draw; 0: off
+  long long n, pool;
+  unsigned long long seed;
+  int* idx;
+  const unsigned int* surf_bits;
+  long long* parts_this;   // cleared (this step's fused kernel has consumed it)
+  long long* parts_next;   // receives the next draw's surface counts
+  float4* zero_ptr;
+  long long zero_n16;
+};
+__global__ void k_reduce_partials(V1Args a, int nblocks, Pass1Args p1, DrawRiderArgs dr);
 int fill_pass1_args(Pass1Args* p1, const shine_step_config* cfg);  // shine_step_support.hip
+int fill_draw_rider_args(DrawRiderArgs* dr, const shine_step_config* cfg);
 __global__ void k_mark_touched(V1Args a);
 int launch_operand_image(const V1Args& a, float* image, hipStream_t st);  // shine_step_support.hip (image: V3_IMAGE_FLOATS floats)
 

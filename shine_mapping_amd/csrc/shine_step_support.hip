@@ -60,10 +60,103 @@ __global__ __launch_bounds__(256) void k_mark_touched(V1Args a) {
 
 // second stage: add the per-workgroup partial vectors into the gradient tensors / loss.
 // One 1024-thread block per 64 entries: lane = entry (coalesced 256-B rows), the 16 waves split the blocks.
-__global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks, Pass1Args p1) {
+// cfg->draw_rider: one 1024-thread block = four sampler blocks of 256 threads (quarter q = threadIdx.x >> 8).  The first
+// ceil(nblocks / 4) rider blocks run pass 1 of the draw after next, the others pass 2 of the next draw — k_sample_pass1 /
+// k_sample_pass2's arithmetic and summation order (shine_sampler.hip), so the draws are bit-identical to the stand-alone
+// sampler's; every rider thread also takes its share of the zero-fill.  `rb`: index among the rider blocks.
+__device__ __forceinline__ void draw_rider_block(const DrawRiderArgs& dr, int rb) {
+  __shared__ double s_red[4][4];
+  __shared__ double s_wave_pre[4][4];
+  __shared__ int s_cnt[4][4];
+  const int qb = (dr.nblocks + 3) / 4;
+  const int q = threadIdx.x >> 8, t256 = threadIdx.x & 255, w = t256 >> 6, lane = threadIdx.x & 63;
+  const unsigned long long sid = dr.state[dr.parity];  // stream id of the draw THIS step used
+  for (long long z = (long long)rb * 1024 + threadIdx.x; z < dr.zero_n16; z += (long long)2 * qb * 1024)
+    dr.zero_ptr[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rb < qb) {  // ---- pass 1 of draw sid + 2
+    const unsigned long long stream = sid + 2ull;
+    const int vb = rb * 4 + q;
+    if (rb == 0 && threadIdx.x == 0) dr.state[1 - dr.parity] = sid + 1ull;
+    if (rb == 0 && dr.parts_this && threadIdx.x < SURF_PARTS) dr.parts_this[threadIdx.x] = 0;
+    const long long k0 = (long long)vb * SB + t256 * 4;
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (vb < dr.nblocks && k0 + j < dr.n + 1) v += exp1v(dr.seed, stream, (unsigned long long)(k0 + j));
+    v = wave_sum_d(v);
+    if (lane == 0) s_red[q][w] = v;
+    __syncthreads();
+    if (t256 == 0 && vb < dr.nblocks) dr.bs_after[vb] = s_red[q][0] + s_red[q][1] + s_red[q][2] + s_red[q][3];
+    return;
+  }
+  // ---- pass 2 of draw sid + 1
+  const unsigned long long stream = sid + 1ull;
+  const int vb = (rb - qb) * 4 + q;
+  const bool on = vb < dr.nblocks;  // (padding quarters of the last block walk through the barriers only)
+  double before = 0.0, total = 0.0;
+  for (int b = t256; b < dr.nblocks; b += 256) {
+    const double v = dr.bs_next[b];
+    total += v;
+    if (b < vb) before += v;
+  }
+  before = wave_sum_d(before);
+  if (lane == 0) s_red[q][w] = before;
+  __syncthreads();
+  before = s_red[q][0] + s_red[q][1] + s_red[q][2] + s_red[q][3];
+  __syncthreads();
+  total = wave_sum_d(total);
+  if (lane == 0) s_red[q][w] = total;
+  __syncthreads();
+  total = s_red[q][0] + s_red[q][1] + s_red[q][2] + s_red[q][3];
+  __syncthreads();
+  const long long k0 = (long long)vb * SB + t256 * 4;
+  double e[4], run = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    e[j] = (on && k0 + j <= dr.n) ? exp1v(dr.seed, stream, (unsigned long long)(k0 + j)) : 0.0;
+    run += e[j];
+  }
+  double inc = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) s_wave_pre[q][w] = inc;
+  __syncthreads();
+  double wpre = 0.0;
+  for (int ww = 0; ww < w; ++ww) wpre += s_wave_pre[q][ww];
+  double sacc = before + wpre + (inc - run);
+  int surf = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sacc += e[j];
+    if (on && k0 + j < dr.n) {
+      long long v = (long long)((sacc / total) * (double)dr.pool);
+      v = v < 0 ? 0 : (v >= dr.pool ? dr.pool - 1 : v);
+      dr.idx[k0 + j] = (int)v;
+      if (dr.parts_next) surf += (int)((dr.surf_bits[v >> 5] >> (v & 31)) & 1u);
+    }
+  }
+  if (dr.parts_next) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) surf += __shfl_xor(surf, o, 64);
+    if (lane == 0) s_cnt[q][w] = surf;
+    __syncthreads();
+    if (t256 == 0 && on)
+      __hip_atomic_fetch_add(dr.parts_next + (vb & (SURF_PARTS - 1)), (long long)(s_cnt[q][0] + s_cnt[q][1] + s_cnt[q][2] + s_cnt[q][3]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_partials(V1Args a, int nblocks, Pass1Args p1, DrawRiderArgs dr) {
   __shared__ float s_red[16][64];
   __shared__ double s_dred[16][3];
   constexpr int RB = (PART_FLOATS + 63) / 64;  // blocks of the reduction proper
+  if ((int)blockIdx.x >= RB && dr.nblocks > 0) {
+    draw_rider_block(dr, (int)blockIdx.x - RB);
+    return;
+  }
   if ((int)blockIdx.x >= RB) {
     // pass 1 of the next sorted draw (k_sample_pass1's arithmetic and summation order: the draw is bit-identical to the
     // stand-alone form): each 256-thread quarter of this block is one sampler block of 1024 draws
@@ -203,6 +296,38 @@ __global__ void k_selftest_mfma16(const float* A, const float* B, float* D) {
 }
 
 long long* g_prof_buffer = nullptr;
+
+// host: cfg->draw_rider -> the whole-draw rider of the reduction launch
+int fill_draw_rider_args(DrawRiderArgs* dr, const shine_step_config* cfg) {
+  *dr = DrawRiderArgs{};
+  const shine_draw_rider* r = cfg->draw_rider;
+  if (!r) return SHINE_OK;
+  if (cfg->next_draw || cfg->defer_reduce)
+    return set_error(SHINE_E_INVALID, "shine_train_step: draw_rider excludes next_draw and defer_reduce");
+  const long long nb = (r->n + 1 + SB - 1) / SB;
+  if (r->n < 1 || nb > 0x3fffff || r->pool_size < 1 || r->pool_size > 0x7fffffffll || !r->state || !r->idx_out ||
+      !r->block_sum[0] || !r->block_sum[1] || (r->parity != 0 && r->parity != 1) ||
+      (r->surf_bits && (!r->surf_parts[0] || !r->surf_parts[1])))
+    return set_error(SHINE_E_INVALID, "shine_train_step: draw_rider wants n >= 1, a device state, both block-sum buffers, idx_out, "
+                                      "parity 0 / 1 and (with surf_bits) both surf_parts");
+  if (r->zero_ptr && (((size_t)r->zero_ptr | (size_t)r->zero_bytes) & 15))
+    return set_error(SHINE_E_INVALID, "shine_train_step: draw_rider's zero buffer must be 16-byte aligned and sized");
+  dr->bs_next = r->block_sum[1 - r->parity];
+  dr->bs_after = r->block_sum[r->parity];
+  dr->state = reinterpret_cast<unsigned long long*>(r->state);
+  dr->parity = r->parity;
+  dr->nblocks = (int)nb;
+  dr->n = r->n;
+  dr->pool = r->pool_size;
+  dr->seed = r->seed;
+  dr->idx = r->idx_out;
+  dr->surf_bits = r->surf_bits;
+  dr->parts_this = r->surf_bits ? reinterpret_cast<long long*>(r->surf_parts[r->parity]) : nullptr;
+  dr->parts_next = r->surf_bits ? reinterpret_cast<long long*>(r->surf_parts[1 - r->parity]) : nullptr;
+  dr->zero_ptr = reinterpret_cast<float4*>(r->zero_ptr);
+  dr->zero_n16 = r->zero_ptr ? r->zero_bytes / 16 : 0;
+  return SHINE_OK;
+}
 
 // host: cfg->next_draw -> the pass-1 rider of the reduction launch
 int fill_pass1_args(Pass1Args* p1, const shine_step_config* cfg) {

@@ -203,8 +203,12 @@ extern "C" int shine_train_step_v3(const shine_tables* t, const shine_step_confi
     Pass1Args p1;  // cfg->next_draw: pass 1 of the next sorted draw as extra blocks of this launch (4 sampler blocks each)
     rc = fill_pass1_args(&p1, cfg);
     if (rc != SHINE_OK) return rc;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((PART_FLOATS + 63) / 64 + (p1.nblocks + 3) / 4)), dim3(1024), 0, st, a,
-                       sl.blocks, p1);
+    DrawRiderArgs dr;  // cfg->draw_rider: the whole next draw + the next step's zero-fill (2 x 4 sampler blocks per extra block)
+    rc = fill_draw_rider_args(&dr, cfg);
+    if (rc != SHINE_OK) return rc;
+    hipLaunchKernelGGL(k_reduce_partials,
+                       dim3((unsigned)((PART_FLOATS + 63) / 64 + (p1.nblocks + 3) / 4 + 2 * ((dr.nblocks + 3) / 4))), dim3(1024), 0,
+                       st, a, sl.blocks, p1, dr);
     SHINE_HIP_CHECK(hipGetLastError());
   }
   return SHINE_OK;
@@ -255,7 +259,8 @@ extern "C" int shine_interp_sdf_backward(const shine_tables* t, const shine_step
   const void* fn = grad_g ? step_fn<true, true, false>(cfg->n_levels, g.wg_waves, false)
                           : step_fn<false, true, false>(cfg->n_levels, g.wg_waves, false);
   SHINE_HIP_CHECK(hipLaunchKernel(fn, dim3((unsigned)g.blocks), dim3((unsigned)(g.wg_waves * 64)), params, 0, st));
-  hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks, Pass1Args{});
+  hipLaunchKernelGGL(k_reduce_partials, dim3((PART_FLOATS + 63) / 64), dim3(1024), 0, st, a, (int)g.blocks, Pass1Args{},
+                     DrawRiderArgs{});
   SHINE_HIP_CHECK(hipGetLastError());
   return SHINE_OK;
 }

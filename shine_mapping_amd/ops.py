@@ -39,6 +39,8 @@ class StepOptions:
     zero_f64: Optional[torch.Tensor] = None     # one float64 element cleared by the step (the regulariser's accumulator)
     next_draw: Optional[object] = None          # SortedPool.next_draw(...): the first pass of the NEXT large sorted draw rides on
                                                 # the step's reduction launch; complete it with pool.draw(..., pass1_done=True)
+    draw_rider: Optional[object] = None         # sampler.DrawChain.rider[parity]: the WHOLE next sorted draw and the next step's
+                                                # zero-fill ride on this step's reduction launch (cfg.draw_rider)
     kernel_variant: int = 0           # 0 the fused step (5 / 6: its far / near build whatever the table size); tests / tools: 1 the
                                       # lane-per-point reference kernel
                                       # (libshine_check.so)
@@ -211,6 +213,10 @@ def _fused_launch(octree, decoder, coord, sdf_label, weight, opts: StepOptions, 
         cfg.zero_f64 = opts.zero_f64.data_ptr()
     if opts.next_draw is not None:
         cfg.next_draw = C.pointer(opts.next_draw)
+    if opts.draw_rider is not None:
+        if pending is not None or graph is not None or opts.next_draw is not None:
+            raise ValueError("draw_rider is a hook of the plain fused step (not with next_draw / the deferred-reduction forms)")
+        cfg.draw_rider = C.pointer(opts.draw_rider)
     if eik and n_surf is None:
         n_surf = (weight > 0).sum()  # stays on the device; under DP the caller all-reduces it first
     if eik and n_surf.numel() > 1:  # the sampler's per-block partial counts (SortedPool.draw(surf_parts=...))

@@ -50,6 +50,62 @@ def importance_chunks(perm, n, bs, down_rate=1):
     return idx, begin, n_chunks, largest
 
 
+class DrawChain:
+    """The whole next large sorted draw — and the next step's opt.zero_grad() — riding on every step's reduction launch
+    (include/shine_hip.h shine_draw_rider): a batch-mode step is then TWO launches, the fused kernel and its reduction.
+
+        chain = pool.draw_chain(n, idx, buckets=(flat_a, flat_b), surf=eikonal)   # idx: int32 [n], the batch every step reads
+        chain.prime()                                                             # draw 0 + pass 1 of draw 1; parity 0 next
+        for k in ...:
+            p = chain.parity
+            fused_train_step(..., opts_p (draw_rider=chain.rider[p]), n_surf=chain.surf_parts[p], pool=pool, idx=idx,
+                             grad_buffers=<views of buckets[p]>)
+            chain.parity ^= 1
+
+    Step k accumulates into buckets[k & 1]; its launch clears buckets[(k + 1) & 1], draws batch k + 1 into idx and runs pass 1 of
+    batch k + 2.  Capture-safe: the stream ids live in device memory; a captured graph bakes the parity of each of its steps in, so
+    replay graphs only where the host's `parity` says the device is (an even number of steps per graph keeps it at 0)."""
+
+    def __init__(self, pool, n, idx, buckets=None, surf=False):
+        dev = pool.device
+        n = int(n)
+        if not (idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == n):
+            raise ValueError("DrawChain: idx must be a contiguous CUDA int32 tensor of n entries")
+        self.pool, self.n, self.idx = pool, n, idx
+        nb = (n + 1 + 1023) // 1024
+        self.state = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.block_sum = (torch.zeros(nb, dtype=torch.float64, device=dev), torch.zeros(nb, dtype=torch.float64, device=dev))
+        self.surf_parts = (pool.surf_parts_buffer(), pool.surf_parts_buffer()) if surf else (None, None)
+        self.buckets = buckets
+        self.parity = 0
+        self.rider = []
+        for p in (0, 1):
+            r = _lib.DrawRider()
+            r.pool_size, r.n, r.seed = pool.size, n, pool.seed
+            r.state, r.parity = self.state.data_ptr(), p
+            r.block_sum[0], r.block_sum[1] = self.block_sum[0].data_ptr(), self.block_sum[1].data_ptr()
+            r.idx_out = idx.data_ptr()
+            if surf:
+                r.surf_bits = pool.surf_bits().data_ptr()
+                r.surf_parts[0], r.surf_parts[1] = self.surf_parts[0].data_ptr(), self.surf_parts[1].data_ptr()
+            if buckets is not None:
+                z = buckets[1 - p]  # the NEXT step's bucket
+                if not (z.is_cuda and z.is_contiguous() and z.data_ptr() % 16 == 0 and (z.numel() * z.element_size()) % 16 == 0):
+                    raise ValueError("DrawChain: the gradient buckets must be contiguous, 16-byte aligned and sized")
+                r.zero_ptr, r.zero_bytes = z.data_ptr(), z.numel() * z.element_size()
+            self.rider.append(r)
+
+    def prime(self, first_stream_id=None):
+        """draw 0 into idx (stream id = the pool's draw count, which moves past the chain's head), pass 1 of draw 1; the
+        caller's buckets[0] must be clean"""
+        sid = int(self.pool.draws if first_stream_id is None else first_stream_id)
+        _lib.check(_lib.lib().shine_draw_rider_prime(C.byref(self.rider[0]), sid, _lib.current_stream_handle()),
+                   "shine_draw_rider_prime")
+        self.first_stream_id = sid
+        self.parity = 0
+        return self
+
+
 class SortedPool:
     def __init__(self, octree, coord, sdf_label, weight, seed=42, canonical=False):
         """`canonical`: order the samples of one node by their original pool index.  The plan's counting sort places the
@@ -199,6 +255,10 @@ class SortedPool:
         if not graph_safe:
             self.draws += 1
         return idx
+
+    def draw_chain(self, n, idx, buckets=None, surf=False):
+        """DrawChain(self, ...): every step's reduction launch draws the next batch (and clears the next step's bucket)"""
+        return DrawChain(self, n, idx, buckets=buckets, surf=surf)
 
     def next_draw(self, n, out=None, surf_parts=None, n_global=None):
         """The graph-replayable draw(n, out=out, surf_parts=...) as a shine_next_draw record, for

@@ -1707,7 +1707,8 @@ def test_b3_gradient_against_the_exact_sum_at_the_scale_of_its_summands(name):
     inv_n = 1.0 if fx["cfg"].get("loss_reduction", "mean") == "sum" else 1.0 / n
     delta = (torch.sigmoid(wide["pred"].double()) - torch.sigmoid(fx["sdf_label"].double() / fx["sigma"])) * inv_n
     exact = float(wide["mlp_grads"][5].double().sum())
-    assert abs(float(delta.sum()) - exact) <= 1e-9 * float(delta.abs().sum())  # (the eikonal term sends nothing to a bias)
+    # (the eikonal term sends nothing to a bias; the oracle's own delta differs from this restatement by its fp32 targets only)
+    assert abs(float(delta.sum()) - exact) <= 1e-7 * float(delta.abs().sum())
     got = float(dec.fused_params()[5].grad.double().sum())
     scale = float(delta.abs().sum())
     print("b3 gradient %s: exact %.6e, HIP %.6e, |err| / sum|delta| = %.2e (cancellation: |sum| / sum|.| = %.2e)" % (
@@ -1761,3 +1762,105 @@ def test_regulariser_riding_on_the_query_equals_its_own_launches(monkeypatch):
         octree2.hierarchical_indices  # (materialised: the composite reads them)
         comp = float(octree2._cal_regularization_composite())
         assert abs(v - own) <= 1e-5 * max(abs(own), 1e-30) and abs(v - comp) <= 1e-5 * max(abs(comp), 1e-30), (v, own, comp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,eik,variant", [(3000, True, 0), (40000, True, 0), (16 * 1024 + 5, False, 0)])
+def test_whole_next_draw_rides_on_the_steps_reduction_launch(n, eik, variant):
+    """sampler.DrawChain (cfg->draw_rider, include/shine_hip.h shine_draw_rider): every step's reduction launch also runs pass 2 of
+    the NEXT draw, pass 1 of the one after it and the zero-fill of the next step's gradient bucket — a batch-mode step is two
+    launches.  Six steps eagerly, then the same six as two replays of ONE captured graph of... (even) steps:
+      * the batch every step reads is bit-identical to the stand-alone sampler's draw with the same stream id
+        (shine_sample_sorted), so is its surface count;
+      * the step's bucket holds what a plain step on that batch leaves (n = 3000 deterministic: bit for bit);
+      * the other bucket is clean when the step's launches are done."""
+    import copy
+
+    from shine_mapping_amd import StepOptions, dp, fused_train_step
+    from shine_mapping_amd.sampler import SortedPool
+
+    wl = _workload("kitti" if eik else "maicity", 3)
+    octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
+    octree._require_tables(with_ranks=True)
+    params = list(octree.hier_features) + dec.fused_params()
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    flat_a = dp.GradReducer(params).flat
+    flat_b = torch.zeros_like(flat_a)
+
+    def views(flat):
+        out, off = [], 0
+        for p in params:
+            out.append(flat[off: off + p.numel()].view_as(p))
+            off += p.numel()
+        return out[:len(octree.hier_features)], out[len(octree.hier_features):]
+
+    bucket_views = (views(flat_a), views(flat_b))
+    det = n <= 4096
+    opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=eik, weight_e=cfg.weight_e, deterministic=det, kernel_variant=variant)
+    sp = SortedPool(octree, wl.pool.coord, wl.pool.sdf_label, wl.pool.weight, seed=11)
+    steps, sid0 = 6, 40
+    # reference: stand-alone draws with explicit stream ids + plain steps
+    want_idx, want_grad, want_surf = [], [], []
+    for k in range(steps + 2):
+        sp.draws = sid0 + k
+        idx = sp.draw(n).clone()
+        want_idx.append(idx)
+        want_surf.append(int((sp.weight[idx.long()] > 0).sum()))
+        if k < steps:
+            flat_a.zero_()
+            fused_train_step(octree, dec, None, None, None, opts, pool=sp, idx=idx)
+            want_grad.append(flat_a.clone())
+    idx_buf = torch.empty(n, dtype=torch.int32, device="cuda")
+    chain = sp.draw_chain(n, idx_buf, buckets=(flat_a, flat_b), surf=eik)
+    step_opts = []
+    for p in (0, 1):
+        o = copy.copy(opts)
+        o.draw_rider = chain.rider[p]
+        step_opts.append(o)
+    seen = {k: torch.empty_like(flat_a) for k in ("grad",)}
+    log = []
+
+    def step(p, record):
+        used = idx_buf.clone()  # the batch this step reads
+        surf = chain.surf_parts[p].sum().clone() if eik else None
+        fused_train_step(octree, dec, None, None, None, step_opts[p], n_surf=chain.surf_parts[p] if eik else None, pool=sp,
+                         idx=idx_buf, grad_buffers=bucket_views[p])
+        record.append((used, surf, (flat_a, flat_b)[p].clone(), (flat_a, flat_b)[1 - p].abs().max().clone()))
+
+    def check(record, first):
+        torch.cuda.synchronize()
+        for j, (used, surf, grad, other) in enumerate(record):
+            k = first + j
+            assert torch.equal(used, want_idx[k]), "batch of step %d" % k
+            if eik:
+                assert int(surf) == want_surf[k], "surface count of step %d" % k
+            if det:
+                assert torch.equal(grad, want_grad[k]), "gradients of step %d" % k
+            else:
+                assert float((grad - want_grad[k]).abs().max()) <= 1e-6 * float(want_grad[k].abs().max()), "gradients of step %d" % k
+            assert float(other) == 0.0, "the next step's bucket is not clean after step %d" % k
+
+    # eagerly
+    flat_a.zero_()
+    flat_b.fill_(3.0)  # (dirty: step 0's launch must clear it before step 1 accumulates)
+    chain.prime(sid0)
+    rec = []
+    for k in range(steps):
+        step(chain.parity, rec)
+        chain.parity ^= 1
+    check(rec, 0)
+    assert torch.equal(idx_buf, want_idx[steps])  # the batch the NEXT step would read
+    # one captured graph of 3 x 2 steps, primed again, replayed once (stream ids advance on the device)
+    flat_a.zero_()
+    flat_b.fill_(3.0)
+    chain.prime(sid0)
+    torch.cuda.synchronize()
+    rec2 = []
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(steps):
+            step(k & 1, rec2)
+    g.replay()
+    check(rec2, 0)
+    assert torch.equal(idx_buf, want_idx[steps])
