@@ -763,7 +763,7 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, cpu_baselin
         cfg->draw_rider) — the stand-alone draw launch of rounds 3-5 (7 us + a launch gap of an 86 us step) is gone.  Two gradient
         buckets alternate: step k accumulates into bucket k & 1, which stays intact — the step's result — until step k + 1's launch
         clears it.  A captured graph bakes each step's parity in; `run` replays the graph of U steps only where the host's parity
-        says the device is at 0 and single-step graphs (one per parity) otherwise."""
+        says the device is (one graph of U steps and one single-step graph per starting parity)."""
         import copy
 
         for p in params:
@@ -800,7 +800,7 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, cpu_baselin
                 chain.parity ^= 1
             return out
 
-        launch, g1, gu, loss1, lossu = "eager", [None, None], None, [None, None], None
+        launch, g1, gu, loss1, lossu = "eager", [None, None], [None, None], [None, None], [None, None]
         if not args.no_graph:
             try:
                 eager(4)  # warm caches / allocate workspaces outside capture (an even number: parity back at 0)
@@ -809,17 +809,18 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, cpu_baselin
                     g1[par] = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g1[par]):
                         loss1[par] = step_body(par)
-                if U > 1:
-                    gu = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gu):
-                        for j in range(U):
-                            lossu = step_body(j & 1)
+                if U > 1:  # one graph of U steps per starting parity (the driver's W = 5 warm-up steps leave the chain at parity 1)
+                    for par in (0, 1):
+                        gu[par] = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gu[par]):
+                            for j in range(U):
+                                lossu[par] = step_body((par + j) & 1)
                 launch = ("hipgraph, %d step%s per replay, fresh batch per step; a step = 2 launches: the fused kernel and its "
                           "reduction, which also draws the next batch and clears the next step's bucket (two buckets alternate)" % (
                               U, "s" if U > 1 else ""))
             except Exception as e:
                 print("graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
-                g1, gu, launch = [None, None], None, "eager"
+                g1, gu, launch = [None, None], [None, None], "eager"
                 torch.cuda.synchronize()
 
         def run(k):
@@ -829,9 +830,9 @@ def run_batch(args, workload, dist, world, rank, dev, steps, warmup, cpu_baselin
                 out = eager(k)
             else:
                 while k > 0:
-                    if gu is not None and k >= U and chain.parity == 0:
-                        gu.replay()
-                        out, k = lossu, k - U
+                    if gu[chain.parity] is not None and k >= U:
+                        gu[chain.parity].replay()
+                        out, k = lossu[chain.parity], k - U
                         chain.parity ^= U & 1
                     else:
                         g1[chain.parity].replay()

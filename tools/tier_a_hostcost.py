@@ -30,6 +30,10 @@ def incremental():
         opt = optim.setup_optimizer(cfg, list(octree.parameters()), list(geo_mlp.parameters()))
         pool = type("P", (), {"coord": coord, "sdf_label": label, "weight": weight})()
         torch.cuda.synchronize()
+        prof = None
+        if os.environ.get("PROFILE") and fi == len(frames) - 1:  # cProfile over the last frame's iterations
+            prof = cProfile.Profile()
+            prof.enable()
         for it in range(50):
             t = [pc()]
             c, sdf_label, w = synth.draw_batch(pool, 4096, gen); t.append(pc())
@@ -49,6 +53,10 @@ def incremental():
                 for i in range(len(names)):
                     acc[i] += t[i + 1] - t[i]
         torch.cuda.synchronize()
+        if prof is not None:
+            prof.disable()
+            print("== cProfile of the last frame's 50 iterations (divide by 50), by own time")
+            pstats.Stats(prof).sort_stats("tottime").print_stats(40)
         opt.zero_grad(set_to_none=True)
         data = type("D", (), {"coord_pool": coord, "sdf_label_pool": label})()
         incre_learning.cal_feature_importance(data, octree, geo_mlp, cfg.sigma_sigmoid, 4096, 2, "sum")
