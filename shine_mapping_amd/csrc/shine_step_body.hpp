@@ -15,6 +15,10 @@ constexpr int V3_BIG = SHINE_V3_BIG;           // waves per workgroup of the ful
 #define SHINE_V3_GB 4
 #endif
 constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch (register budget: 8 floats each)
+#ifndef SHINE_V3_ABLATE  // measurement builds only (tools/mk_variant.py -DSHINE_V3_ABLATE=bits; the product is 0): 1 no feature-grad
+#define SHINE_V3_ABLATE 0  // atomics, 8 no row gathers (zeros instead) — how much of the kernel each holds exclusively (far_ablate.py);
+                           // 16: s_waitcnt vmcnt(0) behind every tile's scatter
+#endif
 #ifndef SHINE_V3_PROFBUILD  // 1: also instantiate the kernels with per-wave phase cycle counters (AB_PROF of tools/ab_build.py)
 #define SHINE_V3_PROFBUILD 0
 #endif
@@ -56,6 +60,9 @@ constexpr int V3_GB = SHINE_V3_GB;             // corner rows gathered per batch
 // one — cost the cache-resident kitti map 298 us against 225: profiles/r05_ab_experiments.txt block 4).  The eight corners of a
 // node sit in eight different slots, so no two lane groups meet in one; nothing else writes the lattice between a run's peek
 // and its close (closes are the only writes, and a wave closes one run per level at a time).
+__device__ __forceinline__ void grad_atomic(float* p, float v) {
+  if (!(SHINE_V3_ABLATE & 1)) atomic_add_f32(p, v);
+}
 __device__ __forceinline__ void lattice_peek(const float* lat, int packed, int sq, int& T, float& V) {
   const int slot = (packed >> V3_ROW_BITS) & (V3_CSLOTS - 1);
   T = reinterpret_cast<const int*>(lat)[slot];
@@ -66,7 +73,7 @@ __device__ __forceinline__ void lattice_close(float* lat, float* gbase, int pack
   const bool same = T == row;
   lat[V3_CSLOTS + slot * F + sq] = same ? V + v : v;
   reinterpret_cast<int*>(lat)[slot] = row;  // (the group's eight lanes write the same word)
-  if (!same && T >= 0) atomic_add_f32(gbase + ((unsigned int)T << 3) + sq, V);
+  if (!same && T >= 0) grad_atomic(gbase + ((unsigned int)T << 3) + sq, V);
 }
 
 // RECORD pools (a.pool_mode == 2, cfg->sorted_input 3): the pool is ONE 32-byte record per sample instead of four arrays read at
@@ -378,6 +385,10 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES, FAR
 #pragma unroll
         for (int c = 0; c < V3_GB; ++c) {  // a miss reads row 0 with weight 0 (no branches)
           const float* row = lv_feat + (size_t)(hit ? (unsigned int)ids[cb + c] : 0u) * F;
+          if (SHINE_V3_ABLATE & 8) {
+            r0[c] = r1[c] = make_float4(0.01f * (float)ids[cb + c], 0.f, 0.f, 0.f);  // (keeps the ids live, no row traffic)
+            continue;
+          }
           r0[c] = *reinterpret_cast<const float4*>(row);
           r1[c] = *reinterpret_cast<const float4*>(row + 4);
         }
@@ -835,7 +846,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES, FAR
             if (cm & (1u << p2)) {  // a new node (or a run of misses) starts here: close the open run
               if (rhit) {  // scalar branch
                 if (FAR) lattice_close(lat, gbase, rid, sq, racc, lt, lv);
-                else atomic_add_f32(gbase + (unsigned int)rid, racc);
+                else grad_atomic(gbase + (unsigned int)rid, racc);
               }
               racc = 0.f;
               // float offset of this lane's (corner row, feature); FAR: the staged id itself (row | lattice slot << 25)
@@ -856,6 +867,7 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES, FAR
       }
     }
     wave_lds_fence();
+    if (SHINE_V3_ABLATE & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (measurement: wait for the atomics' acknowledgements)
     SHINE_STAMP(4)  // scatter
   }
 
@@ -877,10 +889,10 @@ __device__ __forceinline__ void step_body(const V1Args& a, StepShared<WAVES, FAR
       for (int j = 0; j < 8; ++j) {
         const int slot = 8 * sc + j;
         const int T = reinterpret_cast<const int*>(lat)[slot];
-        if (T >= 0) atomic_add_f32(gbase + ((unsigned int)T << 3) + sq, lat[V3_CSLOTS + slot * F + sq]);
+        if (T >= 0) grad_atomic(gbase + ((unsigned int)T << 3) + sq, lat[V3_CSLOTS + slot * F + sq]);
       }
     } else if (run_hit[s]) {
-      atomic_add_f32(gbase + (unsigned int)run_id[s], run_acc[s]);
+      grad_atomic(gbase + (unsigned int)run_id[s], run_acc[s]);
     }
   }
   __syncthreads();  // every wave is done with its staging region: it now holds the wave's partial vector
