@@ -20,6 +20,24 @@ __global__ void k_rows(const int* __restrict__ rows, float* __restrict__ table, 
   }
 }
 
+// Round 6: the same 8 rows x 32 B per wave instruction as 64-bit atomics — lane = (row, feature PAIR), 32 active lanes: is the
+// memory side's rate per lane (then wider atomics halve the time for the same payload) or per byte?  WIDE 1: u64 integer add
+// (two fixed-point halves could share one), 2: f64 add.
+template <int WIDE>
+__global__ void k_rows_wide(const int* __restrict__ rows, float* __restrict__ table, int wave_ops, int per_wave) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  for (int j = 0; j < per_wave; ++j) {
+    const long long op = wave * per_wave + j;
+    if (op >= wave_ops) return;
+    if (lane >= 32) continue;
+    const int row = rows[op * 8 + (lane >> 2)];
+    void* p = &table[(long long)row * 8 + 2 * (lane & 3)];
+    if (WIDE == 1) atomicAdd(reinterpret_cast<unsigned long long*>(p), 0x0000000100000001ull);
+    else unsafeAtomicAdd(reinterpret_cast<double*>(p), 1.0);
+  }
+}
+
 int main() {
   const int wave_ops = 131072;  // the headline step: 8.0 node runs per 16-point tile x 16384 tiles
   for (long long M : {400000ll, 4000000ll}) {
@@ -52,6 +70,25 @@ int main() {
         printf("M = %lld rows, %s, %d ops per wave: %.1f us for %d wave-atomics (8 rows x 32 B each) = %.1f row-atomics/ns, %.2f fp32 atomics per ns\n",
                M, mode == 0 ? "rows uniform" : mode == 1 ? "8 rows within 32 of a random base" : "neighbouring bases (3 rows apart)",
                per_wave, us, wave_ops, wave_ops * 8 / us / 1e3, wave_ops * 64 / us / 1e3);
+      }
+      for (int wide = 1; wide <= 2; ++wide) {
+        const int per_wave = 8;
+        const int waves = (wave_ops + per_wave - 1) / per_wave;
+        const int blocks = (waves * 64 + 255) / 256;
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        auto launch = [&]() {
+          if (wide == 1) k_rows_wide<1><<<blocks, 256>>>(rows, table, wave_ops, per_wave);
+          else k_rows_wide<2><<<blocks, 256>>>(rows, table, wave_ops, per_wave);
+        };
+        launch();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a));
+        for (int r = 0; r < 20; ++r) launch();
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        const double us = ms * 1000.0 / 20;
+        printf("M = %lld rows, mode %d, 8 ops per wave, 64-BIT %s atomics (32 lanes per instruction, the same 8 rows x 32 B): %.1f us = %.1f row-atomics/ns, %.2f lane atomics per ns\n",
+               M, mode, wide == 1 ? "u64 add" : "f64 add", us, wave_ops * 8 / us / 1e3, wave_ops * 32 / us / 1e3);
       }
       CK(hipFree(rows)); CK(hipFree(table));
     }
