@@ -13,7 +13,9 @@ Workloads (synthetic, shine_mapping_amd/synth.py; BASELINE.json configs):
                fused Adam, importance sweep, octree growth on the device, one HIP graph per iteration
 A "step" (batch workloads) is one pass of the hot path over one batch resident in HBM: sorted draw from the
 node-ordered pool (also clears the dense grads, i.e. opt.zero_grad) -> fused query + decode + loss + backward
-(shine_batch.py:123-209 minus the optimiser) [-> gradient exchange under data parallelism].  For ncd-incre a step is
+(shine_batch.py:123-209 minus the optimiser) [-> gradient exchange under data parallelism].  On one rank with batches of
+<= 2^18 points (--draw-rider auto) the draw and the zero-fill of step i + 1 ride on the reduction launch of step i: a step is
+two launches — the fused kernel and its reduction — over two alternating gradient buckets.  For ncd-incre a step is
 one frame.  With N>1 ranks (torch.distributed.run, one process per GPU, RCCL): ONE global sorted draw (same seed
 everywhere), rank r takes the r-th contiguous slice of P points (weak scaling), global normalisers come from the common
 draw, and the grads are exchanged (--exchange).

@@ -278,7 +278,7 @@ int prepare_finish(FinLaunch* out, const shine_step_config* cfg, int64_t n, cons
     }
   }
   a.dec_units = L + (u - a.feat_units);  // the L trash rows first, then the decoder
-  V2Geometry g = v3_geometry(n);
+  V2Geometry g = v3_geometry(n, cfg->kernel_variant >> 8);
   if ((cfg->kernel_variant >> 8) & 64) g.blocks = 1;  // the deterministic single-workgroup launch
   a.partials = (const float*)workspace;
   a.nblocks = (int)g.blocks;

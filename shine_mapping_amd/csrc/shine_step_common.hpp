@@ -130,7 +130,7 @@ struct V2Geometry {
   long long waves, chunk, blocks, tiles;
   int wg_waves;  // waves per workgroup
 };
-V2Geometry v3_geometry(long long n);  // shine_step_v3.hip: tiles dealt evenly to every resident wave slot
+V2Geometry v3_geometry(long long n, int ablate = 0);  // shine_step_v3.hip: tiles dealt evenly to every resident wave slot
 long long v3_lds_bytes(int wg_waves);
 
 // measurement aid (shine_debug_set_profile_buffer): per-wave phase cycle counters or null

@@ -48,7 +48,7 @@ __global__ void k_selftest_permlane(const float* x, const float* y, float* o32, 
   o16[lane] = xsum16(x[lane], y[lane]);
 }
 
-V2Geometry v3_geometry(long long n) {
+V2Geometry v3_geometry(long long n, int ablate) {
   V2Geometry g;
   long long tiles = (n + V3_TP - 1) / V3_TP;
   if (tiles < 1) tiles = 1;
@@ -57,6 +57,13 @@ V2Geometry v3_geometry(long long n) {
   const long long max_waves = 256 * V3_BIG;  // resident waves of the full-chip launch
   const long long waves = tiles < max_waves ? tiles : max_waves;
   g.blocks = (waves + g.wg_waves - 1) / g.wg_waves;
+  // Round 6 (measured: tools/small_batch_geometry.py, profiles/r06_small_batch_geometry.txt): up to 512
+  // tiles as ONE tile per workgroup — one active wave on every CU instead of four on a quarter of the chip — takes the kernel
+  // alone from 11.9 to 10.7 us at N = 4096 (13.6 -> 12.5 at 8192, nothing from 1024 tiles on), but every workgroup leaves a
+  // partial vector and the iteration's tail (k_finish) then adds up 256 of them instead of 64: the whole graphed iteration
+  // 38.6 -> 43.0 us, ncd-incre 610 -> 518 frames/s.  So the product keeps four tiles per workgroup; kernel_variant bit 0x8000
+  // asks for the other form (measurement).
+  if (tiles <= 512 && (ablate & 128)) g.blocks = tiles;
   g.waves = g.blocks * g.wg_waves;  // every launched wave takes its share (a wave beyond the tile count gets none)
   g.chunk = 0;
   return g;
@@ -127,7 +134,7 @@ int prepare_step_v3(StepLaunch* out, const shine_tables* t, const shine_step_con
   if (rc != SHINE_OK) return rc;
   out->fn = nullptr;
   if (n == 0) return SHINE_OK;
-  V2Geometry g = v3_geometry(n);
+  V2Geometry g = v3_geometry(n, a.ablate);
   if (a.ablate & 64) {  // kernel_variant bit 0x4000: the deterministic (single-wave) launch of the test suite
     g.blocks = 1;
     g.wg_waves = 4;
@@ -242,7 +249,7 @@ extern "C" int shine_interp_sdf_backward(const shine_tables* t, const shine_step
   a.ext_delta = grad_pred;
   a.ext_q = grad_g;
   a.inv_n = 1.0f;
-  V2Geometry g = v3_geometry(n);
+  V2Geometry g = v3_geometry(n, a.ablate);
   if (a.ablate & 64) {  // kernel_variant bit 0x4000: the deterministic (single-wave) launch of the test suite, as in prepare_step_v3
     g.blocks = 1;
     g.wg_waves = 4;
