@@ -1864,3 +1864,44 @@ def test_whole_next_draw_rides_on_the_steps_reduction_launch(n, eik, variant):
     g.replay()
     check(rec2, 0)
     assert torch.equal(idx_buf, want_idx[steps])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levels", [1, 2, 3, 4])
+@pytest.mark.parametrize("eik", [False, True])
+def test_record_pool_equals_the_same_batch_handed_over_as_arrays(levels, eik):
+    """Round 6: a pool batch is read from ONE 32-byte record per sample (csrc/shine_step_body.hpp RecLayout: the weight inside the
+    record for L <= 3, a separate array for L = 4; slots at dword 5 / 4).  For every level count and both losses the step on a
+    drawn pool batch must equal the step on the SAME samples handed over as plain arrays (get_batch -> a planned batch): pred in the
+    batch's order bit for bit, loss and every gradient tensor to 1e-6 of max-abs (the plan may visit a node's samples in another
+    order), with loss_weight_on as well (the weight is then read by the BCE build too)."""
+    from shine_mapping_amd import StepOptions, dp, fused_train_step
+    from shine_mapping_amd.sampler import SortedPool
+
+    wl = _workload("kitti" if eik else "maicity", levels, frames=4)
+    octree, dec, cfg = wl.octree, wl.decoder, wl.cfg
+    octree._require_tables(with_ranks=True)
+    sp = SortedPool(octree, wl.pool.coord, wl.pool.sdf_label, wl.pool.weight, seed=levels)
+    assert sp.rec is not None and sp.rec.shape[1] == 8 and (sp._weight_sep is not None) == (levels == 4)
+    n = 5003
+    idx = sp.draw(n)
+    c, l, w = sp.get_batch(idx)
+    assert torch.equal(c, sp.coord[idx.long()]) and torch.equal(w, sp.weight[idx.long()])  # (views of the records)
+    params = list(octree.hier_features) + dec.fused_params()
+    for weighted in (False, True):
+        opts = StepOptions(sigma=cfg.sigma_sigmoid, ekional_loss_on=eik, weight_e=cfg.weight_e, loss_weight_on=weighted)
+        for p in params:
+            p.grad = None
+        loss_p, pred_p, g_p = fused_train_step(octree, dec, None, None, None, opts, want_grad_x=True, pool=sp, idx=idx)
+        grads_p = [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        perm, slots = dp.plan_batch(octree, c)
+        loss_a, pred_a, g_a = fused_train_step(octree, dec, c, l, w, opts, want_grad_x=True, perm=perm, slots=slots)
+        torch.cuda.synchronize()
+        assert torch.equal(pred_p, pred_a)
+        if eik:
+            assert torch.equal(g_p, g_a)
+        assert abs(float(loss_p) - float(loss_a)) <= 1e-6 * max(1.0, abs(float(loss_a)))
+        for a_, b_ in zip(grads_p, [p.grad for p in params]):
+            assert rel_err(a_, b_) <= 1e-6, (levels, eik, weighted)
