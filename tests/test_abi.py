@@ -189,3 +189,32 @@ def test_device_constants_on_the_host():
     assert a.tolist() == pytest.approx([0.01] * 3) and a.dtype == torch.float32
     assert b.tolist() == [3, 0, 3, 0] and b.dtype == torch.int64
     assert _lib.device_constants([], torch.float32, "cpu").numel() == 0
+
+
+def test_extension_build_failure_is_remembered_and_not_fatal(tmp_path, monkeypatch):
+    """lib/_shine_ext.so (Tier A's C++ autograd nodes) is optional.  With a host compiler that fails, build()
+    still returns the HIP library, warns once, leaves no stale extension behind and remembers the failure for this input (its own
+    stamp: sources' digest + torch version + ABI flag) instead of recompiling everything at every call.  Runs on copies of the
+    stamps in a scratch directory: the tree's own libraries are not touched."""
+    import shutil
+    import warnings
+
+    import pytest
+
+    from shine_mapping_amd import build
+
+    build.build(verbose=False)  # (the tree is up to date)
+    real_stamp = os.path.join(build.LIBDIR, "libshine_hip.stamp")
+    monkeypatch.setattr(build, "LIBDIR", str(tmp_path))
+    monkeypatch.setattr(build, "EXT_LIB", str(tmp_path / "_shine_ext.so"))
+    shutil.copy(real_stamp, tmp_path / "libshine_hip.stamp")
+    monkeypatch.setenv("CXX", "/bin/false")
+    with pytest.warns(UserWarning, match="was not built"):
+        assert build.build(verbose=False) == build.LIB
+    assert not os.path.exists(build.EXT_LIB)
+    assert open(tmp_path / "_shine_ext.stamp").read().endswith(":failed")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # remembered: no second attempt, no second warning
+        assert build.build(verbose=False) == build.LIB
+    # another torch build / ABI flag is another input: the extension's stamp no longer matches
+    assert build._ext_digest("x") != build._ext_digest("y")
