@@ -42,7 +42,8 @@ def _digest():
         p = os.path.join(CSRC, f)
         if os.path.isfile(p):
             h.update(f.encode())
-            h.update(open(p, "rb").read())
+            with open(p, "rb") as f:
+                h.update(f.read())
     h.update(" ".join(f for f in FLAGS if not os.path.isabs(f)).encode())  # (not the checkout's own path: the snapshot on a GPU box
     #                                                                          lives elsewhere and must not rebuild for that)
     return h.hexdigest()
@@ -61,7 +62,15 @@ def _ext_digest(hip_digest: str) -> str:
 
 
 def _read(path):
-    return open(path).read() if os.path.isfile(path) else None
+    if not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        return f.read()
+
+
+def _write(path, text):
+    with open(path, "w") as f:
+        f.write(text)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -111,7 +120,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     link(LIB, product_objs)
     # the check library: the product's objects + the lane-per-point reference step
     link(CHECK_LIB, product_objs + check_objs)
-    open(stamp, "w").write(dig)  # the HIP libraries stand on their own: the extension below is optional
+    _write(stamp, dig)  # the HIP libraries stand on their own: the extension below is optional
     _build_extension_optional(verbose, ext_stamp, ext_dig)
     return LIB
 
@@ -121,13 +130,13 @@ def _build_extension_optional(verbose, ext_stamp, ext_dig):
     the Python autograd nodes (autograd_ops.py) serve — warn, remember the failure for this input, carry on."""
     try:
         build_extension(verbose)
-        open(ext_stamp, "w").write(ext_dig)
+        _write(ext_stamp, ext_dig)
     except Exception as e:
         import warnings
 
         if os.path.isfile(EXT_LIB):
             os.remove(EXT_LIB)  # (a stale library from another torch would fail at import with undefined symbols)
-        open(ext_stamp, "w").write(ext_dig + ":failed")
+        _write(ext_stamp, ext_dig + ":failed")
         warnings.warn("shine_mapping_amd: lib/_shine_ext.so (Tier A's C++ autograd nodes) was not built — the Python nodes are used "
                       "instead (same launches, more host time per iteration): %s" % str(e)[:2000])
 
