@@ -96,9 +96,13 @@ class DrawChain:
             self.rider.append(r)
 
     def prime(self, first_stream_id=None):
-        """draw 0 into idx (stream id = the pool's draw count, which moves past the chain's head), pass 1 of draw 1; the
-        caller's buckets[0] must be clean"""
-        sid = int(self.pool.draws if first_stream_id is None else first_stream_id)
+        """draw 0 into idx, pass 1 of draw 1; the caller's buckets[0] must be clean.  Stream ids: every chain of a pool gets a
+        range of its own (chain number << 40, + the pool's draw count), so its batches repeat neither the stand-alone draws of
+        the pool (stream ids 0, 1, 2, ...) nor another chain's; `first_stream_id` pins it (tests: the stand-alone sampler's ids)"""
+        if first_stream_id is None:
+            self.pool._chains = getattr(self.pool, "_chains", 0) + 1
+            first_stream_id = (self.pool._chains << 40) + int(self.pool.draws)
+        sid = int(first_stream_id)
         _lib.check(_lib.lib().shine_draw_rider_prime(C.byref(self.rider[0]), sid, _lib.current_stream_handle()),
                    "shine_draw_rider_prime")
         self.first_stream_id = sid
